@@ -1,0 +1,122 @@
+// sim_types.h -- plain data shared by the device code (sim_device.h) and its launchers.
+#pragma once
+#include <stdint.h>
+
+namespace modle_dev {
+
+using u8 = uint8_t;
+using u16 = uint16_t;
+using u32 = uint32_t;
+using u64 = uint64_t;
+using i32 = int32_t;
+using i64 = int64_t;
+using f64 = double;
+
+// Positions and binding epochs are held as 32-bit values on the device (every human chromosome
+// is < 2^32 bp; the host rejects longer intervals).  A released LEF has all three at UNBOUND,
+// the 32-bit image of the reference's numeric_limits<bp_t>::max() marker
+// (reference: src/libmodle/internal/extrusion_factors_impl.hpp:96-131).
+constexpr u32 UNBOUND = 0xFFFFFFFFu;
+
+// Collision word, 32-bit image of Collision<uint_fast32_t>
+// (reference: src/libmodle/cpu/include/modle/collision_encoding.hpp:54-109): index in the low 24
+// bits, the 5 event flags above them.
+constexpr u32 CW_SHIFT = 24;
+constexpr u32 CW_INDEX_MASK = 0x00FFFFFFu;
+constexpr u32 EV_COLLISION = 0x10u;
+constexpr u32 EV_CHROM_BOUNDARY = 0x08u;
+constexpr u32 EV_LEF_BAR = 0x04u;
+constexpr u32 EV_LEF_LEF_PRIMARY = 0x02u;
+constexpr u32 EV_LEF_LEF_SECONDARY = 0x01u;
+
+constexpr u32 DIR_FWD = 1u;
+constexpr u32 DIR_REV = 2u;
+constexpr u32 CS_NOISIFY = 1u;
+constexpr u32 CS_TAD = 2u;
+constexpr u32 CS_LOOP = 4u;
+
+// PRNG block generator geometry: every lane produces RNG_CHUNK consecutive outputs per block.
+constexpr u32 RNG_CHUNK = 8;
+constexpr u32 RNG_BLOCK = 64 * RNG_CHUNK;      // raws per block
+constexpr u32 RNG_RING = 2 * RNG_BLOCK;        // raws held in LDS per wave
+constexpr u32 JUMP_TABLE_WORDS = 64 * 16 * 4;  // u64 words (32 KiB)
+
+// Parameters of the path, digested once on the host from modle_hip_config.
+struct Params {
+  f64 rev_speed, fwd_speed;                // after burn-in
+  f64 rev_speed_burnin, fwd_speed_burnin;
+  f64 rev_std, fwd_std;
+  f64 p_release, p_release_burnin;
+  f64 hard_stall_mult, soft_stall_mult;
+  f64 p_bypass;
+  f64 pblock_major, pblock_minor;
+  f64 tad_to_loop_ratio;
+  f64 gev_mu, gev_sigma, gev_xi;
+  f64 target_contact_density;
+  u64 min_burnin_epochs, max_burnin_epochs;
+  u64 burnin_target_epochs_for_lef_activation;
+  u32 bin_size;
+  u32 sampling_strategy;
+  u32 skip_burnin;
+  u32 hist_len;   // burnin_history_length
+  u32 window;     // burnin_smoothing_window_size
+  u32 track_1d;
+};
+
+struct Interval {
+  u32 start, end;  // [start, end)
+  u32 n_barriers;
+  u32 pad_;
+  const u32* bar_pos;        // sorted ascending
+  const u8* bar_dir;         // DIR_FWD / DIR_REV (blocking direction)
+  const f64* bar_stp_active;
+  const f64* bar_stp_inactive;
+  const f64* bar_occupancy;  // compute_occupancy_from_stp(stp_active, stp_inactive)
+  u32* contacts;             // band matrix, nrows*ncols+1 words
+  u64* occupancy_1d;         // ncols words or nullptr
+  u64* missed_updates;       // one counter
+  u64 nrows, ncols;
+};
+
+struct Task {
+  u32 interval;
+  u32 num_lefs;
+  u64 cell_id;
+  u64 num_target_epochs;
+  u64 num_target_contacts;
+  u64 contacts_per_epoch;  // Simulation::compute_contacts_per_epoch(num_lefs)
+  u64 prng[4];
+};
+
+struct CellResult {
+  u64 epochs, burnin_epochs, num_contacts, raws_consumed;
+  u64 prng_final[4];
+  u64 sum_active_lefs, sampling_events, sim_epochs;
+};
+
+// Per-wave scratch in device memory (sized for the largest task of the launch).
+struct Workspace {
+  u32 *rev_pos, *fwd_pos, *epoch;       // by LEF id
+  u32 *rev_rank, *fwd_rank;             // LEF ids in 5'->3' order of their rev / fwd unit
+  u32 *rev_moves, *fwd_moves;           // by LEF id
+  u32 *rev_coll, *fwd_coll;             // collision words by LEF id
+  u32 *tmp_a, *tmp_b, *tmp_c, *tmp_d;   // L words each
+  u64* sort_keys;                       // pow2ceil(L) words
+  f64* hist;                            // 2 * hist_len doubles (burn-in history)
+  u8* bar_active;                       // n_barriers bytes
+  u32 capacity_lefs, capacity_barriers;
+};
+
+// LDS-resident (or host-emulated) per-wave context.
+struct WaveLds {
+  u64* ring;              // RNG_RING raws
+  const u64* jump_table;  // T^RNG_BLOCK nibble table
+  const f64* zig_norm_x;  // 129
+  const f64* zig_norm_y;  // 129
+  const f64* zig_exp_x;   // 257
+  const f64* zig_exp_y;   // 257
+  u32* list;              // small per-wave list (LIST_CAP entries)
+};
+constexpr u32 LIST_CAP = 256;
+
+}  // namespace modle_dev

@@ -1,0 +1,82 @@
+// wave_emu.cpp -- fiber scheduler of the lane emulator (see wave_emu.h).  TEST INFRASTRUCTURE.
+#include "wave_emu.h"
+
+namespace wave_emu {
+
+thread_local WaveRuntime* g_rt = nullptr;
+
+// callee-saved register context switch (SysV x86-64)
+asm(R"(
+.text
+.globl modle_emu_switch
+.type modle_emu_switch,@function
+modle_emu_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size modle_emu_switch,.-modle_emu_switch
+)");
+
+static void lane_entry() {
+  WaveRuntime* rt = g_rt;
+  rt->body(rt->arg);
+  const int me = rt->cur;
+  rt->done[me] = true;
+  int nxt = -1;
+  for (int k = 1; k <= kLanes; ++k) {
+    const int c = (me + k) % kLanes;
+    if (!rt->done[c]) {
+      nxt = c;
+      break;
+    }
+  }
+  void* dummy;
+  if (nxt < 0) {
+    modle_emu_switch(&dummy, rt->main_sp);
+  } else {
+    rt->cur = nxt;
+    modle_emu_switch(&dummy, rt->lane_sp[nxt]);
+  }
+  abort();  // a finished lane is never resumed
+}
+
+void run_wave(void (*body)(void*), void* arg) {
+  constexpr size_t kStack = 512 * 1024;
+  WaveRuntime rt;
+  memset(&rt, 0, sizeof(rt));
+  rt.stacks = static_cast<char*>(aligned_alloc(64, kStack * kLanes));
+  rt.body = body;
+  rt.arg = arg;
+  for (int l = 0; l < kLanes; ++l) {
+    for (int b = 0; b < 2; ++b) rt.slots[b][l].line = -1;
+    char* top = rt.stacks + kStack * (l + 1);
+    uintptr_t a = reinterpret_cast<uintptr_t>(top) & ~uintptr_t(15);
+    a -= 16;  // return-address slot, 16-byte aligned
+    void** sp = reinterpret_cast<void**>(a);
+    sp[0] = reinterpret_cast<void*>(&lane_entry);
+    sp[1] = nullptr;
+    sp -= 6;  // rbp rbx r12 r13 r14 r15
+    for (int k = 0; k < 6; ++k) sp[k] = nullptr;
+    rt.lane_sp[l] = sp;
+  }
+  WaveRuntime* prev = g_rt;
+  g_rt = &rt;
+  rt.cur = 0;
+  modle_emu_switch(&rt.main_sp, rt.lane_sp[0]);
+  g_rt = prev;
+  free(rt.stacks);
+}
+
+}  // namespace wave_emu

@@ -1,0 +1,148 @@
+// wave_emu.h -- CPU emulation of the wavefront vocabulary of modle_amd/csrc/wave_hip.h.
+//
+// TEST INFRASTRUCTURE.  The 64 lanes of a wave run as cooperative fibers on one host thread.  A
+// lane runs until it reaches a collective (ballot / shuffle / sync), deposits its operand and
+// yields to the next lane; when control comes back every lane has deposited, so the collective
+// can be evaluated.  Slots are double-buffered because a lane can be at most one collective
+// ahead of another.  Every collective carries the source line it was issued from and the
+// emulator aborts when lanes meet at different lines: wave-divergent collectives (which would
+// be undefined on hardware) are caught here.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MODLE_DEV static inline __attribute__((always_inline))
+#define MODLE_DEV_NOINLINE static __attribute__((noinline))
+
+namespace wave_emu {
+
+constexpr int kLanes = 64;
+
+struct Slot {
+  uint64_t v[2];
+  int line;
+};
+
+struct WaveRuntime {
+  void* lane_sp[kLanes];
+  void* main_sp;
+  char* stacks;
+  int cur;
+  bool done[kLanes];
+  Slot slots[2][kLanes];
+  unsigned coll_count[kLanes];
+  void (*body)(void*);
+  void* arg;
+};
+
+extern thread_local WaveRuntime* g_rt;
+
+extern "C" void modle_emu_switch(void** save_sp, void* load_sp);
+
+inline void yield_next() {
+  WaveRuntime* rt = g_rt;
+  const int me = rt->cur;
+  int nxt = me;
+  for (int k = 1; k <= kLanes; ++k) {
+    const int c = (me + k) % kLanes;
+    if (!rt->done[c]) {
+      nxt = c;
+      break;
+    }
+  }
+  if (nxt == me) return;
+  rt->cur = nxt;
+  modle_emu_switch(&rt->lane_sp[me], rt->lane_sp[nxt]);
+}
+
+// deposit + rendezvous; returns the slot bank to read from
+inline const Slot* collective(uint64_t lo, uint64_t hi, int line) {
+  WaveRuntime* rt = g_rt;
+  const int me = rt->cur;
+  const unsigned bank = rt->coll_count[me]++ & 1u;
+  rt->slots[bank][me].v[0] = lo;
+  rt->slots[bank][me].v[1] = hi;
+  rt->slots[bank][me].line = line;
+  yield_next();
+  const Slot* s = rt->slots[bank];
+  for (int l = 0; l < kLanes; ++l) {
+    if (s[l].line != line) {
+      fprintf(stderr, "wave_emu: divergent collective: lane %d at line %d, lane %d at line %d\n",
+              me, line, l, s[l].line);
+      abort();
+    }
+  }
+  return s;
+}
+
+void run_wave(void (*body)(void*), void* arg);
+
+}  // namespace wave_emu
+
+namespace wave {
+
+MODLE_DEV unsigned lane() { return static_cast<unsigned>(wave_emu::g_rt->cur); }
+
+MODLE_DEV uint64_t ballot(bool p, int line = __builtin_LINE()) {
+  const wave_emu::Slot* s = wave_emu::collective(p ? 1 : 0, 0, line);
+  uint64_t m = 0;
+  for (int l = 0; l < 64; ++l) m |= (s[l].v[0] & 1ull) << l;
+  return m;
+}
+MODLE_DEV bool any(bool p, int line = __builtin_LINE()) { return ballot(p, line) != 0; }
+
+template <class T>
+MODLE_DEV T shfl(T v, unsigned src, int line = __builtin_LINE()) {
+  static_assert(sizeof(T) <= 16, "shuffle operand too wide");
+  uint64_t w[2] = {0, 0};
+  memcpy(w, &v, sizeof(T));
+  const wave_emu::Slot* s = wave_emu::collective(w[0], w[1], line);
+  T out;
+  memcpy(&out, s[src & 63].v, sizeof(T));
+  return out;
+}
+template <class T>
+MODLE_DEV T bcast(T v, unsigned src, int line = __builtin_LINE()) {
+  return shfl(v, src, line);
+}
+template <class T>
+MODLE_DEV T shfl_down(T v, unsigned delta, int line = __builtin_LINE()) {
+  const unsigned l = lane();
+  const unsigned src = l + delta < 64 ? l + delta : l;
+  return shfl(v, src, line);
+}
+template <class T>
+MODLE_DEV T shfl_up(T v, unsigned delta, int line = __builtin_LINE()) {
+  const unsigned l = lane();
+  const unsigned src = l >= delta ? l - delta : l;
+  return shfl(v, src, line);
+}
+
+MODLE_DEV void sync_mem(int line = __builtin_LINE()) { (void)wave_emu::collective(0, 0, line); }
+MODLE_DEV void lockstep(int line = __builtin_LINE()) { (void)wave_emu::collective(0, 0, line); }
+
+MODLE_DEV void atomic_inc_u32(uint32_t* p) { __atomic_fetch_add(p, 1u, __ATOMIC_RELAXED); }
+MODLE_DEV void atomic_add_u64(uint64_t* p, uint64_t v) {
+  __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
+}
+MODLE_DEV uint32_t atomic_fetch_add_u32(uint32_t* p, uint32_t v) {
+  return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
+}
+
+MODLE_DEV double f_log(double x) { return log(x); }
+MODLE_DEV double f_exp(double x) { return exp(x); }
+MODLE_DEV double f_pow(double x, double y) { return pow(x, y); }
+MODLE_DEV double f_sqrt(double x) { return sqrt(x); }
+MODLE_DEV double f_floor(double x) { return floor(x); }
+MODLE_DEV double f_round(double x) { return round(x); }
+MODLE_DEV double f_abs(double x) { return fabs(x); }
+MODLE_DEV bool f_isfinite(double x) { return isfinite(x); }
+
+MODLE_DEV int popc64(uint64_t x) { return __builtin_popcountll(x); }
+MODLE_DEV int ctz64(uint64_t x) { return x ? __builtin_ctzll(x) : -1; }
+MODLE_DEV int clz64(uint64_t x) { return x ? __builtin_clzll(x) : 64; }
+
+}  // namespace wave
