@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Benchmark of the loop-extrusion hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload grch38|chr1] [--cells C]
+
+A "step" is one pass of the hot path over one batch of synthetic input: every (chromosome, cell)
+task of this rank's shard is simulated by the HIP kernel (one wavefront per cell) and, for N > 1,
+the per-rank contact matrices are summed with RCCL.  Default workload = BASELINE.json configs[2]:
+the whole GRCh38-shaped genome (24 chromosomes, synthetic barriers with the bundled BED's
+statistics), 2048 cells per GPU, all parameters at the reference defaults, seed 0.  Cells are
+sharded over ranks (weak scaling: 2048 cells per GPU; configs[3] is the 8-GPU point).
+
+Prints ONE JSON line on rank 0 (contract in the task statement): metric = simulated
+genome-cells/s (whole job), plus `roofline` (algorithmic HBM bytes of the simulation kernel over
+its HIP-event duration, against 8 TB/s) and `cpu_baseline` (the CPU oracle timed on the host
+cores over a bounded sample of the same workload; N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=["grch38", "chr1"], default="grch38")
+    ap.add_argument("--cells", type=int, default=None, help="cells per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-cells", type=int, default=None)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, genome, unit, sample_cells):
+    """Times the CPU oracle (oracle/, kind "port") on every host core over a bounded sample:
+    `sample_cells` cells of every chromosome of the workload."""
+    from modle_amd import api
+    from oracle import binding as oracle
+
+    cores = os.cpu_count() or 1
+    sample = sample_cells or max(2, min(cores, 64))
+    jobs = []
+    for iv in genome:
+        if len(iv["bar_pos"]) == 0 and not cfg.simulate_chromosomes_wo_barriers:
+            continue
+        tasks = api.make_tasks(cfg, iv["name"], iv["size"], iv["start"], iv["end"])
+        n = min(sample, len(tasks))
+        stp_a, stp_i = api.barrier_stps(cfg, iv["bar_occupancy"])
+        jobs.append((iv, api.slice_tasks(tasks, 0, n), stp_a, stp_i))
+    oracle.lib()
+    t0 = time.perf_counter()
+    epochs = 0
+    for iv, tasks, stp_a, stp_i in jobs:
+        _, _, _, res = oracle.simulate_interval(cfg, iv["start"], iv["end"], iv["bar_pos"],
+                                                iv["bar_dir"], stp_a, stp_i, tasks,
+                                                nthreads=cores,
+                                                track_occupancy=bool(cfg.track_1d_lef_position))
+        epochs += sum(r.epochs for r in res)
+    dt = time.perf_counter() - t0
+    return {
+        "value": sample / dt,
+        "unit": unit,
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{sample} cells of each of the {len(jobs)} chromosomes "
+                  f"({sample * len(jobs)} tasks, {epochs} epochs) in {dt:.1f} s",
+    }
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+
+    from modle_amd import api, driver, synthetic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    cells_per_gpu = args.cells or (2048 if args.workload == "grch38" else 512)
+    if args.workload == "grch38":
+        genome = synthetic.grch38_like(seed=42)
+        workload = (f"GRCh38-shaped genome (24 chromosomes, synthetic H1-like barriers), "
+                    f"{cells_per_gpu} cells per GPU, reference defaults (BASELINE configs[2]/[3])")
+        unit = "genome-cells/s"
+    else:
+        genome = synthetic.grch38_like(seed=42, chroms={"chr1"})
+        workload = (f"chr1-shaped interval (248 956 422 bp, 3129 synthetic barriers), "
+                    f"{cells_per_gpu} cells per GPU, reference defaults (BASELINE configs[1])")
+        unit = "chr1-cells/s"
+    total_cells = cells_per_gpu * world
+    cfg = api.make_config(num_cells=total_cells, seed=0)
+
+    plan = driver.plan_genome(cfg, genome, rank, world)
+    # outputs live in torch tensors so that RCCL can reduce them in place
+    buffers, tensors = [], []
+    for entry in plan:
+        if entry["skipped"]:
+            buffers.append((None, None))
+            tensors.append(None)
+            continue
+        c = torch.zeros(entry["nrows"] * entry["ncols"] + 1, dtype=torch.int32, device=dev)
+        o = torch.zeros(entry["ncols"], dtype=torch.int64, device=dev)
+        buffers.append((c.data_ptr(), o.data_ptr()))
+        tensors.append((c, o))
+    sim = api.Simulator(cfg, local_rank)
+    ids = driver.enqueue_plan(sim, cfg, plan, buffers)  # uploads barriers, enqueues step 0
+    stream = torch.cuda.current_stream(dev)
+
+    kernel_ms = []
+    alg_bytes = []
+
+    def step(first):
+        if not first:
+            for entry, iid in zip(plan, ids):
+                if iid is not None:
+                    sim.submit(iid, entry["tasks"])
+        for t in tensors:
+            if t is not None:
+                t[0].zero_()
+                t[1].zero_()
+        sim.launch(stream.cuda_stream)
+        sim.wait()
+        if world > 1:
+            import torch.distributed as dist
+
+            for t in tensors:
+                if t is not None:
+                    dist.reduce(t[0], dst=0, op=dist.ReduceOp.SUM)
+                    dist.reduce(t[1], dst=0, op=dist.ReduceOp.SUM)
+        kernel_ms.append(sim.kernel_ms())
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    first = True
+    for _ in range(args.warmup):
+        step(first)
+        first = False
+    kernel_ms.clear()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(first)
+        first = False
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # algorithmic bytes of the LAST step of this rank (results accumulate per step)
+    n_tasks = 0
+    step_bytes = 0
+    epochs = 0
+    for entry, iid in zip(plan, ids):
+        if iid is None:
+            continue
+        res = sim.results(iid)
+        k = len(entry["tasks"])
+        last = res[len(res) - k:]
+        step_bytes += driver.algorithmic_bytes(last, len(entry["interval"]["bar_pos"]),
+                                               bool(cfg.track_1d_lef_position))
+        epochs += sum(r.epochs for r in last)
+        n_tasks += k
+    avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3 if kernel_ms else float("nan")
+    achieved = step_bytes / avg_kernel_s / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "simulated cells/sec (whole node), GRCh38 default barriers",
+            "value": total_cells * args.steps / dt,
+            "unit": unit,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32/f64",
+            "data": "synthetic",
+            "config": {"workload": workload, "cells_per_gpu": cells_per_gpu,
+                       "total_cells": total_cells, "tasks_per_gpu": n_tasks,
+                       "cell_epochs_per_gpu_step": epochs, "seed": 0,
+                       "parallelism": f"cells sharded over {world} GPU(s), RCCL sum-reduce"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "modle_simulate_cells",
+                         "kernel_ms": avg_kernel_s * 1e3,
+                         "algorithmic_bytes_per_launch": step_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, genome, unit, args.cpu_sample_cells)
+        print(json.dumps(out), flush=True)
+    sim.close()
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

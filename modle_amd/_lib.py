@@ -1,0 +1,96 @@
+"""Loader of the native library (modle_amd/libmodle_hip.so).
+
+There is deliberately no fallback: when the shared library is missing the import of any compute
+entry point fails loudly instead of silently running something else.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .params import CellResult, Config, Task
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libmodle_hip.so")
+
+# every symbol include/modle_hip.h declares
+EXPORTS = [
+    "modle_hip_config_default", "modle_hip_config_transform", "modle_hip_interval_hash",
+    "modle_hip_prng_seed", "modle_hip_prng_jump", "modle_hip_compute_num_lefs",
+    "modle_hip_compute_contacts_per_epoch", "modle_hip_matrix_shape", "modle_hip_make_tasks",
+    "modle_hip_stp_active_from_occupancy", "modle_hip_occupancy_from_stp", "modle_hip_create",
+    "modle_hip_destroy", "modle_hip_add_interval", "modle_hip_submit_tasks", "modle_hip_launch",
+    "modle_hip_wait", "modle_hip_last_kernel_ms", "modle_hip_get_results",
+    "modle_hip_interval_outputs", "modle_hip_copy_outputs", "modle_hip_reset",
+    "modle_hip_simulate_interval", "modle_hip_test_phases",
+]
+
+u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc, gfx950). modle_amd has no CPU fallback.")
+    L = C.CDLL(SO_PATH)
+    P = C.POINTER
+    err = [C.c_char_p, C.c_size_t]
+    L.modle_hip_config_default.argtypes = [P(Config)]
+    L.modle_hip_config_default.restype = None
+    L.modle_hip_config_transform.argtypes = [P(Config)] + err
+    L.modle_hip_interval_hash.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64,
+                                          C.c_uint64]
+    L.modle_hip_interval_hash.restype = C.c_uint64
+    L.modle_hip_prng_seed.argtypes = [C.c_uint64, P(C.c_uint64)]
+    L.modle_hip_prng_seed.restype = None
+    L.modle_hip_prng_jump.argtypes = [P(C.c_uint64)]
+    L.modle_hip_prng_jump.restype = None
+    L.modle_hip_compute_num_lefs.argtypes = [P(Config), C.c_uint64]
+    L.modle_hip_compute_num_lefs.restype = C.c_uint64
+    L.modle_hip_compute_contacts_per_epoch.argtypes = [P(Config), C.c_uint64]
+    L.modle_hip_compute_contacts_per_epoch.restype = C.c_uint64
+    L.modle_hip_matrix_shape.argtypes = [P(Config), C.c_uint64, P(C.c_uint64), P(C.c_uint64)]
+    L.modle_hip_matrix_shape.restype = None
+    L.modle_hip_make_tasks.argtypes = [P(Config), C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64,
+                                       C.c_uint64, P(Task)]
+    L.modle_hip_stp_active_from_occupancy.argtypes = [C.c_double, C.c_double]
+    L.modle_hip_stp_active_from_occupancy.restype = C.c_double
+    L.modle_hip_occupancy_from_stp.argtypes = [C.c_double, C.c_double]
+    L.modle_hip_occupancy_from_stp.restype = C.c_double
+    L.modle_hip_create.argtypes = [P(Config), C.c_int] + err
+    L.modle_hip_create.restype = C.c_void_p
+    L.modle_hip_destroy.argtypes = [C.c_void_p]
+    L.modle_hip_destroy.restype = None
+    L.modle_hip_reset.argtypes = [C.c_void_p]
+    L.modle_hip_add_interval.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, u64p, u8p, f64p,
+                                         f64p, C.c_size_t, C.c_void_p, C.c_void_p] + err
+    L.modle_hip_submit_tasks.argtypes = [C.c_void_p, C.c_int, P(Task), C.c_size_t] + err
+    L.modle_hip_launch.argtypes = [C.c_void_p, C.c_void_p] + err
+    L.modle_hip_wait.argtypes = [C.c_void_p] + err
+    L.modle_hip_last_kernel_ms.argtypes = [C.c_void_p, P(C.c_float)]
+    L.modle_hip_get_results.argtypes = [C.c_void_p, C.c_int, P(CellResult), C.c_size_t]
+    L.modle_hip_interval_outputs.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p), P(C.c_void_p),
+                                             P(C.c_uint64), P(C.c_uint64)]
+    L.modle_hip_copy_outputs.argtypes = [C.c_void_p, C.c_int, C.c_void_p, P(C.c_uint64),
+                                         C.c_void_p] + err
+    L.modle_hip_simulate_interval.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, u64p, u8p,
+                                              f64p, f64p, C.c_size_t, P(Task), C.c_size_t, u32p,
+                                              C.c_uint64, C.c_uint64, P(C.c_uint64), C.c_void_p,
+                                              P(CellResult)] + err
+    L.modle_hip_test_phases.argtypes = ([C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64,
+                                         C.c_size_t] + [u64p] * 9 +
+                                        [C.c_size_t, u64p, u8p, u8p, P(C.c_uint64),
+                                         P(C.c_uint64)] + err)
+    for name in EXPORTS:
+        getattr(L, name)  # raises AttributeError if a declared symbol is not exported
+    _lib = L
+    return L

@@ -1,0 +1,726 @@
+// modle_hip.hip -- gfx950 kernels and the device half of the C ABI (include/modle_hip.h).
+//
+// One wavefront simulates one (interval, cell) task (reference seam:
+// Simulation::simulate_one_cell, src/libmodle/cpu/simulation.cpp:896-986, called from
+// src/libmodle/cpu/scheduler_simulate.cpp:240).  The launch is persistent: one 512-thread
+// workgroup per CU, its 8 waves pull tasks (largest chromosomes first) from a device-side
+// counter, the way the reference's worker threads drain the task queue
+// (scheduler_simulate.cpp:190-271).  LDS holds what every wave of the workgroup shares (the
+// GF(2) jump table of the PRNG block generator and the ziggurat layer tables) plus each wave's
+// ring of raw PRNG outputs; per-cell LEF / barrier state lives in a per-wave slice of a device
+// workspace.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "modle_hip.h"
+#include "wave_hip.h"
+// clang-format off
+#include "sim_device.h"
+// clang-format on
+#include "host_prng.hpp"
+#include "launch_common.hpp"
+#include "zig_tables.h"
+
+using namespace modle_dev;
+
+namespace {
+
+constexpr int kWavesPerBlock = 8;
+constexpr int kThreadsPerBlock = kWavesPerBlock * 64;
+
+struct DeviceTables {
+  const u64* jump;   // JUMP_TABLE_WORDS
+  const f64* zig;    // norm_x[129] norm_y[129] exp_x[257] exp_y[257]
+};
+constexpr int kZigWords = 129 + 129 + 257 + 257;
+
+struct SimArgs {
+  Params params;
+  DeviceTables tables;
+  const Interval* intervals;
+  const Task* tasks;
+  CellResult* results;
+  u32* status;        // one word per task
+  u32* task_counter;
+  char* workspace;
+  u64 workspace_stride;
+  u32 n_tasks;
+  u32 max_lefs;
+  u32 max_barriers;
+  u32 pad_;
+};
+
+__device__ Workspace device_carve(char* base, u32 max_lefs, u32 max_barriers, u32 hist_len) {
+  // mirrors modle_host::carve_workspace
+  const u64 Lp = (static_cast<u64>(max_lefs) + 63) & ~u64(63);
+  u64 pw = 1;
+  const u32 ml = max_lefs < 64 ? 64 : max_lefs;
+  while (pw < ml) pw <<= 1;
+  Workspace ws;
+  char* p = base;
+  ws.sort_keys = reinterpret_cast<u64*>(p);
+  p += pw * 8;
+  ws.hist = reinterpret_cast<f64*>(p);
+  p += 2 * static_cast<u64>(hist_len) * 8;
+  u32* q = reinterpret_cast<u32*>(p);
+  ws.rev_pos = q + 0 * Lp;
+  ws.fwd_pos = q + 1 * Lp;
+  ws.epoch = q + 2 * Lp;
+  ws.rev_rank = q + 3 * Lp;
+  ws.fwd_rank = q + 4 * Lp;
+  ws.rev_moves = q + 5 * Lp;
+  ws.fwd_moves = q + 6 * Lp;
+  ws.rev_coll = q + 7 * Lp;
+  ws.fwd_coll = q + 8 * Lp;
+  ws.tmp_a = q + 9 * Lp;
+  ws.tmp_b = q + 10 * Lp;
+  ws.tmp_c = q + 11 * Lp;
+  ws.tmp_d = q + 12 * Lp;
+  p += 13 * Lp * 4;
+  ws.bar_active = reinterpret_cast<u8*>(p);
+  ws.capacity_lefs = max_lefs;
+  ws.capacity_barriers = max_barriers;
+  return ws;
+}
+
+struct BlockLds {
+  u64 jump[JUMP_TABLE_WORDS];
+  f64 zig[kZigWords];
+  u64 ring[kWavesPerBlock][RNG_RING];
+  u32 list[kWavesPerBlock][LIST_CAP];
+};
+
+__device__ WaveLds make_wave_lds(BlockLds& s, int wave_in_block) {
+  WaveLds l;
+  l.ring = s.ring[wave_in_block];
+  l.jump_table = s.jump;
+  l.zig_norm_x = s.zig;
+  l.zig_norm_y = s.zig + 129;
+  l.zig_exp_x = s.zig + 258;
+  l.zig_exp_y = s.zig + 258 + 257;
+  l.list = s.list[wave_in_block];
+  return l;
+}
+
+__device__ void load_block_tables(BlockLds& s, const DeviceTables& t, int nthreads) {
+  for (u32 i = threadIdx.x; i < JUMP_TABLE_WORDS; i += nthreads) s.jump[i] = t.jump[i];
+  for (u32 i = threadIdx.x; i < static_cast<u32>(kZigWords); i += nthreads) s.zig[i] = t.zig[i];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs a) {
+  __shared__ BlockLds s;
+  load_block_tables(s, a.tables, kThreadsPerBlock);
+  const int wave_in_block = threadIdx.x / 64;
+  const u32 slot = blockIdx.x * kWavesPerBlock + wave_in_block;
+  const WaveLds lds = make_wave_lds(s, wave_in_block);
+  const Workspace ws = device_carve(a.workspace + static_cast<u64>(slot) * a.workspace_stride,
+                                    a.max_lefs, a.max_barriers, a.params.hist_len);
+  for (;;) {
+    u32 t = 0;
+    if (wave::lane() == 0) t = atomicAdd(a.task_counter, 1u);
+    t = wave::bcast(t, 0);
+    if (t >= a.n_tasks) break;  // every wave leaves once the queue is empty
+    const Task task = a.tasks[t];
+    CellResult res;
+    const u32 st = simulate_cell(a.params, a.intervals[task.interval], task, ws, lds, res, a.pad_);
+    if (wave::lane() == 0) {
+      a.results[t] = res;
+      a.status[t] = st;
+    }
+  }
+}
+
+struct PhaseArgs {
+  Params params;
+  DeviceTables tables;
+  Interval interval;
+  char* workspace;
+  u32 mask;
+  u32 n;
+  u64 prng[4];
+  u64* raws_out;
+  u32* status_out;
+  u32 max_barriers;
+};
+
+__global__ __launch_bounds__(64) void modle_test_phases(PhaseArgs a) {
+  __shared__ BlockLds s;
+  load_block_tables(s, a.tables, 64);
+  const WaveLds lds = make_wave_lds(s, 0);
+  const Workspace ws = device_carve(a.workspace, a.n, a.max_barriers, 4);
+  u64 raws = 0;
+  const u32 st = run_test_phases(a.params, a.interval, ws, lds, a.mask, a.n, a.prng, raws);
+  if (wave::lane() == 0) {
+    *a.raws_out = raws;
+    *a.status_out = st;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+void set_err(char* err, size_t errlen, const std::string& msg) {
+  if (err != nullptr && errlen != 0) std::snprintf(err, errlen, "%s", msg.c_str());
+}
+
+#define HIP_TRY(expr)                                                                     \
+  do {                                                                                    \
+    const hipError_t e_ = (expr);                                                         \
+    if (e_ != hipSuccess) {                                                               \
+      set_err(err, errlen, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+      return MODLE_HIP_ERR_DEVICE;                                                        \
+    }                                                                                     \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { reset(); }
+  void reset() {
+    if (p != nullptr) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  hipError_t ensure(size_t count) {
+    if (count <= n) return hipSuccess;
+    reset();
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+};
+
+struct IntervalRec {
+  uint64_t start = 0, end = 0;
+  uint64_t nrows = 0, ncols = 0;
+  size_t n_barriers = 0;
+  DevBuf<u32> bar_pos;
+  DevBuf<u8> bar_dir;
+  DevBuf<f64> bar_stp;  // stp_active | stp_inactive | occupancy
+  DevBuf<u32> own_contacts;
+  DevBuf<u64> own_occupancy;
+  DevBuf<u64> missed;
+  u32* d_contacts = nullptr;
+  u64* d_occupancy = nullptr;
+  std::vector<modle_hip_task> pending;
+  std::vector<modle_hip_cell_result> results;  // submission order
+  std::vector<size_t> launch_slots;            // index into the launch's task array
+};
+
+}  // namespace
+
+struct modle_hip_handle {
+  modle_hip_config cfg;
+  Params params;
+  int device = 0;
+  int num_cus = 0;
+  std::vector<std::unique_ptr<IntervalRec>> intervals;
+  DevBuf<u64> d_jump;
+  DevBuf<f64> d_zig;
+  DevBuf<Interval> d_intervals;
+  DevBuf<Task> d_tasks;
+  DevBuf<CellResult> d_results;
+  DevBuf<u32> d_status;
+  DevBuf<u32> d_counter;
+  DevBuf<char> d_workspace;
+  DevBuf<u64> d_phase_out;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  hipStream_t stream = nullptr;
+  bool in_flight = false;
+  size_t n_launched = 0;
+  std::vector<std::pair<int, size_t>> launch_map;  // launch task -> (interval, submission idx)
+  float last_ms = 0.0f;
+};
+
+extern "C" {
+
+modle_hip_handle* modle_hip_create(const modle_hip_config* c, int device, char* err,
+                                   size_t errlen) {
+  if (c == nullptr) {
+    set_err(err, errlen, "null config");
+    return nullptr;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_err(err, errlen, "no HIP device available: the MI355X path has no CPU fallback");
+    return nullptr;
+  }
+  if (device < 0 || device >= ndev) {
+    set_err(err, errlen, "invalid device ordinal");
+    return nullptr;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    set_err(err, errlen, "hipSetDevice failed");
+    return nullptr;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    set_err(err, errlen, "hipGetDeviceProperties failed");
+    return nullptr;
+  }
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+    set_err(err, errlen, std::string("unsupported GPU architecture ") + prop.gcnArchName +
+                             " (this library is built for gfx950 only)");
+    return nullptr;
+  }
+  auto h = std::make_unique<modle_hip_handle>();
+  h->cfg = *c;
+  h->params = modle_host::make_params(*c);
+  h->device = device;
+  h->num_cus = prop.multiProcessorCount;
+  const std::vector<uint64_t> jump = modle_host::build_jump_table(RNG_BLOCK);
+  std::vector<f64> zig;
+  zig.insert(zig.end(), ZIG_NORM_X, ZIG_NORM_X + 129);
+  zig.insert(zig.end(), ZIG_NORM_Y, ZIG_NORM_Y + 129);
+  zig.insert(zig.end(), ZIG_EXP_X, ZIG_EXP_X + 257);
+  zig.insert(zig.end(), ZIG_EXP_Y, ZIG_EXP_Y + 257);
+  if (h->d_jump.ensure(jump.size()) != hipSuccess || h->d_zig.ensure(zig.size()) != hipSuccess ||
+      h->d_counter.ensure(1) != hipSuccess || h->d_phase_out.ensure(2) != hipSuccess ||
+      hipMemcpy(h->d_jump.p, jump.data(), jump.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(h->d_zig.p, zig.data(), zig.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+      hipEventCreate(&h->ev_start) != hipSuccess || hipEventCreate(&h->ev_stop) != hipSuccess) {
+    set_err(err, errlen, "device allocation failed");
+    return nullptr;
+  }
+  return h.release();
+}
+
+void modle_hip_destroy(modle_hip_handle* h) {
+  if (h == nullptr) return;
+  (void)hipSetDevice(h->device);
+  if (h->in_flight) (void)hipStreamSynchronize(h->stream);
+  if (h->ev_start != nullptr) (void)hipEventDestroy(h->ev_start);
+  if (h->ev_stop != nullptr) (void)hipEventDestroy(h->ev_stop);
+  delete h;
+}
+
+int modle_hip_reset(modle_hip_handle* h) {
+  if (h == nullptr) return MODLE_HIP_ERR_ARG;
+  if (h->in_flight) return MODLE_HIP_ERR_STATE;
+  (void)hipSetDevice(h->device);
+  h->intervals.clear();
+  h->launch_map.clear();
+  return MODLE_HIP_OK;
+}
+
+int modle_hip_add_interval(modle_hip_handle* h, uint64_t start, uint64_t end,
+                           const uint64_t* bar_pos, const uint8_t* bar_dir,
+                           const double* bar_stp_active, const double* bar_stp_inactive,
+                           size_t n_barriers, void* d_contacts, void* d_occupancy, char* err,
+                           size_t errlen) {
+  if (h == nullptr) return MODLE_HIP_ERR_ARG;
+  if (h->in_flight) {
+    set_err(err, errlen, "a launch is in flight");
+    return MODLE_HIP_ERR_STATE;
+  }
+  if (const char* msg = modle_host::check_limits(h->cfg, start, end, 1, n_barriers)) {
+    set_err(err, errlen, msg);
+    return MODLE_HIP_ERR_ARG;
+  }
+  if (n_barriers != 0 && (bar_pos == nullptr || bar_dir == nullptr || bar_stp_active == nullptr ||
+                          bar_stp_inactive == nullptr)) {
+    set_err(err, errlen, "null barrier arrays");
+    return MODLE_HIP_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  auto rec = std::make_unique<IntervalRec>();
+  rec->start = start;
+  rec->end = end;
+  rec->n_barriers = n_barriers;
+  modle_hip_matrix_shape(&h->cfg, end - start, &rec->nrows, &rec->ncols);
+  std::vector<u32> pos(n_barriers);
+  std::vector<u8> dir(n_barriers);
+  std::vector<f64> stp(3 * n_barriers);
+  for (size_t i = 0; i < n_barriers; ++i) {
+    if (bar_pos[i] < start || bar_pos[i] >= end || (i > 0 && bar_pos[i] < bar_pos[i - 1])) {
+      set_err(err, errlen, "barriers must be sorted by position and lie inside the interval");
+      return MODLE_HIP_ERR_ARG;
+    }
+    if (bar_dir[i] != MODLE_HIP_DIR_FWD && bar_dir[i] != MODLE_HIP_DIR_REV) {
+      set_err(err, errlen, "barrier direction must be MODLE_HIP_DIR_FWD or MODLE_HIP_DIR_REV");
+      return MODLE_HIP_ERR_ARG;
+    }
+    pos[i] = static_cast<u32>(bar_pos[i]);
+    dir[i] = bar_dir[i];
+    stp[i] = bar_stp_active[i];
+    stp[n_barriers + i] = bar_stp_inactive[i];
+    stp[2 * n_barriers + i] = modle_hip_occupancy_from_stp(bar_stp_active[i], bar_stp_inactive[i]);
+  }
+  HIP_TRY(rec->bar_pos.ensure(n_barriers));
+  HIP_TRY(rec->bar_dir.ensure(n_barriers));
+  HIP_TRY(rec->bar_stp.ensure(3 * n_barriers));
+  HIP_TRY(rec->missed.ensure(1));
+  HIP_TRY(hipMemset(rec->missed.p, 0, 8));
+  if (n_barriers != 0) {
+    HIP_TRY(hipMemcpy(rec->bar_pos.p, pos.data(), n_barriers * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(rec->bar_dir.p, dir.data(), n_barriers, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(rec->bar_stp.p, stp.data(), 3 * n_barriers * 8, hipMemcpyHostToDevice));
+  }
+  const size_t nwords = rec->nrows * rec->ncols + 1;
+  if (d_contacts != nullptr) {
+    rec->d_contacts = static_cast<u32*>(d_contacts);
+  } else {
+    HIP_TRY(rec->own_contacts.ensure(nwords));
+    HIP_TRY(hipMemset(rec->own_contacts.p, 0, nwords * 4));
+    rec->d_contacts = rec->own_contacts.p;
+  }
+  if (d_occupancy != nullptr) {
+    rec->d_occupancy = static_cast<u64*>(d_occupancy);
+  } else if (h->cfg.track_1d_lef_position) {
+    HIP_TRY(rec->own_occupancy.ensure(rec->ncols));
+    HIP_TRY(hipMemset(rec->own_occupancy.p, 0, rec->ncols * 8));
+    rec->d_occupancy = rec->own_occupancy.p;
+  }
+  h->intervals.push_back(std::move(rec));
+  return static_cast<int>(h->intervals.size()) - 1;
+}
+
+int modle_hip_submit_tasks(modle_hip_handle* h, int interval_id, const modle_hip_task* tasks,
+                           size_t n_tasks, char* err, size_t errlen) {
+  if (h == nullptr || interval_id < 0 || static_cast<size_t>(interval_id) >= h->intervals.size() ||
+      (tasks == nullptr && n_tasks != 0)) {
+    set_err(err, errlen, "invalid arguments");
+    return MODLE_HIP_ERR_ARG;
+  }
+  if (h->in_flight) {
+    set_err(err, errlen, "a launch is in flight");
+    return MODLE_HIP_ERR_STATE;
+  }
+  IntervalRec& rec = *h->intervals[static_cast<size_t>(interval_id)];
+  for (size_t i = 0; i < n_tasks; ++i) {
+    if (const char* msg = modle_host::check_limits(h->cfg, rec.start, rec.end, tasks[i].num_lefs,
+                                                   rec.n_barriers)) {
+      set_err(err, errlen, msg);
+      return MODLE_HIP_ERR_ARG;
+    }
+    rec.pending.push_back(tasks[i]);
+  }
+  return MODLE_HIP_OK;
+}
+
+int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen) {
+  if (h == nullptr) return MODLE_HIP_ERR_ARG;
+  if (h->in_flight) {
+    set_err(err, errlen, "a launch is already in flight");
+    return MODLE_HIP_ERR_STATE;
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  h->stream = static_cast<hipStream_t>(stream);
+  // gather pending tasks, largest chromosomes first (long tasks must not start last)
+  std::vector<Task> tasks;
+  h->launch_map.clear();
+  u32 max_lefs = 1, max_barriers = 0;
+  for (size_t iv = 0; iv < h->intervals.size(); ++iv) {
+    IntervalRec& rec = *h->intervals[iv];
+    const size_t base = rec.results.size();
+    rec.results.resize(base + rec.pending.size());
+    for (size_t k = 0; k < rec.pending.size(); ++k) {
+      const modle_hip_task& t = rec.pending[k];
+      Task d;
+      d.interval = static_cast<u32>(iv);
+      d.num_lefs = static_cast<u32>(t.num_lefs);
+      d.cell_id = t.cell_id;
+      d.num_target_epochs = t.num_target_epochs;
+      d.num_target_contacts = t.num_target_contacts;
+      d.contacts_per_epoch = modle_hip_compute_contacts_per_epoch(&h->cfg, t.num_lefs);
+      std::memcpy(d.prng, t.prng, sizeof(d.prng));
+      tasks.push_back(d);
+      h->launch_map.emplace_back(static_cast<int>(iv), base + k);
+      max_lefs = std::max(max_lefs, d.num_lefs);
+    }
+    if (!rec.pending.empty()) max_barriers = std::max<u32>(max_barriers, static_cast<u32>(rec.n_barriers));
+    rec.pending.clear();
+  }
+  h->n_launched = tasks.size();
+  if (tasks.empty()) return MODLE_HIP_OK;
+  std::vector<size_t> order(tasks.size());
+  std::iota(order.begin(), order.end(), size_t(0));
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+    const IntervalRec& ia = *h->intervals[tasks[a].interval];
+    const IntervalRec& ib = *h->intervals[tasks[b].interval];
+    const uint64_t wa = static_cast<uint64_t>(tasks[a].num_lefs) + ia.n_barriers;
+    const uint64_t wb = static_cast<uint64_t>(tasks[b].num_lefs) + ib.n_barriers;
+    return wa > wb;
+  });
+  std::vector<Task> sorted(tasks.size());
+  std::vector<std::pair<int, size_t>> sorted_map(tasks.size());
+  for (size_t i = 0; i < order.size(); ++i) {
+    sorted[i] = tasks[order[i]];
+    sorted_map[i] = h->launch_map[order[i]];
+  }
+  h->launch_map.swap(sorted_map);
+
+  std::vector<Interval> ivs(h->intervals.size());
+  for (size_t iv = 0; iv < h->intervals.size(); ++iv) {
+    const IntervalRec& rec = *h->intervals[iv];
+    Interval& d = ivs[iv];
+    d.start = static_cast<u32>(rec.start);
+    d.end = static_cast<u32>(rec.end);
+    d.n_barriers = static_cast<u32>(rec.n_barriers);
+    d.pad_ = 0;
+    d.bar_pos = rec.bar_pos.p;
+    d.bar_dir = rec.bar_dir.p;
+    d.bar_stp_active = rec.bar_stp.p;
+    d.bar_stp_inactive = rec.bar_stp.p + rec.n_barriers;
+    d.bar_occupancy = rec.bar_stp.p + 2 * rec.n_barriers;
+    d.contacts = rec.d_contacts;
+    d.occupancy_1d = rec.d_occupancy;
+    d.missed_updates = rec.missed.p;
+    d.nrows = rec.nrows;
+    d.ncols = rec.ncols;
+  }
+  const int grid = std::max(1, std::min<int>(h->num_cus, static_cast<int>((sorted.size() + kWavesPerBlock - 1) / kWavesPerBlock)));
+  const auto layout = modle_host::workspace_layout(max_lefs, max_barriers, h->params.hist_len);
+  const size_t n_slots = static_cast<size_t>(grid) * kWavesPerBlock;
+  HIP_TRY(h->d_intervals.ensure(ivs.size()));
+  HIP_TRY(h->d_tasks.ensure(sorted.size()));
+  HIP_TRY(h->d_results.ensure(sorted.size()));
+  HIP_TRY(h->d_status.ensure(sorted.size()));
+  HIP_TRY(h->d_workspace.ensure(layout.total_bytes * n_slots));
+  HIP_TRY(hipMemcpyAsync(h->d_intervals.p, ivs.data(), ivs.size() * sizeof(Interval),
+                         hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_tasks.p, sorted.data(), sorted.size() * sizeof(Task),
+                         hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_counter.p, 0, 4, h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_status.p, 0xFF, sorted.size() * 4, h->stream));
+  // the source vectors must outlive the async copies
+  HIP_TRY(hipStreamSynchronize(h->stream));
+
+  SimArgs a;
+  a.params = h->params;
+  a.tables.jump = h->d_jump.p;
+  a.tables.zig = h->d_zig.p;
+  a.intervals = h->d_intervals.p;
+  a.tasks = h->d_tasks.p;
+  a.results = h->d_results.p;
+  a.status = h->d_status.p;
+  a.task_counter = h->d_counter.p;
+  a.workspace = h->d_workspace.p;
+  a.workspace_stride = layout.total_bytes;
+  a.n_tasks = static_cast<u32>(sorted.size());
+  a.max_lefs = max_lefs;
+  a.max_barriers = max_barriers;
+  a.pad_ = std::getenv("MODLE_HIP_DEBUG_STAGE") ? static_cast<u32>(std::atoi(std::getenv("MODLE_HIP_DEBUG_STAGE"))) : 0;
+  HIP_TRY(hipEventRecord(h->ev_start, h->stream));
+  hipLaunchKernelGGL(modle_simulate_cells, dim3(grid), dim3(kThreadsPerBlock), 0, h->stream, a);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
+  h->in_flight = true;
+  return MODLE_HIP_OK;
+}
+
+int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen) {
+  if (h == nullptr) return MODLE_HIP_ERR_ARG;
+  if (!h->in_flight) return MODLE_HIP_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->in_flight = false;
+  HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev_start, h->ev_stop));
+  std::vector<CellResult> res(h->n_launched);
+  std::vector<u32> status(h->n_launched);
+  HIP_TRY(hipMemcpy(res.data(), h->d_results.p, res.size() * sizeof(CellResult),
+                    hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(status.data(), h->d_status.p, status.size() * 4, hipMemcpyDeviceToHost));
+  int rc = MODLE_HIP_OK;
+  for (size_t i = 0; i < res.size(); ++i) {
+    const auto [iv, idx] = h->launch_map[i];
+    static_assert(sizeof(CellResult) == sizeof(modle_hip_cell_result), "result layouts differ");
+    std::memcpy(&h->intervals[static_cast<size_t>(iv)]->results[idx], &res[i], sizeof(CellResult));
+    if (status[i] != 0 && rc == MODLE_HIP_OK) {
+      set_err(err, errlen,
+              "task " + std::to_string(i) + " failed on the device with status " +
+                  std::to_string(status[i]) + " (internal capacity exceeded)");
+      rc = MODLE_HIP_ERR_STATE;
+    }
+  }
+  return rc;
+}
+
+int modle_hip_last_kernel_ms(modle_hip_handle* h, float* ms) {
+  if (h == nullptr || ms == nullptr) return MODLE_HIP_ERR_ARG;
+  *ms = h->last_ms;
+  return MODLE_HIP_OK;
+}
+
+int modle_hip_get_results(modle_hip_handle* h, int interval_id, modle_hip_cell_result* results,
+                          size_t n_results) {
+  if (h == nullptr || interval_id < 0 || static_cast<size_t>(interval_id) >= h->intervals.size())
+    return MODLE_HIP_ERR_ARG;
+  const IntervalRec& rec = *h->intervals[static_cast<size_t>(interval_id)];
+  if (n_results > rec.results.size()) return MODLE_HIP_ERR_ARG;
+  std::memcpy(results, rec.results.data(), n_results * sizeof(modle_hip_cell_result));
+  return MODLE_HIP_OK;
+}
+
+int modle_hip_interval_outputs(modle_hip_handle* h, int interval_id, void** d_contacts,
+                               void** d_occupancy, uint64_t* nrows, uint64_t* ncols) {
+  if (h == nullptr || interval_id < 0 || static_cast<size_t>(interval_id) >= h->intervals.size())
+    return MODLE_HIP_ERR_ARG;
+  const IntervalRec& rec = *h->intervals[static_cast<size_t>(interval_id)];
+  if (d_contacts != nullptr) *d_contacts = rec.d_contacts;
+  if (d_occupancy != nullptr) *d_occupancy = rec.d_occupancy;
+  if (nrows != nullptr) *nrows = rec.nrows;
+  if (ncols != nullptr) *ncols = rec.ncols;
+  return MODLE_HIP_OK;
+}
+
+int modle_hip_copy_outputs(modle_hip_handle* h, int interval_id, uint32_t* contacts,
+                           uint64_t* missed_updates, uint64_t* occupancy, char* err,
+                           size_t errlen) {
+  if (h == nullptr || interval_id < 0 || static_cast<size_t>(interval_id) >= h->intervals.size()) {
+    set_err(err, errlen, "invalid interval id");
+    return MODLE_HIP_ERR_ARG;
+  }
+  if (h->in_flight) {
+    set_err(err, errlen, "a launch is in flight");
+    return MODLE_HIP_ERR_STATE;
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  const IntervalRec& rec = *h->intervals[static_cast<size_t>(interval_id)];
+  if (contacts != nullptr)
+    HIP_TRY(hipMemcpy(contacts, rec.d_contacts, (rec.nrows * rec.ncols + 1) * 4,
+                      hipMemcpyDeviceToHost));
+  if (missed_updates != nullptr)
+    HIP_TRY(hipMemcpy(missed_updates, rec.missed.p, 8, hipMemcpyDeviceToHost));
+  if (occupancy != nullptr && rec.d_occupancy != nullptr)
+    HIP_TRY(hipMemcpy(occupancy, rec.d_occupancy, rec.ncols * 8, hipMemcpyDeviceToHost));
+  return MODLE_HIP_OK;
+}
+
+int modle_hip_simulate_interval(modle_hip_handle* h, uint64_t start, uint64_t end,
+                                const uint64_t* bar_pos, const uint8_t* bar_dir,
+                                const double* bar_stp_active, const double* bar_stp_inactive,
+                                size_t n_barriers, const modle_hip_task* tasks, size_t n_tasks,
+                                uint32_t* contacts, uint64_t nrows, uint64_t ncols,
+                                uint64_t* missed_updates, uint64_t* occupancy,
+                                modle_hip_cell_result* results, char* err, size_t errlen) {
+  if (h == nullptr) return MODLE_HIP_ERR_ARG;
+  const int id = modle_hip_add_interval(h, start, end, bar_pos, bar_dir, bar_stp_active,
+                                        bar_stp_inactive, n_barriers, nullptr, nullptr, err,
+                                        errlen);
+  if (id < 0) return id;
+  IntervalRec& rec = *h->intervals[static_cast<size_t>(id)];
+  if (rec.nrows != nrows || rec.ncols != ncols) {
+    set_err(err, errlen, "contact matrix shape does not match bin_size / diagonal_width");
+    return MODLE_HIP_ERR_ARG;
+  }
+  int rc = modle_hip_submit_tasks(h, id, tasks, n_tasks, err, errlen);
+  if (rc == MODLE_HIP_OK) rc = modle_hip_launch(h, nullptr, err, errlen);
+  if (rc == MODLE_HIP_OK) rc = modle_hip_wait(h, err, errlen);
+  if (rc != MODLE_HIP_OK) return rc;
+  if (results != nullptr) std::memcpy(results, rec.results.data(), n_tasks * sizeof(*results));
+  // accumulate into the caller's (shared) matrix like ContactMatrixDense::increment does
+  const size_t nwords = nrows * ncols + 1;
+  if (contacts != nullptr) {
+    std::vector<uint32_t> tmp(nwords);
+    HIP_TRY(hipMemcpy(tmp.data(), rec.d_contacts, nwords * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < nwords; ++i) contacts[i] += tmp[i];
+  }
+  if (missed_updates != nullptr) {
+    uint64_t m = 0;
+    HIP_TRY(hipMemcpy(&m, rec.missed.p, 8, hipMemcpyDeviceToHost));
+    *missed_updates += m;
+  }
+  if (occupancy != nullptr && rec.d_occupancy != nullptr) {
+    std::vector<uint64_t> tmp(ncols);
+    HIP_TRY(hipMemcpy(tmp.data(), rec.d_occupancy, ncols * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < ncols; ++i) occupancy[i] += tmp[i];
+  }
+  return MODLE_HIP_OK;
+}
+
+int modle_hip_test_phases(modle_hip_handle* h, uint32_t phase_mask, uint64_t start, uint64_t end,
+                          size_t n, uint64_t* rev_pos, uint64_t* fwd_pos, uint64_t* epoch,
+                          uint64_t* rev_rank, uint64_t* fwd_rank, uint64_t* rev_moves,
+                          uint64_t* fwd_moves, uint64_t* rev_coll, uint64_t* fwd_coll,
+                          size_t n_barriers, const uint64_t* bar_pos, const uint8_t* bar_dir,
+                          const uint8_t* bar_active, uint64_t prng[4], uint64_t* raws_consumed,
+                          char* err, size_t errlen) {
+  if (h == nullptr || n == 0) return MODLE_HIP_ERR_ARG;
+  if (h->in_flight) return MODLE_HIP_ERR_STATE;
+  HIP_TRY(hipSetDevice(h->device));
+  const auto layout =
+      modle_host::workspace_layout(static_cast<u32>(n), static_cast<u32>(n_barriers), 4);
+  std::vector<uint64_t> image(layout.total_bytes / 8 + 1, 0);
+  Workspace ws = modle_host::carve_workspace(image.data(), static_cast<u32>(n),
+                                             static_cast<u32>(n_barriers), 4);
+  for (size_t i = 0; i < n; ++i) {
+    ws.rev_pos[i] = modle_host::pos_to_dev(rev_pos[i]);
+    ws.fwd_pos[i] = modle_host::pos_to_dev(fwd_pos[i]);
+    ws.epoch[i] = modle_host::pos_to_dev(epoch[i]);
+    ws.rev_rank[i] = static_cast<u32>(rev_rank[i]);
+    ws.fwd_rank[i] = static_cast<u32>(fwd_rank[i]);
+    ws.rev_moves[i] = static_cast<u32>(rev_moves[i]);
+    ws.fwd_moves[i] = static_cast<u32>(fwd_moves[i]);
+    ws.rev_coll[i] = modle_host::coll_to_dev(rev_coll[i]);
+    ws.fwd_coll[i] = modle_host::coll_to_dev(fwd_coll[i]);
+  }
+  for (size_t i = 0; i < n_barriers; ++i) ws.bar_active[i] = bar_active[i];
+  DevBuf<char> d_ws;
+  DevBuf<u32> d_bpos;
+  DevBuf<u8> d_bdir;
+  HIP_TRY(d_ws.ensure(layout.total_bytes));
+  HIP_TRY(d_bpos.ensure(n_barriers));
+  HIP_TRY(d_bdir.ensure(n_barriers));
+  HIP_TRY(hipMemcpy(d_ws.p, image.data(), layout.total_bytes, hipMemcpyHostToDevice));
+  std::vector<u32> bp(n_barriers);
+  for (size_t i = 0; i < n_barriers; ++i) bp[i] = static_cast<u32>(bar_pos[i]);
+  if (n_barriers != 0) {
+    HIP_TRY(hipMemcpy(d_bpos.p, bp.data(), n_barriers * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_bdir.p, bar_dir, n_barriers, hipMemcpyHostToDevice));
+  }
+  PhaseArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.params = h->params;
+  a.tables.jump = h->d_jump.p;
+  a.tables.zig = h->d_zig.p;
+  a.interval.start = static_cast<u32>(start);
+  a.interval.end = static_cast<u32>(end);
+  a.interval.n_barriers = static_cast<u32>(n_barriers);
+  a.interval.bar_pos = d_bpos.p;
+  a.interval.bar_dir = d_bdir.p;
+  a.interval.nrows = 1;
+  a.interval.ncols = 1;
+  a.workspace = d_ws.p;
+  a.mask = phase_mask;
+  a.n = static_cast<u32>(n);
+  std::memcpy(a.prng, prng, sizeof(a.prng));
+  a.raws_out = h->d_phase_out.p;
+  a.status_out = reinterpret_cast<u32*>(h->d_phase_out.p + 1);
+  a.max_barriers = static_cast<u32>(n_barriers);
+  hipLaunchKernelGGL(modle_test_phases, dim3(1), dim3(64), 0, nullptr, a);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  uint64_t out[2] = {0, 0};
+  HIP_TRY(hipMemcpy(out, h->d_phase_out.p, 16, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(image.data(), d_ws.p, layout.total_bytes, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i) {
+    rev_pos[i] = modle_host::pos_to_abi(ws.rev_pos[i]);
+    fwd_pos[i] = modle_host::pos_to_abi(ws.fwd_pos[i]);
+    epoch[i] = modle_host::pos_to_abi(ws.epoch[i]);
+    rev_rank[i] = ws.rev_rank[i];
+    fwd_rank[i] = ws.fwd_rank[i];
+    rev_moves[i] = ws.rev_moves[i];
+    fwd_moves[i] = ws.fwd_moves[i];
+    rev_coll[i] = modle_host::coll_to_abi(ws.rev_coll[i]);
+    fwd_coll[i] = modle_host::coll_to_abi(ws.fwd_coll[i]);
+  }
+  if (raws_consumed != nullptr) *raws_consumed = out[0];
+  if (static_cast<u32>(out[1]) != 0) {
+    set_err(err, errlen, "device phase runner reported status " + std::to_string(out[1]));
+    return MODLE_HIP_ERR_STATE;
+  }
+  return MODLE_HIP_OK;
+}
+
+}  // extern "C"

@@ -1111,6 +1111,17 @@ MODLE_DEV void lef_lef_collision_pos(u32 rev_p, u32 fwd_p, u32 rev_move, u32 fwd
   }
 }
 
+// Position of the barrier a stalled unit's collision word points at.  The reference indexes the
+// barrier array with the word's index without checking that the word is a LEF-BAR collision
+// (simulation_detect_collisions.cpp:371, 389; only asserted in debug builds): a unit flagged at
+// the interval boundary (index 5 / 3) that still takes part in the primary pass makes it read
+// barrier #5 / #3, or past the end of the array when there are fewer barriers.  In-range
+// indices behave like the reference; out-of-range ones (undefined behaviour there) read as 0.
+MODLE_DEV u32 stalling_barrier_pos(const Interval& iv, u32 word) {
+  const u32 idx = cw_index(word);
+  return idx < iv.n_barriers ? iv.bar_pos[idx] : 0u;
+}
+
 // detect_primary_lef_lef_collisions (reference: simulation_detect_collisions.cpp:250-397),
 // evaluated per rev unit: the merge loop pairs the rev unit of rank j with the last fwd unit
 // strictly upstream of it, provided j is the first rev unit downstream of that fwd unit and the
@@ -1167,11 +1178,11 @@ MODLE_DEV void detect_primary(Cell& c, BoundaryCounts bc, const u32* fwd_sorted)
         ws.rev_coll[rev_idx] = cw_make(fwd_idx, prim);
         ws.fwd_coll[fwd_idx] = cw_make(rev_idx, prim);
       } else if (rev_occ && !fwd_occ) {
-        const u32 barrier_pos = c.iv->bar_pos[cw_index(rc)];
+        const u32 barrier_pos = stalling_barrier_pos(*c.iv, rc);
         if (cpos_fwd > barrier_pos) ws.rev_coll[rev_idx] = cw_make(fwd_idx, prim);
         ws.fwd_coll[fwd_idx] = cw_make(rev_idx, prim);
       } else if (!rev_occ && fwd_occ) {
-        const u32 barrier_pos = c.iv->bar_pos[cw_index(fc)];
+        const u32 barrier_pos = stalling_barrier_pos(*c.iv, fc);
         ws.rev_coll[rev_idx] = cw_make(fwd_idx, prim);
         if (cpos_rev < barrier_pos) ws.fwd_coll[fwd_idx] = cw_make(rev_idx, prim);
       }
@@ -1833,7 +1844,10 @@ MODLE_DEV void reset_cell_buffers(Cell& c) {
 // Simulates one (interval, cell) task on the calling wave.  Returns 0 or a non-zero status when
 // an internal capacity was exceeded (the host turns that into an error).
 MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& task,
-                            const Workspace& ws, const WaveLds& lds, CellResult& res) {
+                            const Workspace& ws, const WaveLds& lds, CellResult& res,
+                            u32 debug_stage = 0) {
+#define MODLE_STAGE(k) \
+  if (debug_stage == (k)) { res.epochs = (k); return 0; }
   Cell c;
   c.p = &p;
   c.iv = &iv;
@@ -1846,8 +1860,11 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
   c.error = 0;
   c.g.ring = lds.ring;
   c.g.jump = lds.jump_table;
+  MODLE_STAGE(1)
   rng_init(c.g, task.prng);
+  MODLE_STAGE(2)
   reset_cell_buffers(c);
+  MODLE_STAGE(3)
 
   u64 epoch = 0, num_burnin_epochs = 0, num_contacts = 0;
   u64 sum_active = 0, events_done = 0, sim_epochs = 0;
@@ -1857,6 +1874,7 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
       static_cast<f64>(task.num_lefs) / static_cast<f64>(p.burnin_target_epochs_for_lef_activation);
 
   barriers_init_states(c);
+  MODLE_STAGE(4)
   if (p.skip_burnin) {
     c.n_active = c.n_lefs;
     burnin_completed = true;
@@ -1888,11 +1906,20 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
       } while (c.n_active == 0);
     }
 
+    MODLE_STAGE(5)
+    if (debug_stage >= 100 && epoch == debug_stage - 100) {
+      res.epochs = epoch;
+      res.burnin_epochs = burnin_completed ? 1 : 0;
+      res.num_contacts = c.n_active;
+      return 0;
+    }
     const u32 epoch32 = static_cast<u32>(epoch);
     phase_bind(c, epoch32);
+    MODLE_STAGE(6)
     rank_update<false>(c, epoch32, first_ranking);
     rank_update<true>(c, epoch32, first_ranking);
     first_ranking = false;
+    MODLE_STAGE(7)
 
     if (burnin_completed) {
       num_contacts += phase_sample_contacts(c, task.contacts_per_epoch, task.num_target_contacts,
@@ -1903,8 +1930,10 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
     sum_active += c.n_active;
     ++sim_epochs;
     phase_generate_moves(c, burnin_completed);
+    MODLE_STAGE(8)
     barriers_next_state(c);
     clear_collisions(c);
+    MODLE_STAGE(9)
     if (!phase_process_collisions(c)) {
       status = c.error;
       break;
@@ -1918,7 +1947,9 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
                 c.ws.rev_coll[i] & 0xFFFFFF, c.ws.fwd_coll[i] >> 24, c.ws.fwd_coll[i] & 0xFFFFFF);
     }
 #endif
+    MODLE_STAGE(10)
     phase_extrude_and_release(c, burnin_completed);
+    MODLE_STAGE(11)
 #ifdef MODLE_TRACE
     {
       u64 sr = 0, sf = 0;

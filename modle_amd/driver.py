@@ -1,0 +1,74 @@
+"""Host driver standing in for `Simulation::run_simulate` (reference:
+src/libmodle/cpu/scheduler_simulate.cpp:43-170) on top of the C ABI.
+
+For every interval in genome order it derives the per-cell tasks exactly like the reference
+(seed hash, one PRNG jump per cell, target-contact split), keeps the cells of this rank's shard,
+registers the interval with the simulator and enqueues the tasks.  One launch then processes the
+tasks of all intervals together (the reference's workers also drain one queue that mixes
+intervals).  Cells are independent, so sharding them over ranks needs no data-path collective;
+the per-rank contact matrices are summed afterwards (`reduce_outputs`).
+"""
+from . import api
+
+
+def shard_bounds(num_cells, rank, world):
+    """Contiguous cell-id range [lo, hi) owned by `rank` (any partition gives the same result:
+    every cell's PRNG state is fixed by its cell id)."""
+    base, rem = divmod(num_cells, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def plan_genome(cfg, genome, rank=0, world=1):
+    """Task derivation for every interval of `genome` (list of dicts, see synthetic.py).
+
+    Returns a list of {interval, tasks (this rank's shard), nrows, ncols, skipped}."""
+    plan = []
+    task_id = 0
+    for iv in genome:
+        size = iv["end"] - iv["start"]
+        nrows, ncols = api.matrix_shape(cfg, size)
+        entry = {"interval": iv, "nrows": nrows, "ncols": ncols, "tasks": None, "skipped": False}
+        if not cfg.simulate_chromosomes_wo_barriers and len(iv["bar_pos"]) == 0:
+            # scheduler_simulate.cpp:111-124: intervals without barriers are skipped
+            entry["skipped"] = True
+            plan.append(entry)
+            continue
+        tasks = api.make_tasks(cfg, iv["name"], iv["size"], iv["start"], iv["end"], task_id)
+        task_id += int(cfg.num_cells)
+        lo, hi = shard_bounds(int(cfg.num_cells), rank, world)
+        entry["tasks"] = api.slice_tasks(tasks, lo, hi)
+        plan.append(entry)
+    return plan
+
+
+def enqueue_plan(sim, cfg, plan, device_buffers=None):
+    """Registers intervals + tasks of a plan with `sim`.  `device_buffers`: optional list of
+    (contacts_ptr, occupancy_ptr) device pointers per plan entry (e.g. torch tensors)."""
+    ids = []
+    for k, entry in enumerate(plan):
+        if entry["skipped"]:
+            ids.append(None)
+            continue
+        iv = entry["interval"]
+        stp_active, stp_inactive = api.barrier_stps(cfg, iv["bar_occupancy"])
+        dc, do = (None, None) if device_buffers is None else device_buffers[k]
+        iid = sim.add_interval(iv["start"], iv["end"], iv["bar_pos"], iv["bar_dir"], stp_active,
+                               stp_inactive, dc, do)
+        if len(entry["tasks"]) != 0:
+            sim.submit(iid, entry["tasks"])
+        ids.append(iid)
+    return ids
+
+
+def algorithmic_bytes(results, n_barriers, track_1d=True):
+    """ALGORITHMIC HBM bytes of a set of finished cells of one interval:
+    per simulated epoch 40 B per active LEF (read+write of rev/fwd position, binding epoch and
+    the two ranks), 22 B per barrier (position, two transition probabilities, state read+write)
+    and 64 B of PRNG state; per sampling event 8 B (contact read-modify-write) and, with the 1-D
+    occupancy track, 16 B."""
+    total = 0
+    for r in results:
+        total += 40 * r.sum_active_lefs + (22 * n_barriers + 64) * r.sim_epochs
+        total += (8 + (16 if track_1d else 0)) * r.sampling_events
+    return total

@@ -84,7 +84,7 @@ def lib():
         [P(Config), sz] + [u64p] * 7 + [sz, u64p, u8p, u8p, u64p, u64p, P(Prng), C.c_uint64,
                                         C.c_uint64])
     L.mo_detect_primary_lef_lef_collisions.argtypes = (
-        [P(Config), sz] + [u64p] * 9 + [P(Prng), C.c_uint64, C.c_uint64])
+        [P(Config), sz] + [u64p] * 6 + [sz] + [u64p] * 3 + [P(Prng), C.c_uint64, C.c_uint64])
     L.mo_correct_moves_for_lef_bar_collisions.argtypes = [sz] + [u64p] * 7
     L.mo_correct_moves_for_primary_lef_lef_collisions.argtypes = [sz] + [u64p] * 8
     L.mo_process_secondary_lef_lef_collisions.argtypes = (

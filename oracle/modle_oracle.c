@@ -882,12 +882,23 @@ static void lef_lef_collision_pos(uint64_t rev_p, uint64_t fwd_p, uint64_t rev_m
   *out_fwd = collision_pos - 1;
 }
 
+/* The reference reads barriers.pos(collision.decode_index()) without checking that the
+ * collision is a LEF-BAR one (simulation_detect_collisions.cpp:371, 389; asserted in debug
+ * builds only).  A boundary-flagged unit (index 5 / 3) reaching this point makes it read barrier
+ * #5 / #3 -- or out of bounds when there are fewer barriers, which is undefined behaviour in
+ * the reference and reads as position 0 here. */
+static uint64_t stalling_barrier_pos(size_t nb, const uint64_t* bar_pos, uint64_t word) {
+  const uint64_t idx = coll_index(word);
+  return idx < nb ? bar_pos[idx] : 0;
+}
+
 void mo_detect_primary_lef_lef_collisions(const mo_params_t* p, size_t n, const uint64_t* rev_pos,
                                           const uint64_t* fwd_pos, const uint64_t* rev_rank,
                                           const uint64_t* fwd_rank, const uint64_t* rev_moves,
-                                          const uint64_t* fwd_moves, const uint64_t* bar_pos,
-                                          uint64_t* rev_coll, uint64_t* fwd_coll, mo_prng_t* g,
-                                          uint64_t n5, uint64_t n3) {
+                                          const uint64_t* fwd_moves, size_t nb,
+                                          const uint64_t* bar_pos, uint64_t* rev_coll,
+                                          uint64_t* fwd_coll, mo_prng_t* g, uint64_t n5,
+                                          uint64_t n3) {
   /* simulation_detect_collisions.cpp:250-397 */
   if (n5 == n || n3 == n) return;
   size_t i1 = 0;
@@ -925,7 +936,7 @@ void mo_detect_primary_lef_lef_collisions(const mo_params_t* p, size_t n, const 
         rev_coll[rev_idx] = coll_make(fwd_idx, prim);
         fwd_coll[fwd_idx] = coll_make(rev_idx, prim);
       } else if (rev_occ && !fwd_occ) {
-        const uint64_t barrier_pos = bar_pos[coll_index(rev_coll[rev_idx])];
+        const uint64_t barrier_pos = stalling_barrier_pos(nb, bar_pos, rev_coll[rev_idx]);
         if (cpos_fwd > barrier_pos) {
           rev_coll[rev_idx] = coll_make(fwd_idx, prim);
           fwd_coll[fwd_idx] = coll_make(rev_idx, prim);
@@ -933,7 +944,7 @@ void mo_detect_primary_lef_lef_collisions(const mo_params_t* p, size_t n, const 
           fwd_coll[fwd_idx] = coll_make(rev_idx, prim);
         }
       } else if (!rev_occ && fwd_occ) {
-        const uint64_t barrier_pos = bar_pos[coll_index(fwd_coll[fwd_idx])];
+        const uint64_t barrier_pos = stalling_barrier_pos(nb, bar_pos, fwd_coll[fwd_idx]);
         rev_coll[rev_idx] = coll_make(fwd_idx, prim);
         if (cpos_rev < barrier_pos) fwd_coll[fwd_idx] = coll_make(rev_idx, prim);
       }
@@ -1120,7 +1131,7 @@ void mo_process_collisions(const mo_params_t* p, uint64_t start, uint64_t end, s
                                fwd_moves, nb, bar_pos, bar_dir, bar_active, rev_coll, fwd_coll, g,
                                n5, n3);
   mo_detect_primary_lef_lef_collisions(p, n, rev_pos, fwd_pos, rev_rank, fwd_rank, rev_moves,
-                                       fwd_moves, bar_pos, rev_coll, fwd_coll, g, n5, n3);
+                                       fwd_moves, nb, bar_pos, rev_coll, fwd_coll, g, n5, n3);
   mo_correct_moves_for_lef_bar_collisions(n, rev_pos, fwd_pos, bar_pos, rev_moves, fwd_moves,
                                           rev_coll, fwd_coll);
   mo_correct_moves_for_primary_lef_lef_collisions(n, rev_pos, fwd_pos, rev_rank, fwd_rank,

@@ -181,9 +181,10 @@ void mo_detect_lef_bar_collisions(const mo_params_t* p, size_t n, const uint64_t
 void mo_detect_primary_lef_lef_collisions(const mo_params_t* p, size_t n, const uint64_t* rev_pos,
                                           const uint64_t* fwd_pos, const uint64_t* rev_rank,
                                           const uint64_t* fwd_rank, const uint64_t* rev_moves,
-                                          const uint64_t* fwd_moves, const uint64_t* bar_pos,
-                                          uint64_t* rev_coll, uint64_t* fwd_coll, mo_prng_t* g,
-                                          uint64_t n5, uint64_t n3);
+                                          const uint64_t* fwd_moves, size_t nb,
+                                          const uint64_t* bar_pos, uint64_t* rev_coll,
+                                          uint64_t* fwd_coll, mo_prng_t* g, uint64_t n5,
+                                          uint64_t n3);
 void mo_correct_moves_for_lef_bar_collisions(size_t n, const uint64_t* rev_pos,
                                              const uint64_t* fwd_pos, const uint64_t* bar_pos,
                                              uint64_t* rev_moves, uint64_t* fwd_moves,

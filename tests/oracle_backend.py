@@ -54,7 +54,7 @@ class OracleBackend:
     def detect_primary_lef_lef_collisions(self, cfg, st, rng, n5=0, n3=0):
         self.L.mo_detect_primary_lef_lef_collisions(
             C.byref(cfg), st.n, st.rev_pos, st.fwd_pos, st.rev_rank, st.fwd_rank, st.rev_moves,
-            st.fwd_moves, st.bar_pos, st.rev_coll, st.fwd_coll, C.byref(rng), n5, n3)
+            st.fwd_moves, len(st.bar_pos), st.bar_pos, st.rev_coll, st.fwd_coll, C.byref(rng), n5, n3)
 
     def process_lef_lef_collisions(self, cfg, st, rng):
         # Simulation::test_process_lef_lef_collisions (simulation.hpp:540-555)

@@ -1,0 +1,56 @@
+"""Shared inputs for the whole-cell parity tests (oracle vs emulated device code vs GPU)."""
+import numpy as np
+
+from modle_amd import api, synthetic
+
+# name -> (chrom size, Config overrides, with barriers, barrier spacing)
+CASES = {
+    # BASELINE.json configs[0]: 5 Mb, 64 cells, 16 LEFs/Mb, no barriers
+    "config0_5mb_nobarriers": dict(size=5_000_000, barriers=False,
+                                   cfg=dict(num_cells=64, number_of_lefs_per_mbp=16.0,
+                                            simulate_chromosomes_wo_barriers=1)),
+    # barriers + default probabilities (bypass 0.1 => secondary / fix paths are exercised)
+    "chr20mb_barriers": dict(size=20_000_000, barriers=True, cfg=dict(num_cells=512)),
+    # collision-heavy stress shaped like BASELINE.json configs[4]
+    "chr12mb_dense_softstall": dict(size=12_000_000, barriers=True,
+                                    cfg=dict(num_cells=512, number_of_lefs_per_mbp=64.0,
+                                             lef_bar_minor_collision_pblock=0.3,
+                                             soft_stall_lef_stability_multiplier=2.0)),
+    # no noise, loop contacts only, no 1-D occupancy track, bypass disabled
+    "chr8mb_loop_only": dict(size=8_000_000, barriers=True,
+                             cfg=dict(num_cells=256, contact_sampling_strategy=4,
+                                      track_1d_lef_position=0,
+                                      probability_of_extrusion_unit_bypass=0.0)),
+    # stopping on epochs instead of contact density is not derived by transform_config here;
+    # burn-in skipped: every LEF is bound in epoch 0 (full-sort path of the ranking)
+    "chr6mb_skip_burnin": dict(size=6_000_000, barriers=True,
+                               cfg=dict(num_cells=128, skip_burnin=1)),
+}
+
+
+def build_case(name):
+    spec = CASES[name]
+    cfg = api.make_config(**spec["cfg"])
+    chrom = synthetic.synthetic_chromosome("chrT", spec["size"], with_barriers=spec["barriers"])
+    stp_active, stp_inactive = api.barrier_stps(cfg, chrom["bar_occupancy"])
+    tasks = api.make_tasks(cfg, chrom["name"], chrom["size"], chrom["start"], chrom["end"])
+    nrows, ncols = api.matrix_shape(cfg, chrom["end"] - chrom["start"])
+    return dict(cfg=cfg, chrom=chrom, stp_active=stp_active, stp_inactive=stp_inactive,
+                tasks=tasks, nrows=nrows, ncols=ncols)
+
+
+def assert_same_results(res_a, res_b, what):
+    assert len(res_a) == len(res_b)
+    for i, (a, b) in enumerate(zip(res_a, res_b)):
+        for field in ("epochs", "burnin_epochs", "num_contacts", "raws_consumed",
+                      "sum_active_lefs", "sampling_events", "sim_epochs"):
+            assert getattr(a, field) == getattr(b, field), f"{what}: cell {i}: {field}"
+
+
+def assert_same_outputs(a, b, what):
+    ca, ma, oa = a
+    cb, mb, ob = b
+    assert ma == mb, f"{what}: missed updates {ma} != {mb}"
+    assert np.array_equal(ca, cb), f"{what}: contact matrices differ"
+    if oa is not None and ob is not None:
+        assert np.array_equal(oa, ob), f"{what}: 1-D occupancy differs"
