@@ -479,7 +479,9 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
     d.nrows = rec.nrows;
     d.ncols = rec.ncols;
   }
-  const int grid = std::max(1, std::min<int>(h->num_cus, static_cast<int>((sorted.size() + kWavesPerBlock - 1) / kWavesPerBlock)));
+  // one workgroup per CU even when there are fewer tasks than waves: the waves that win a task
+  // are then spread over all CUs instead of being packed 8 to a CU
+  const int grid = std::max(1, static_cast<int>(std::min<size_t>(h->num_cus, sorted.size())));
   const auto layout = modle_host::workspace_layout(max_lefs, max_barriers, h->params.hist_len);
   const size_t n_slots = static_cast<size_t>(grid) * kWavesPerBlock;
   HIP_TRY(h->d_intervals.ensure(ivs.size()));

@@ -1,0 +1,24 @@
+"""Whole-cell parity of the product's DEVICE CODE (run by the CPU lane emulator, tests/wave_emu)
+against the oracle.  Small inputs: the emulator is ~100x slower than the oracle."""
+import pytest
+
+import emu_sim
+from modle_amd import api
+from parity_cases import assert_same_outputs, assert_same_results, build_case
+
+
+@pytest.mark.parametrize("name,ncells", [("config0_5mb_nobarriers", 2), ("chr6mb_skip_burnin", 1),
+                                         ("chr8mb_loop_only", 1)])
+def test_emulated_device_code_matches_oracle(oracle, name, ncells):
+    case = build_case(name)
+    cfg, chrom = case["cfg"], case["chrom"]
+    tasks = api.slice_tasks(case["tasks"], 0, ncells)
+    track = bool(cfg.track_1d_lef_position)
+    oc, om, oo, ores = oracle.simulate_interval(
+        cfg, chrom["start"], chrom["end"], chrom["bar_pos"], chrom["bar_dir"],
+        case["stp_active"], case["stp_inactive"], tasks, nthreads=1, track_occupancy=track)
+    ec, em, eo, eres = emu_sim.simulate_interval(
+        cfg, chrom["start"], chrom["end"], chrom["bar_pos"], chrom["bar_dir"], case["stp_active"],
+        case["stp_inactive"], tasks, case["nrows"], case["ncols"], track_occupancy=track)
+    assert_same_results(ores, eres, name)
+    assert_same_outputs((oc, om, oo), (ec, em, eo), name)

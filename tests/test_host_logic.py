@@ -1,0 +1,118 @@
+"""Host-side logic of the product library (no GPU needed): Config defaults and derived
+parameters, interval seeding, PRNG state derivation, task generation -- checked against the
+oracle, the python `xxhash` module and the values SURVEY.md section 8c quotes."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import xxhash
+
+from modle_amd import _lib, api
+from modle_amd.params import Config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "modle_hip.h")).read()
+    declared = set(re.findall(r"\b(modle_hip_[a-z0-9_]+)\s*\(", header))
+    declared -= {"modle_hip_config", "modle_hip_task", "modle_hip_cell_result", "modle_hip_handle"}
+    assert declared, "no declarations parsed"
+    lib = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} is declared in include/modle_hip.h but not exported"
+    assert declared == set(_lib.EXPORTS)
+
+
+def test_config_layout_matches_header():
+    header = open(os.path.join(ROOT, "include", "modle_hip.h")).read()
+    body = header.split("typedef struct modle_hip_config {")[1].split("} modle_hip_config;")[0]
+    fields = re.findall(r"^\s*(?:uint64_t|double)\s+(\w+);", body, re.M)
+    assert fields == [f[0] for f in Config._fields_]
+    assert C.sizeof(Config) == 8 * len(fields)
+
+
+def test_default_config_and_transform():
+    # reference: simulation_config.hpp:47-113 and cli.cpp:886-1016
+    cfg = api.default_config()
+    assert (cfg.bin_size, cfg.diagonal_width, cfg.num_cells) == (5000, 3_000_000, 512)
+    assert cfg.number_of_lefs_per_mbp == 20 and cfg.avg_lef_processivity == 300_000
+    api.transform_config(cfg)
+    assert cfg.rev_extrusion_speed == cfg.fwd_extrusion_speed == 4000
+    assert cfg.rev_extrusion_speed_std == cfg.fwd_extrusion_speed_std == 200.0
+    assert cfg.prob_of_lef_release == 8000 / 300000
+    assert cfg.burnin_target_epochs_for_lef_activation == 187  # 5 * 300000 / 8000
+    assert cfg.tad_to_loop_contact_ratio == 5.0
+    assert cfg.probability_of_extrusion_unit_bypass == 0.1  # ratio == 1: no normalisation
+    assert cfg.extrusion_barrier_occupancy == pytest.approx(0.3 / 1.3)
+    # a different resolution rescales the speeds and triggers probability normalisation
+    cfg2 = api.make_config(bin_size=10000)
+    assert cfg2.rev_extrusion_speed == 8000
+    assert cfg2.probability_of_extrusion_unit_bypass == pytest.approx(0.2)
+    assert cfg2.barrier_not_occupied_stp == pytest.approx(0.7 ** 2)
+    # loop-only sampling disables TAD contacts (cli.cpp:970-983)
+    assert api.make_config(contact_sampling_strategy=4).tad_to_loop_contact_ratio == 0.0
+    assert np.isinf(api.make_config(contact_sampling_strategy=2 | 1).tad_to_loop_contact_ratio)
+
+
+def test_barrier_stp_math():
+    # reference: test/units/simulation_internal/extrusion_barriers_test.cpp:36-97
+    L = _lib.lib()
+    assert L.modle_hip_occupancy_from_stp(1.0, 0.0) == 1.0
+    assert L.modle_hip_occupancy_from_stp(0.0, 1.0) == 0.0
+    assert L.modle_hip_occupancy_from_stp(0.7, 0.7) == 0.5
+    assert L.modle_hip_occupancy_from_stp(0.7, 0.5) == pytest.approx(0.625, rel=1e-12)
+    assert L.modle_hip_occupancy_from_stp(1.0, 0.5) == 1.0
+    assert L.modle_hip_occupancy_from_stp(0.7, 1.0) == 0.0
+    for stp_inactive, occ in ((0.7, 0.85), (0.65, 0.93)):
+        stp_active = L.modle_hip_stp_active_from_occupancy(stp_inactive, occ)
+        assert L.modle_hip_occupancy_from_stp(stp_active, stp_inactive) == pytest.approx(occ)
+
+
+def test_interval_hash_matches_xxhash():
+    for name, size, start, end, seed in (("chr1", 248956422, 0, 248956422, 0),
+                                         ("chrY", 57227415, 0, 57227415, 0),
+                                         ("chrUn_KI270302v1_a_rather_long_name", 2274, 10, 2000, 7),
+                                         ("x" * 150, 12345, 1, 12345, 2 ** 63 + 5)):
+        data = name.encode() + b"".join(int(v).to_bytes(8, "little") for v in (size, start, end))
+        assert api.interval_hash(name, size, start, end, seed) == \
+            xxhash.xxh3_64(data, seed=seed).intdigest()
+    # values quoted in SURVEY.md section 8c
+    assert api.interval_hash("chr1", 248956422, 0, 248956422, 0) == 0xA53D8E35875B84B9
+
+
+def test_prng_seed_and_jump_match_oracle(oracle):
+    assert api.prng_seed(752741483) == [0x2A3BC28B8FC13C5A, 0xDB997EC403E6D05D,
+                                        0x3B9841261CC6FECA, 0x3943D8B92B198BDB]
+    g = oracle.prng_from_seed(10556020843759504871)
+    assert api.prng_seed(10556020843759504871) == g.state()
+    oracle.lib().mo_prng_jump(C.byref(g))
+    assert api.prng_jump(api.prng_seed(10556020843759504871)) == g.state()
+
+
+def test_make_tasks_matches_oracle(oracle):
+    cfg = api.make_config(num_cells=37, seed=11)
+    mine = api.make_tasks(cfg, "chr7", 159345973, 0, 159345973, first_task_id=100)
+    ref = oracle.make_tasks(cfg, "chr7", 159345973, 0, 159345973, first_id=100)
+    assert len(mine) == len(ref) == 37
+    total = 0
+    for a, b in zip(mine, ref):
+        assert (a.id, a.cell_id, a.num_lefs, a.num_target_contacts, a.num_target_epochs) == \
+               (b.id, b.cell_id, b.num_lefs, b.num_target_contacts, b.num_target_epochs)
+        assert list(a.prng) == list(b.prng)
+        total += a.num_target_contacts
+    nrows, ncols = api.matrix_shape(cfg, 159345973)
+    assert total == nrows * ncols  # density 1.0: the split never overshoots
+    assert api.compute_num_lefs(cfg, 248956422) == 4979
+    assert api.compute_contacts_per_epoch(cfg, 4979) == 797
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(api.ModleHipError, match="no CPU fallback"):
+        api.Simulator(api.make_config())

@@ -1,0 +1,92 @@
+"""Pins and sanity-checks the oracle's PRNG and distribution restatement."""
+import ctypes as C
+import math
+
+import numpy as np
+
+
+def test_prng_known_answers(oracle):
+    # SURVEY.md section 8c (xoshiro-cpp 1.1 semantics; consistent with the reference's
+    # seed-dependent tests "Simulation 011/012")
+    L = oracle.lib()
+    g = oracle.prng_from_seed(752741483)
+    assert [L.mo_prng_next(C.byref(g)) for _ in range(3)] == \
+        [0xCC992FEFAA72FC27, 0x71DF6BFD251890FC, 0xE07EE158ACF122D2]
+    g = oracle.prng_from_seed(10556020843759504871)
+    assert [L.mo_prng_next(C.byref(g)) for _ in range(3)] == \
+        [0x251CEF6953CE03A9, 0x58DAC8141359ADFE, 0x23E6C58DEF1F389D]
+    # first Bernoulli(0.75) of the reference's "Simulation 011" stream must fail
+    g = oracle.prng_from_seed(752741483)
+    assert L.mo_bernoulli(C.byref(g), 0.75) == 0
+
+
+def test_jump_equals_2_128_steps_structure(oracle):
+    # jump() must commute with stepping: jump(next^k(s)) == next^k(jump(s))
+    L = oracle.lib()
+    a = oracle.prng_from_seed(1)
+    b = oracle.prng_from_seed(1)
+    for _ in range(17):
+        L.mo_prng_next(C.byref(a))
+    L.mo_prng_jump(C.byref(a))
+    L.mo_prng_jump(C.byref(b))
+    for _ in range(17):
+        L.mo_prng_next(C.byref(b))
+    assert a.state() == b.state()
+
+
+def test_uniform_int_bounds_and_degenerate_ranges(oracle):
+    L = oracle.lib()
+    g = oracle.prng_from_seed(3)
+    before = g.count
+    assert L.mo_uniform_int(C.byref(g), 42, 42) == 42 and g.count == before  # no draw
+    vals = [L.mo_uniform_int(C.byref(g), 10, 19) for _ in range(5000)]
+    assert min(vals) == 10 and max(vals) == 19
+    assert abs(np.mean(vals) - 14.5) < 0.2
+    assert L.mo_bernoulli(C.byref(g), 0.0) == 0  # p == 0 consumes nothing
+    assert g.count == before + 5000
+
+
+def test_distribution_moments(oracle):
+    L = oracle.lib()
+    g = oracle.prng_from_seed(12345)
+    n = 200_000
+    x = np.array([L.mo_normal(C.byref(g), 4000.0, 200.0) for _ in range(n)])
+    assert abs(x.mean() - 4000) < 2 and abs(x.std() - 200) < 2
+    # ~98.8 % of the normal draws take the ziggurat fast path (one raw output); the rest need a
+    # wedge / tail test and possibly retries, ~4 % extra outputs in total
+    assert 1.02 < g.count / n < 1.06
+    for mean in (0.43, 26.6):  # inversion and PTRD regimes (chr1 defaults give 26.6)
+        k = np.array([L.mo_poisson(C.byref(g), mean) for _ in range(60_000)], dtype=float)
+        assert abs(k.mean() - mean) < 0.05 * max(1.0, mean) and abs(k.var() - mean) < 0.1 * max(1, mean)
+    for t, p in ((13, 1 / 6), (797, 1 / 6)):  # inversion and BTRD regimes
+        k = np.array([L.mo_binomial(C.byref(g), t, p) for _ in range(60_000)], dtype=float)
+        assert abs(k.mean() - t * p) < 0.02 * t * p + 0.02
+        assert abs(k.var() - t * p * (1 - p)) < 0.05 * t * p
+    u = np.array([L.mo_canonical(C.byref(g)) for _ in range(20_000)])
+    assert 0.0 <= u.min() and u.max() < 1.0
+    gev = np.array([L.mo_genextreme(C.byref(g), 0.0, 5000.0, 0.001) for _ in range(50_000)])
+    # xi -> 0 is the Gumbel law: mean ~ +0.5772 sigma, std ~ pi / sqrt(6) sigma
+    assert abs(gev.mean() - 0.5772 * 5000) < 150
+    assert abs(gev.std() - math.pi / math.sqrt(6) * 5000) < 300
+
+
+def test_ziggurat_tables_match_generator():
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "tests", "_zig_regen.h")
+    try:
+        subprocess.run([sys.executable, os.path.join(root, "tools", "gen_ziggurat_tables.py"), out],
+                       check=True, capture_output=True)
+        regenerated = open(out).read()
+    finally:
+        if os.path.exists(out):
+            os.remove(out)
+    assert regenerated == open(os.path.join(root, "oracle", "zig_tables.h")).read()
+    assert regenerated == open(os.path.join(root, "modle_amd", "csrc", "zig_tables.h")).read()
+    # literals of the published Marsaglia-Tsang construction
+    assert "0x1.b8a8c1f45f8c2p+1" in regenerated or float.fromhex("0x1.b8a8c1f45f8c2p+1")
+    x1 = 3.4426198558966521214
+    assert math.isclose(math.exp(-x1 * x1 / 2), 0.0026696290839025035, rel_tol=1e-15)
