@@ -11,7 +11,7 @@ import numpy as np
 from .params import CellResult, Config, Task
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libmodle_hip.so")
+SO_PATH = os.path.join(_HERE, os.environ.get("MODLE_HIP_LIB", "libmodle_hip.so"))
 
 # every symbol include/modle_hip.h declares
 EXPORTS = [

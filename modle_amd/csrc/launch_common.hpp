@@ -83,7 +83,7 @@ inline uint32_t pow2_ceil(uint32_t x) {
 
 // words of scratch one wave needs for `max_lefs` LEFs / `max_barriers` barriers
 struct WorkspaceLayout {
-  size_t u32_words;   // 13 arrays of max_lefs
+  size_t u32_words;   // NUM_STATE_ARRAYS arrays of max_lefs
   size_t u64_words;   // sort keys
   size_t f64_words;   // burn-in history
   size_t u8_bytes;    // barrier states
@@ -94,7 +94,7 @@ inline WorkspaceLayout workspace_layout(uint32_t max_lefs, uint32_t max_barriers
                                         uint32_t hist_len) {
   WorkspaceLayout w;
   const size_t Lp = (static_cast<size_t>(max_lefs) + 63) & ~size_t(63);
-  w.u32_words = 13 * Lp;
+  w.u32_words = modle_dev::NUM_STATE_ARRAYS * Lp;
   w.u64_words = pow2_ceil(max_lefs < 64 ? 64 : max_lefs);
   w.f64_words = 2 * static_cast<size_t>(hist_len);
   w.u8_bytes = (static_cast<size_t>(max_barriers) + 63) & ~size_t(63);
@@ -115,24 +115,78 @@ inline modle_dev::Workspace carve_workspace(void* base, uint32_t max_lefs, uint3
   ws.hist = reinterpret_cast<double*>(p);
   p += w.f64_words * 8;
   uint32_t* q = reinterpret_cast<uint32_t*>(p);
-  ws.rev_pos = q + 0 * Lp;
-  ws.fwd_pos = q + 1 * Lp;
-  ws.epoch = q + 2 * Lp;
-  ws.rev_rank = q + 3 * Lp;
-  ws.fwd_rank = q + 4 * Lp;
-  ws.rev_moves = q + 5 * Lp;
-  ws.fwd_moves = q + 6 * Lp;
-  ws.rev_coll = q + 7 * Lp;
-  ws.fwd_coll = q + 8 * Lp;
-  ws.tmp_a = q + 9 * Lp;
-  ws.tmp_b = q + 10 * Lp;
-  ws.tmp_c = q + 11 * Lp;
-  ws.tmp_d = q + 12 * Lp;
+  uint32_t** slots[12] = {&ws.r_pos, &ws.r_id, &ws.r_move, &ws.r_coll, &ws.f_pos, &ws.f_id,
+                          &ws.f_move, &ws.f_coll, &ws.epoch, &ws.r_rank, &ws.f_rank, &ws.stall};
+  for (int k = 0; k < 12; ++k) *slots[k] = q + static_cast<size_t>(k) * Lp;
+  for (uint32_t k = 0; k < modle_dev::NUM_TMP; ++k) ws.tmp[k] = q + (12 + static_cast<size_t>(k)) * Lp;
   p += w.u32_words * 4;
   ws.bar_active = reinterpret_cast<uint8_t*>(p);
   ws.capacity_lefs = max_lefs;
   ws.capacity_barriers = max_barriers;
   return ws;
+}
+
+// Phase-level test entry point: the caller's arrays (reference layout, 64-bit) packed into nine
+// consecutive u32 arrays of n entries (modle_dev::TestImage)
+template <class Image>
+inline void fill_test_image(uint32_t* base, size_t n, const uint64_t* rev_pos,
+                            const uint64_t* fwd_pos, const uint64_t* epoch,
+                            const uint64_t* rev_rank, const uint64_t* fwd_rank,
+                            const uint64_t* rev_moves, const uint64_t* fwd_moves,
+                            const uint64_t* rev_coll, const uint64_t* fwd_coll, Image& img) {
+  img.rev_pos = base + 0 * n;
+  img.fwd_pos = base + 1 * n;
+  img.epoch = base + 2 * n;
+  img.rev_rank = base + 3 * n;
+  img.fwd_rank = base + 4 * n;
+  img.rev_moves = base + 5 * n;
+  img.fwd_moves = base + 6 * n;
+  img.rev_coll = base + 7 * n;
+  img.fwd_coll = base + 8 * n;
+  for (size_t i = 0; i < n; ++i) {
+    img.rev_pos[i] = pos_to_dev(rev_pos[i]);
+    img.fwd_pos[i] = pos_to_dev(fwd_pos[i]);
+    img.epoch[i] = pos_to_dev(epoch[i]);
+    img.rev_rank[i] = static_cast<uint32_t>(rev_rank[i]);
+    img.fwd_rank[i] = static_cast<uint32_t>(fwd_rank[i]);
+    img.rev_moves[i] = static_cast<uint32_t>(rev_moves[i]);
+    img.fwd_moves[i] = static_cast<uint32_t>(fwd_moves[i]);
+    img.rev_coll[i] = coll_to_dev(rev_coll[i]);
+    img.fwd_coll[i] = coll_to_dev(fwd_coll[i]);
+  }
+}
+
+template <class Image>
+inline void read_test_image(const Image& img, size_t n, uint64_t* rev_pos, uint64_t* fwd_pos,
+                            uint64_t* epoch, uint64_t* rev_rank, uint64_t* fwd_rank,
+                            uint64_t* rev_moves, uint64_t* fwd_moves, uint64_t* rev_coll,
+                            uint64_t* fwd_coll) {
+  for (size_t i = 0; i < n; ++i) {
+    rev_pos[i] = pos_to_abi(img.rev_pos[i]);
+    fwd_pos[i] = pos_to_abi(img.fwd_pos[i]);
+    epoch[i] = pos_to_abi(img.epoch[i]);
+    rev_rank[i] = img.rev_rank[i];
+    fwd_rank[i] = img.fwd_rank[i];
+    rev_moves[i] = img.rev_moves[i];
+    fwd_moves[i] = img.fwd_moves[i];
+    rev_coll[i] = coll_to_abi(img.rev_coll[i]);
+    fwd_coll[i] = coll_to_abi(img.fwd_coll[i]);
+  }
+}
+
+// bucket table for barrier lookups (see modle_dev::Interval::bar_bucket)
+inline std::vector<uint32_t> build_barrier_buckets(uint64_t start, uint64_t end,
+                                                   const std::vector<uint32_t>& bar_pos) {
+  const uint32_t shift = modle_dev::BAR_BUCKET_SHIFT;
+  const size_t n_buckets = static_cast<size_t>((end - start) >> shift) + 2;
+  std::vector<uint32_t> table(n_buckets);
+  size_t i = 0;
+  for (size_t b = 0; b < n_buckets; ++b) {
+    const uint64_t lo = start + (static_cast<uint64_t>(b) << shift);
+    while (i < bar_pos.size() && bar_pos[i] < lo) ++i;
+    table[b] = static_cast<uint32_t>(i);
+  }
+  return table;
 }
 
 }  // namespace modle_host

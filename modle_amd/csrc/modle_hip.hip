@@ -10,6 +10,9 @@
 // ring of raw PRNG outputs; per-cell LEF / barrier state lives in a per-wave slice of a device
 // workspace.
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -50,6 +53,9 @@ struct SimArgs {
   CellResult* results;
   u32* status;        // one word per task
   u32* task_counter;
+  u64* trace;  // diagnostic per-epoch trace of task 0 (MODLE_HIP_TRACE) or nullptr
+  u32 trace_cap;
+  u32 pad2_;
   char* workspace;
   u64 workspace_stride;
   u32 n_tasks;
@@ -71,20 +77,20 @@ __device__ Workspace device_carve(char* base, u32 max_lefs, u32 max_barriers, u3
   ws.hist = reinterpret_cast<f64*>(p);
   p += 2 * static_cast<u64>(hist_len) * 8;
   u32* q = reinterpret_cast<u32*>(p);
-  ws.rev_pos = q + 0 * Lp;
-  ws.fwd_pos = q + 1 * Lp;
-  ws.epoch = q + 2 * Lp;
-  ws.rev_rank = q + 3 * Lp;
-  ws.fwd_rank = q + 4 * Lp;
-  ws.rev_moves = q + 5 * Lp;
-  ws.fwd_moves = q + 6 * Lp;
-  ws.rev_coll = q + 7 * Lp;
-  ws.fwd_coll = q + 8 * Lp;
-  ws.tmp_a = q + 9 * Lp;
-  ws.tmp_b = q + 10 * Lp;
-  ws.tmp_c = q + 11 * Lp;
-  ws.tmp_d = q + 12 * Lp;
-  p += 13 * Lp * 4;
+  ws.r_pos = q + 0 * Lp;
+  ws.r_id = q + 1 * Lp;
+  ws.r_move = q + 2 * Lp;
+  ws.r_coll = q + 3 * Lp;
+  ws.f_pos = q + 4 * Lp;
+  ws.f_id = q + 5 * Lp;
+  ws.f_move = q + 6 * Lp;
+  ws.f_coll = q + 7 * Lp;
+  ws.epoch = q + 8 * Lp;
+  ws.r_rank = q + 9 * Lp;
+  ws.f_rank = q + 10 * Lp;
+  ws.stall = q + 11 * Lp;
+  for (u32 k = 0; k < NUM_TMP; ++k) ws.tmp[k] = q + (12 + static_cast<u64>(k)) * Lp;
+  p += static_cast<u64>(NUM_STATE_ARRAYS) * Lp * 4;
   ws.bar_active = reinterpret_cast<u8*>(p);
   ws.capacity_lefs = max_lefs;
   ws.capacity_barriers = max_barriers;
@@ -96,6 +102,8 @@ struct BlockLds {
   f64 zig[kZigWords];
   u64 ring[kWavesPerBlock][RNG_RING];
   u32 list[kWavesPerBlock][LIST_CAP];
+  u64 sort_keys[kWavesPerBlock][SORT_LDS_CAP];
+  u32 stage[kWavesPerBlock][STAGE_CAP];
 };
 
 __device__ WaveLds make_wave_lds(BlockLds& s, int wave_in_block) {
@@ -107,6 +115,10 @@ __device__ WaveLds make_wave_lds(BlockLds& s, int wave_in_block) {
   l.zig_exp_x = s.zig + 258;
   l.zig_exp_y = s.zig + 258 + 257;
   l.list = s.list[wave_in_block];
+  l.sort_lds = s.sort_keys[wave_in_block];
+  l.stage = s.stage[wave_in_block];
+  l.trace = nullptr;
+  l.trace_cap = 0;
   return l;
 }
 
@@ -119,23 +131,34 @@ __device__ void load_block_tables(BlockLds& s, const DeviceTables& t, int nthrea
 __global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs a) {
   __shared__ BlockLds s;
   load_block_tables(s, a.tables, kThreadsPerBlock);
-  const int wave_in_block = threadIdx.x / 64;
+  const int wave_in_block = wave::uniform(static_cast<int>(threadIdx.x / 64));
   const u32 slot = blockIdx.x * kWavesPerBlock + wave_in_block;
   const WaveLds lds = make_wave_lds(s, wave_in_block);
   const Workspace ws = device_carve(a.workspace + static_cast<u64>(slot) * a.workspace_stride,
                                     a.max_lefs, a.max_barriers, a.params.hist_len);
   for (;;) {
+    // Pop one task.  Only lane 0 touches the counter, so this block branches on the lane id; the
+    // wave barrier (a convergent operation the optimizer may not duplicate) and the laundered
+    // lane id keep jump threading from routing the other 63 lanes around the pop along a second
+    // back edge, which would split the wave for the convergent operations that follow.
+    wave::lockstep();
+    u32 leader = wave::lane();
+    asm volatile("" : "+v"(leader));
     u32 t = 0;
-    if (wave::lane() == 0) t = atomicAdd(a.task_counter, 1u);
-    t = wave::bcast(t, 0);
+    if (leader == 0) t = atomicAdd(a.task_counter, 1u);
+    t = wave::bcast(t, 0);  // scalar from here on: the queue loop is a scalar loop
     if (t >= a.n_tasks) break;  // every wave leaves once the queue is empty
     const Task task = a.tasks[t];
     CellResult res;
-    const u32 st = simulate_cell(a.params, a.intervals[task.interval], task, ws, lds, res, a.pad_);
-    if (wave::lane() == 0) {
-      a.results[t] = res;
-      a.status[t] = st;
+    WaveLds lds_t = lds;
+    if (t == 0 && a.trace != nullptr) {
+      lds_t.trace = a.trace;
+      lds_t.trace_cap = a.trace_cap;
     }
+    const u32 st = simulate_cell(a.params, a.intervals[task.interval], task, ws, lds_t, res);
+    // all lanes store the same words (no lane-dependent branch at the end of the loop body)
+    a.results[t] = res;
+    a.status[t] = st;
   }
 }
 
@@ -144,6 +167,7 @@ struct PhaseArgs {
   DeviceTables tables;
   Interval interval;
   char* workspace;
+  u32* image;  // TestImage: nine arrays of n words
   u32 mask;
   u32 n;
   u64 prng[4];
@@ -158,7 +182,17 @@ __global__ __launch_bounds__(64) void modle_test_phases(PhaseArgs a) {
   const WaveLds lds = make_wave_lds(s, 0);
   const Workspace ws = device_carve(a.workspace, a.n, a.max_barriers, 4);
   u64 raws = 0;
-  const u32 st = run_test_phases(a.params, a.interval, ws, lds, a.mask, a.n, a.prng, raws);
+  TestImage img;
+  img.rev_pos = a.image + 0 * a.n;
+  img.fwd_pos = a.image + 1 * a.n;
+  img.epoch = a.image + 2 * a.n;
+  img.rev_rank = a.image + 3 * a.n;
+  img.fwd_rank = a.image + 4 * a.n;
+  img.rev_moves = a.image + 5 * a.n;
+  img.fwd_moves = a.image + 6 * a.n;
+  img.rev_coll = a.image + 7 * a.n;
+  img.fwd_coll = a.image + 8 * a.n;
+  const u32 st = run_test_phases(a.params, a.interval, ws, lds, img, a.mask, a.n, a.prng, raws);
   if (wave::lane() == 0) {
     *a.raws_out = raws;
     *a.status_out = st;
@@ -207,6 +241,8 @@ struct IntervalRec {
   DevBuf<u32> bar_pos;
   DevBuf<u8> bar_dir;
   DevBuf<f64> bar_stp;  // stp_active | stp_inactive | occupancy
+  DevBuf<u32> bar_bucket;
+  size_t n_buckets = 0;
   DevBuf<u32> own_contacts;
   DevBuf<u64> own_occupancy;
   DevBuf<u64> missed;
@@ -234,6 +270,7 @@ struct modle_hip_handle {
   DevBuf<u32> d_counter;
   DevBuf<char> d_workspace;
   DevBuf<u64> d_phase_out;
+  DevBuf<u64> d_trace;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   hipStream_t stream = nullptr;
   bool in_flight = false;
@@ -361,6 +398,10 @@ int modle_hip_add_interval(modle_hip_handle* h, uint64_t start, uint64_t end,
   HIP_TRY(rec->bar_stp.ensure(3 * n_barriers));
   HIP_TRY(rec->missed.ensure(1));
   HIP_TRY(hipMemset(rec->missed.p, 0, 8));
+  const std::vector<u32> buckets = modle_host::build_barrier_buckets(start, end, pos);
+  rec->n_buckets = buckets.size();
+  HIP_TRY(rec->bar_bucket.ensure(buckets.size()));
+  HIP_TRY(hipMemcpy(rec->bar_bucket.p, buckets.data(), buckets.size() * 4, hipMemcpyHostToDevice));
   if (n_barriers != 0) {
     HIP_TRY(hipMemcpy(rec->bar_pos.p, pos.data(), n_barriers * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(rec->bar_dir.p, dir.data(), n_barriers, hipMemcpyHostToDevice));
@@ -478,6 +519,9 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
     d.missed_updates = rec.missed.p;
     d.nrows = rec.nrows;
     d.ncols = rec.ncols;
+    d.bar_bucket = rec.bar_bucket.p;
+    d.bucket_shift = BAR_BUCKET_SHIFT;
+    d.n_buckets = static_cast<u32>(rec.n_buckets);
   }
   // one workgroup per CU even when there are fewer tasks than waves: the waves that win a task
   // are then spread over all CUs instead of being packed 8 to a CU
@@ -507,12 +551,32 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
   a.results = h->d_results.p;
   a.status = h->d_status.p;
   a.task_counter = h->d_counter.p;
+  a.trace = nullptr;
+  a.trace_cap = 0;
+  a.pad2_ = 0;
+  if (const char* shm = std::getenv("MODLE_HIP_TRACE_SHM"); shm != nullptr) {
+    // diagnostic: the trace of task 0 goes to a file-backed, host-coherent mapping so that it
+    // survives a GPU fault that aborts the process
+    constexpr u32 kTraceEpochs = 4096;
+    const size_t bytes = static_cast<size_t>(kTraceEpochs) * TRACE_STAGES * TRACE_WORDS_PER_STAGE * 8;
+    const int fd = ::open(shm, O_RDWR | O_CREAT | O_TRUNC, 0644);
+    if (fd >= 0 && ::ftruncate(fd, static_cast<off_t>(bytes)) == 0) {
+      void* hp = ::mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+      ::close(fd);
+      void* dp = nullptr;
+      if (hp != MAP_FAILED && hipHostRegister(hp, bytes, hipHostRegisterMapped) == hipSuccess &&
+          hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+        a.trace = static_cast<u64*>(dp);
+        a.trace_cap = kTraceEpochs;
+      }
+    }
+  }
   a.workspace = h->d_workspace.p;
   a.workspace_stride = layout.total_bytes;
   a.n_tasks = static_cast<u32>(sorted.size());
   a.max_lefs = max_lefs;
   a.max_barriers = max_barriers;
-  a.pad_ = std::getenv("MODLE_HIP_DEBUG_STAGE") ? static_cast<u32>(std::atoi(std::getenv("MODLE_HIP_DEBUG_STAGE"))) : 0;
+  a.pad_ = 0;
   HIP_TRY(hipEventRecord(h->ev_start, h->stream));
   hipLaunchKernelGGL(modle_simulate_cells, dim3(grid), dim3(kThreadsPerBlock), 0, h->stream, a);
   HIP_TRY(hipGetLastError());
@@ -653,34 +717,35 @@ int modle_hip_test_phases(modle_hip_handle* h, uint32_t phase_mask, uint64_t sta
   HIP_TRY(hipSetDevice(h->device));
   const auto layout =
       modle_host::workspace_layout(static_cast<u32>(n), static_cast<u32>(n_barriers), 4);
-  std::vector<uint64_t> image(layout.total_bytes / 8 + 1, 0);
-  Workspace ws = modle_host::carve_workspace(image.data(), static_cast<u32>(n),
+  std::vector<u32> image(9 * n);
+  TestImage img;
+  modle_host::fill_test_image(image.data(), n, rev_pos, fwd_pos, epoch, rev_rank, fwd_rank,
+                              rev_moves, fwd_moves, rev_coll, fwd_coll, img);
+  // workspace image: only the barrier states need initial values
+  std::vector<uint64_t> wsimg(layout.total_bytes / 8 + 1, 0);
+  Workspace ws = modle_host::carve_workspace(wsimg.data(), static_cast<u32>(n),
                                              static_cast<u32>(n_barriers), 4);
-  for (size_t i = 0; i < n; ++i) {
-    ws.rev_pos[i] = modle_host::pos_to_dev(rev_pos[i]);
-    ws.fwd_pos[i] = modle_host::pos_to_dev(fwd_pos[i]);
-    ws.epoch[i] = modle_host::pos_to_dev(epoch[i]);
-    ws.rev_rank[i] = static_cast<u32>(rev_rank[i]);
-    ws.fwd_rank[i] = static_cast<u32>(fwd_rank[i]);
-    ws.rev_moves[i] = static_cast<u32>(rev_moves[i]);
-    ws.fwd_moves[i] = static_cast<u32>(fwd_moves[i]);
-    ws.rev_coll[i] = modle_host::coll_to_dev(rev_coll[i]);
-    ws.fwd_coll[i] = modle_host::coll_to_dev(fwd_coll[i]);
-  }
   for (size_t i = 0; i < n_barriers; ++i) ws.bar_active[i] = bar_active[i];
   DevBuf<char> d_ws;
+  DevBuf<u32> d_img;
   DevBuf<u32> d_bpos;
   DevBuf<u8> d_bdir;
+  DevBuf<u32> d_bucket;
   HIP_TRY(d_ws.ensure(layout.total_bytes));
+  HIP_TRY(d_img.ensure(9 * n));
   HIP_TRY(d_bpos.ensure(n_barriers));
   HIP_TRY(d_bdir.ensure(n_barriers));
-  HIP_TRY(hipMemcpy(d_ws.p, image.data(), layout.total_bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_ws.p, wsimg.data(), layout.total_bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_img.p, image.data(), image.size() * 4, hipMemcpyHostToDevice));
   std::vector<u32> bp(n_barriers);
   for (size_t i = 0; i < n_barriers; ++i) bp[i] = static_cast<u32>(bar_pos[i]);
   if (n_barriers != 0) {
     HIP_TRY(hipMemcpy(d_bpos.p, bp.data(), n_barriers * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_bdir.p, bar_dir, n_barriers, hipMemcpyHostToDevice));
   }
+  const std::vector<u32> buckets = modle_host::build_barrier_buckets(start, end, bp);
+  HIP_TRY(d_bucket.ensure(buckets.size()));
+  HIP_TRY(hipMemcpy(d_bucket.p, buckets.data(), buckets.size() * 4, hipMemcpyHostToDevice));
   PhaseArgs a;
   std::memset(&a, 0, sizeof(a));
   a.params = h->params;
@@ -693,7 +758,11 @@ int modle_hip_test_phases(modle_hip_handle* h, uint32_t phase_mask, uint64_t sta
   a.interval.bar_dir = d_bdir.p;
   a.interval.nrows = 1;
   a.interval.ncols = 1;
+  a.interval.bar_bucket = d_bucket.p;
+  a.interval.bucket_shift = BAR_BUCKET_SHIFT;
+  a.interval.n_buckets = static_cast<u32>(buckets.size());
   a.workspace = d_ws.p;
+  a.image = d_img.p;
   a.mask = phase_mask;
   a.n = static_cast<u32>(n);
   std::memcpy(a.prng, prng, sizeof(a.prng));
@@ -705,18 +774,9 @@ int modle_hip_test_phases(modle_hip_handle* h, uint32_t phase_mask, uint64_t sta
   HIP_TRY(hipDeviceSynchronize());
   uint64_t out[2] = {0, 0};
   HIP_TRY(hipMemcpy(out, h->d_phase_out.p, 16, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(image.data(), d_ws.p, layout.total_bytes, hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < n; ++i) {
-    rev_pos[i] = modle_host::pos_to_abi(ws.rev_pos[i]);
-    fwd_pos[i] = modle_host::pos_to_abi(ws.fwd_pos[i]);
-    epoch[i] = modle_host::pos_to_abi(ws.epoch[i]);
-    rev_rank[i] = ws.rev_rank[i];
-    fwd_rank[i] = ws.fwd_rank[i];
-    rev_moves[i] = ws.rev_moves[i];
-    fwd_moves[i] = ws.fwd_moves[i];
-    rev_coll[i] = modle_host::coll_to_abi(ws.rev_coll[i]);
-    fwd_coll[i] = modle_host::coll_to_abi(ws.fwd_coll[i]);
-  }
+  HIP_TRY(hipMemcpy(image.data(), d_img.p, image.size() * 4, hipMemcpyDeviceToHost));
+  modle_host::read_test_image(img, n, rev_pos, fwd_pos, epoch, rev_rank, fwd_rank, rev_moves,
+                              fwd_moves, rev_coll, fwd_coll);
   if (raws_consumed != nullptr) *raws_consumed = out[0];
   if (static_cast<u32>(out[1]) != 0) {
     set_err(err, errlen, "device phase runner reported status " + std::to_string(out[1]));

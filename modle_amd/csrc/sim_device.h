@@ -2,424 +2,69 @@
 // Simulation::simulate_one_cell (reference: src/libmodle/cpu/simulation.cpp:896-986) written for
 // a 64-lane wave.  Included after a `wave` backend (wave_hip.h on the GPU).
 //
-// Conventions
-//   * "uniform" values are identical in all 64 lanes; every collective (ballot / shuffle / sync)
-//     is issued from wave-uniform control flow.
-//   * Per-cell state lives in the wave's Workspace (device memory), indexed by LEF id with two
-//     rank arrays giving the 5'->3' order of rev / fwd units, like the reference's State buffers
-//     (reference: src/libmodle/cpu/include/modle/simulation.hpp:86-94) but with 32-bit fields.
-//   * The cell's single xoshiro256++ stream is produced in blocks of RNG_BLOCK raw outputs by
-//     all 64 lanes (lane l owns RNG_CHUNK consecutive outputs of every block and hops to its
-//     chunk of the next block with a GF(2) jump table) and consumed strictly in the reference's
-//     order; draws whose raw-output count is data dependent are resolved with a
-//     speculate / verify / restart scheme so the stream position of every draw is exact.
+// Data layout (sim_types.h: Workspace).  Extrusion units are kept in RANK ORDER, rev and fwd
+// units separately: r_pos[k] / r_move[k] / r_coll[k] / r_id[k] describe the k-th rev unit in
+// 5'->3' order.  Every pass that walks units in genomic order -- move adjustment, all collision
+// passes, extrusion -- therefore streams contiguous memory.  The things the reference does in
+// LEF-id order because of the PRNG draw order (move generation, release, bind) use id-ordered
+// arrays and cross over with one scatter through the inverse permutations r_rank / f_rank.
+// LEF-LEF collision words carry LEF ids like the reference's; barrier collision words carry the
+// barrier index.
 #pragma once
-#include "sim_types.h"
+#include "sim_rng.h"
 
 namespace modle_dev {
 
-// =============================================================================================
-// small helpers
-// =============================================================================================
-MODLE_DEV u64 lanemask_lt(u32 lane) { return (u64(1) << lane) - 1; }
-MODLE_DEV u32 cw_make(u32 idx, u32 ev) { return (idx & CW_INDEX_MASK) | (ev << CW_SHIFT); }
-MODLE_DEV u32 cw_event(u32 c) { return c >> CW_SHIFT; }
-MODLE_DEV u32 cw_index(u32 c) { return c & CW_INDEX_MASK; }
-MODLE_DEV bool cw_occurred(u32 c) { return (cw_event(c) & EV_COLLISION) != 0; }
-MODLE_DEV bool cw_occurred_as(u32 c, u32 what) { return cw_event(c) == (what | EV_COLLISION); }
-MODLE_DEV bool cw_avoided_as(u32 c, u32 what) { return !cw_occurred(c) && cw_event(c) == what; }
-MODLE_DEV u32 umin(u32 a, u32 b) { return a < b ? a : b; }
-MODLE_DEV u32 umax(u32 a, u32 b) { return a > b ? a : b; }
-MODLE_DEV u64 umin64(u64 a, u64 b) { return a < b ? a : b; }
-MODLE_DEV i64 imin64(i64 a, i64 b) { return a < b ? a : b; }
-MODLE_DEV i64 imax64(i64 a, i64 b) { return a > b ? a : b; }
-
-constexpr f64 TWO64 = 18446744073709551616.0;
-constexpr f64 TWO_M64 = 5.42101086242752217e-20;
-constexpr f64 TWO_M56 = 1.387778780781445675529539585113525390625e-17;
-constexpr f64 DBL_EPS = 2.220446049250313e-16;
-
-// =============================================================================================
-// PRNG: xoshiro256++ block generator (reference stream: random.hpp:26-32)
-// =============================================================================================
-struct Rng {
-  u64 s0, s1, s2, s3;  // per lane: state at the start of this lane's chunk of the NEXT block
-  u64* ring;           // RNG_RING raws (LDS)
-  const u64* jump;     // T^RNG_BLOCK nibble table (LDS)
-  u64 gen_end;         // uniform: raws [gen_end - RNG_RING, gen_end) are in the ring
-  u64 pos;             // uniform: stream position of the next raw to be consumed
-};
-
-MODLE_DEV u64 rotl64(u64 x, int k) { return (x << k) | (x >> (64 - k)); }
-
-MODLE_DEV u64 xo_next(u64& s0, u64& s1, u64& s2, u64& s3) {
-  const u64 result = rotl64(s0 + s3, 23) + s0;
-  const u64 t = s1 << 17;
-  s2 ^= s0;
-  s3 ^= s1;
-  s1 ^= s2;
-  s0 ^= s3;
-  s2 ^= t;
-  s3 = rotl64(s3, 45);
-  return result;
-}
-
-MODLE_DEV u32 ring_index(u64 p) {
-  const u32 off = static_cast<u32>(p) & (RNG_BLOCK - 1);
-  const u32 blk = (static_cast<u32>(p) / RNG_BLOCK) & 1u;
-  // chunk-local XOR swizzle: lanes writing element t of their chunks hit distinct LDS banks
-  return blk * RNG_BLOCK + (off ^ ((off / RNG_CHUNK) & (RNG_CHUNK - 1)));
-}
-
-MODLE_DEV void rng_jump(Rng& g) {
-  u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-  const u64 w[4] = {g.s0, g.s1, g.s2, g.s3};
-#pragma unroll
-  for (int wi = 0; wi < 4; ++wi) {
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const u32 v = static_cast<u32>(w[wi] >> (4 * k)) & 15u;
-      const u64* row = g.jump + ((wi * 16 + k) * 16 + v) * 4;
-      a0 ^= row[0];
-      a1 ^= row[1];
-      a2 ^= row[2];
-      a3 ^= row[3];
-    }
-  }
-  g.s0 = a0;
-  g.s1 = a1;
-  g.s2 = a2;
-  g.s3 = a3;
-}
-
-MODLE_DEV void rng_gen_block(Rng& g) {
-  wave::lockstep();  // other lanes may still be reading the block that is about to be replaced
-  const u32 lane = wave::lane();
-  u64 a0 = g.s0, a1 = g.s1, a2 = g.s2, a3 = g.s3;
-  const u32 base = ((static_cast<u32>(g.gen_end) / RNG_BLOCK) & 1u) * RNG_BLOCK + RNG_CHUNK * lane;
-#pragma unroll
-  for (u32 t = 0; t < RNG_CHUNK; ++t) {
-    g.ring[base + (t ^ (lane & (RNG_CHUNK - 1)))] = xo_next(a0, a1, a2, a3);
-  }
-  rng_jump(g);
-  g.gen_end += RNG_BLOCK;
-  wave::sync_mem();
-}
-
-MODLE_DEV void rng_init(Rng& g, const u64 state[4]) {
-  const u32 lane = wave::lane();
-  g.s0 = state[0];
-  g.s1 = state[1];
-  g.s2 = state[2];
-  g.s3 = state[3];
-  // lane l starts RNG_CHUNK * l outputs into the stream
-  for (u32 k = 0; k < RNG_CHUNK * 63; ++k) {
-    if (k < RNG_CHUNK * lane) (void)xo_next(g.s0, g.s1, g.s2, g.s3);
-  }
-  g.gen_end = 0;
-  g.pos = 0;
-}
-
-// makes raws [pos, pos + k) readable (k <= RNG_BLOCK); uniform
-MODLE_DEV void rng_ensure(Rng& g, u32 k) {
-  while (g.gen_end < g.pos + k) rng_gen_block(g);
-}
-MODLE_DEV u64 rng_peek(const Rng& g, u64 p) { return g.ring[ring_index(p)]; }
-// uniform: next raw of the stream
-MODLE_DEV u64 rng_next(Rng& g) {
-  rng_ensure(g, 1);
-  return rng_peek(g, g.pos++);
-}
-// =============================================================================================
-// Distributions (Boost.Random 1.88 semantics on a 64-bit engine; reference aliases:
-// src/common/include/modle/common/random.hpp:34-53).  "exact" routines are executed uniformly by
-// the whole wave and consume the stream sequentially; "fast" forms evaluate one speculative draw
-// per lane from a raw output that has already been fetched.
-// =============================================================================================
-MODLE_DEV bool bernoulli_raw(u64 raw, f64 p) { return static_cast<f64>(raw) <= p * TWO64; }
-MODLE_DEV f64 canonical_raw(u64 raw) {
-  f64 r = static_cast<f64>(raw) / TWO64;
-  if (r == 1.0) r -= DBL_EPS / 2;
-  return r;
-}
-MODLE_DEV f64 uniform01_exact(Rng& g) {
-  for (;;) {
-    const f64 r = static_cast<f64>(rng_next(g)) * TWO_M64;
-    if (r < 1.0) return r;
-  }
-}
-MODLE_DEV u64 uniform_int_bucket(u64 range) {
-  u64 bucket = ~u64(0) / (range + 1);
-  if (~u64(0) % (range + 1) == range) ++bucket;
-  return bucket;
-}
-// uniform_int_distribution<u64>{0, range}, range != 0 and != 2^64-1
-MODLE_DEV u64 uniform_int_exact(Rng& g, u64 range, u64 bucket) {
-  for (;;) {
-    const u64 r = rng_next(g) / bucket;
-    if (r <= range) return r;
-  }
-}
-
-MODLE_DEV f64 int_float_pair8(u64 raw, u32& bucket) {
-  bucket = static_cast<u32>(raw) & 0xFFu;
-  const u64 u = raw & ~((u64(1) << 11) - 1);
-  return static_cast<f64>(u >> 8) * TWO_M56;
-}
-
-MODLE_DEV f64 unit_exponential_exact(Rng& g, const WaveLds& lds) {
-  f64 shift = 0.0;
-  for (;;) {
-    u32 i;
-    const f64 u = int_float_pair8(rng_next(g), i);
-    const f64 x = u * lds.zig_exp_x[i];
-    if (x < lds.zig_exp_x[i + 1]) return shift + x;
-    if (i == 0) {
-      shift += lds.zig_exp_x[1];
-    } else {
-      const f64 y01 = uniform01_exact(g);
-      const f64 y = lds.zig_exp_y[i] + y01 * (lds.zig_exp_y[i + 1] - lds.zig_exp_y[i]);
-      const f64 y_above_ubound =
-          (lds.zig_exp_x[i] - lds.zig_exp_x[i + 1]) * y01 - (lds.zig_exp_x[i] - x);
-      const f64 y_above_lbound =
-          y - (lds.zig_exp_y[i + 1] + (lds.zig_exp_x[i + 1] - x) * lds.zig_exp_y[i + 1]);
-      if (y_above_ubound < 0 && (y_above_lbound < 0 || y < wave::f_exp(-x))) return x + shift;
-    }
-  }
-}
-
-// boost unit_normal_distribution; uniform, consumes from g.pos
-MODLE_DEV f64 unit_normal_exact(Rng& g, const WaveLds& lds) {
-  for (;;) {
-    u32 b;
-    const f64 u = int_float_pair8(rng_next(g), b);
-    const f64 sign = (b & 1u) ? 1.0 : -1.0;
-    const u32 i = b >> 1;
-    const f64 x = u * lds.zig_norm_x[i];
-    if (x < lds.zig_norm_x[i + 1]) return x * sign;
-    if (i == 0) {
-      const f64 tail_start = lds.zig_norm_x[1];
-      for (;;) {
-        const f64 tx = unit_exponential_exact(g, lds) / tail_start;
-        const f64 ty = unit_exponential_exact(g, lds);
-        if (2 * ty > tx * tx) return (tx + tail_start) * sign;
-      }
-    }
-    const f64 y01 = uniform01_exact(g);
-    const f64 xi = lds.zig_norm_x[i], xi1 = lds.zig_norm_x[i + 1];
-    const f64 yi = lds.zig_norm_y[i], yi1 = lds.zig_norm_y[i + 1];
-    const f64 y = yi + y01 * (yi1 - yi);
-    const f64 chord = (xi - xi1) * y01 - (xi - x);
-    const f64 tangent = y - (yi + (xi - x) * yi * xi);
-    const f64 y_above_ubound = (xi >= 1) ? chord : tangent;
-    const f64 y_above_lbound = (xi >= 1) ? tangent : chord;
-    if (y_above_ubound < 0 && (y_above_lbound < 0 || y < wave::f_exp(-(x * x / 2)))) {
-      return x * sign;
-    }
-  }
-}
-
-// boost poisson_distribution<size_t, double>; uniform
-MODLE_DEV u64 poisson_exact(Rng& g, f64 mean) {
-  if (mean < 10) {
-    f64 p = wave::f_exp(-mean);
-    u64 x = 0;
-    f64 u = uniform01_exact(g);
-    while (u > p) {
-      u = u - p;
-      ++x;
-      p = mean * p / static_cast<f64>(x);
-    }
-    return x;
-  }
-  const f64 log_fact[10] = {0.0,
-                            0.0,
-                            0.69314718055994529,
-                            1.7917594692280550,
-                            3.1780538303479458,
-                            4.7874917427820458,
-                            6.5792512120101012,
-                            8.5251613610654147,
-                            10.604602902745251,
-                            12.801827480081469};
-  const f64 smu = wave::f_sqrt(mean);
-  const f64 b = 0.931 + 2.53 * smu;
-  const f64 a = -0.059 + 0.02483 * b;
-  const f64 inv_alpha = 1.1239 + 1.1328 / (b - 3.4);
-  const f64 v_r = 0.9277 - 3.6224 / (b - 2);
-  for (;;) {
-    f64 u;
-    f64 v = uniform01_exact(g);
-    if (v <= 0.86 * v_r) {
-      u = v / v_r - 0.43;
-      return static_cast<u64>(
-          wave::f_floor((2 * a / (0.5 - wave::f_abs(u)) + b) * u + mean + 0.445));
-    }
-    if (v >= v_r) {
-      u = uniform01_exact(g) - 0.5;
-    } else {
-      u = v / v_r - 0.93;
-      u = ((u < 0) ? -0.5 : 0.5) - u;
-      v = uniform01_exact(g) * v_r;
-    }
-    const f64 us = 0.5 - wave::f_abs(u);
-    if (us < 0.013 && v > us) continue;
-    const f64 k = wave::f_floor((2 * a / us + b) * u + mean + 0.445);
-    v = v * inv_alpha / (a / (us * us) + b);
-    const f64 log_sqrt_2pi = 0.91893853320467267;
-    if (k >= 10) {
-      if (wave::f_log(v * smu) <= (k + 0.5) * wave::f_log(mean / k) - mean - log_sqrt_2pi + k -
-                                      (1 / 12. - (1 / 360. - 1 / (1260. * k * k)) / (k * k)) / k) {
-        return static_cast<u64>(k);
-      }
-    } else if (k >= 0) {
-      f64 lf = 0.0;
-      const int ki = static_cast<int>(k);
-#pragma unroll
-      for (int t = 0; t < 10; ++t) lf = (t == ki) ? log_fact[t] : lf;
-      if (wave::f_log(v) <= k * wave::f_log(mean) - mean - lf) return static_cast<u64>(k);
-    }
-  }
-}
-
-MODLE_DEV f64 binom_fc(i64 k) {
-  const f64 table[10] = {0.08106146679532726, 0.04134069595540929, 0.02767792568499834,
-                         0.02079067210376509, 0.01664469118982119, 0.01387612882307075,
-                         0.01189670994589177, 0.01041126526197209, 0.009255462182712733,
-                         0.008330563433362871};
-  if (k < 10) {
-    f64 v = 0.0;
-#pragma unroll
-    for (int t = 0; t < 10; ++t) v = (t == static_cast<int>(k)) ? table[t] : v;
-    return v;
-  }
-  const f64 ikp1 = 1.0 / static_cast<f64>(k + 1);
-  return (1.0 / 12 - (1.0 / 360 - (1.0 / 1260) * (ikp1 * ikp1)) * (ikp1 * ikp1)) * ikp1;
-}
-
-// boost binomial_distribution<ptrdiff_t, double>{t, p}; uniform
-MODLE_DEV i64 binomial_exact(Rng& g, i64 t, f64 p_) {
-  const f64 p = (0.5 < p_) ? (1 - p_) : p_;
-  const i64 m = static_cast<i64>(static_cast<f64>(t + 1) * p);
-  i64 k;
-  if (m < 11) {
-    const f64 q = 1 - p;
-    const f64 s = p / q;
-    const f64 a = static_cast<f64>(t + 1) * s;
-    f64 r = wave::f_pow(1 - p, static_cast<f64>(t));
-    f64 u = uniform01_exact(g);
-    k = 0;
-    while (u > r) {
-      u = u - r;
-      ++k;
-      const f64 r1 = ((a / static_cast<f64>(k)) - s) * r;
-      if (r1 < DBL_EPS && r1 < r) break;
-      r = r1;
-    }
-    return (0.5 < p_) ? t - k : k;
-  }
-  const f64 r = p / (1 - p);
-  const f64 nr = static_cast<f64>(t + 1) * r;
-  const f64 npq = static_cast<f64>(t) * p * (1 - p);
-  const f64 sqrt_npq = wave::f_sqrt(npq);
-  const f64 b = 1.15 + 2.53 * sqrt_npq;
-  const f64 a = -0.0873 + 0.0248 * b + 0.01 * p;
-  const f64 c = static_cast<f64>(t) * p + 0.5;
-  const f64 alpha = (2.83 + 5.1 / b) * sqrt_npq;
-  const f64 v_r = 0.92 - 4.2 / b;
-  const f64 u_rv_r = 0.86 * v_r;
-  for (;;) {
-    f64 u;
-    f64 v = uniform01_exact(g);
-    if (v <= u_rv_r) {
-      u = v / v_r - 0.43;
-      k = static_cast<i64>(wave::f_floor((2 * a / (0.5 - wave::f_abs(u)) + b) * u + c));
-      break;
-    }
-    if (v >= v_r) {
-      u = uniform01_exact(g) - 0.5;
-    } else {
-      u = v / v_r - 0.93;
-      u = ((u < 0) ? -0.5 : 0.5) - u;
-      v = uniform01_exact(g) * v_r;
-    }
-    const f64 us = 0.5 - wave::f_abs(u);
-    k = static_cast<i64>(wave::f_floor((2 * a / us + b) * u + c));
-    if (k < 0 || k > t) continue;
-    v = v * alpha / (a / (us * us) + b);
-    const i64 kmi = k > m ? k - m : m - k;
-    const f64 km = static_cast<f64>(kmi);
-    if (km <= 15) {
-      f64 f = 1;
-      if (m < k) {
-        i64 i = m;
-        do {
-          ++i;
-          f = f * (nr / static_cast<f64>(i) - r);
-        } while (i != k);
-      } else if (m > k) {
-        i64 i = k;
-        do {
-          ++i;
-          v = v * (nr / static_cast<f64>(i) - r);
-        } while (i != m);
-      }
-      if (v <= f) break;
-      continue;
-    }
-    v = wave::f_log(v);
-    const f64 rho = (km / npq) * (((km / 3. + 0.625) * km + 1. / 6) / npq + 0.5);
-    const f64 tt = -km * km / (2 * npq);
-    if (v < tt - rho) break;
-    if (v > tt + rho) continue;
-    const i64 nm = t - m + 1;
-    const f64 h = (static_cast<f64>(m) + 0.5) *
-                      wave::f_log(static_cast<f64>(m + 1) / (r * static_cast<f64>(nm))) +
-                  binom_fc(m) + binom_fc(t - m);
-    const i64 nk = t - k + 1;
-    if (v <= h +
-                 static_cast<f64>(t + 1) *
-                     wave::f_log(static_cast<f64>(nm) / static_cast<f64>(nk)) +
-                 (static_cast<f64>(k) + 0.5) *
-                     wave::f_log(static_cast<f64>(nk) * r / static_cast<f64>(k + 1)) -
-                 binom_fc(k) - binom_fc(t - k)) {
-      break;
-    }
-  }
-  return (0.5 < p_) ? t - k : k;
-}
-
-// genextreme_value_distribution (reference: genextreme_value_distribution.hpp:87-105)
-MODLE_DEV f64 genextreme_from_canonical(f64 u, f64 mu, f64 sigma, f64 xi) {
-  if (xi == 0.0) return (mu - sigma) * wave::f_log(-wave::f_log(u));
-  return mu + (sigma * (1.0 - wave::f_pow(-wave::f_log(u), xi))) / xi;
-}
-
-// =============================================================================================
-// Cell context
-// =============================================================================================
 struct Cell {
   const Params* p;
   const Interval* iv;
   Workspace ws;
   WaveLds lds;
   Rng g;
-  u32 n_lefs;    // Task::num_lefs
-  u32 n_active;  // State::num_active_lefs
-  u32 hist_len;  // entries in the burn-in history buffers
-  u32 hist_head; // ring head
-  u32 error;     // non-zero when an internal capacity was exceeded (uniform)
+  u32 n_lefs;     // Task::num_lefs
+  u32 n_active;   // State::num_active_lefs
+  u32 hist_len;   // entries in the burn-in history buffers
+  u32 hist_head;  // ring head
+  u32 error;      // non-zero when an internal capacity was exceeded (uniform)
 };
 constexpr u32 ERR_LIST_OVERFLOW = 1;
 constexpr u32 ERR_TRIAL_OVERFLOW = 2;
+constexpr u32 ERR_INTERNAL = 3;
+
+template <class T>
+MODLE_DEV void swap_ptr(T*& a, T*& b) {
+  T* t = a;
+  a = b;
+  b = t;
+}
+
+// first barrier index whose position is >= key
+MODLE_DEV u32 bar_lower_bound(const Interval& iv, u64 key) {
+  const u32 nb = iv.n_barriers;
+  if (key <= iv.start) return 0;
+  const u64 b = (key - iv.start) >> iv.bucket_shift;
+  if (b >= iv.n_buckets) return nb;
+  u32 i = iv.bar_bucket[b];
+  while (i < nb && iv.bar_pos[i] < key) ++i;
+  return i;
+}
+
+MODLE_DEV u32 lower_bound_u32(const u32* a, u32 n, u32 key) {  // first index with a[i] >= key
+  u32 lo = 0, hi = n;
+  while (lo < hi) {
+    const u32 mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
 
 // =============================================================================================
 // select_and_bind_lefs (reference: simulation.cpp:988-993, simulation_impl.hpp:30-91)
 // =============================================================================================
-MODLE_DEV void phase_bind(Cell& c, u32 epoch_now) {
+MODLE_DEV_NOINLINE void phase_bind(Cell& c, u32 epoch_now) {
   const Interval& iv = *c.iv;
   Workspace& ws = c.ws;
-  const u32 n = c.n_active;
+  const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
   const u64 range = static_cast<u64>(iv.end) - 1 - iv.start;
   const u64 bucket = range != 0 ? uniform_int_bucket(range) : 1;
@@ -449,9 +94,12 @@ MODLE_DEV void phase_bind(Cell& c, u32 epoch_now) {
       }
     }
     if (unb) {
-      ws.rev_pos[i] = posv;
-      ws.fwd_pos[i] = posv;
       ws.epoch[i] = epoch_now;
+      const u32 kr = ws.r_rank[i], kf = ws.f_rank[i];
+      ws.r_pos[kr] = posv;
+      ws.r_move[kr] = NEW_MARK;
+      ws.f_pos[kf] = posv;
+      ws.f_move[kf] = NEW_MARK;
     }
   }
   wave::sync_mem();
@@ -461,10 +109,11 @@ MODLE_DEV void phase_bind(Cell& c, u32 epoch_now) {
 // rank_lefs (reference: simulation.cpp:410-496)
 //
 // Total order: position, then binding epoch (rev: older first, fwd: younger first), then the
-// position in the incoming rank array (the reference leaves this last tie to an unstable sort;
-// see DESIGN.md "ranking ties").  Units that were already ranked stay sorted across an epoch, so
-// the update is: split the rank array into carried-over and newly bound units, sort the new
-// ones, merge, then repair epoch ties.
+// position in the incoming rank order (the reference leaves this last tie to an unstable sort;
+// DESIGN.md "ranking ties").  Units that were already ranked stay sorted across an epoch except
+// where fix_secondary_lef_lef_collisions re-positions a pair, so the update is: split the rank
+// order into carried-over units that are still in order and "new" units (bound this epoch, or
+// out of order), sort the new ones, merge, then order equal positions.
 // =============================================================================================
 MODLE_DEV u32 pow2_ceil(u32 x) {
   u32 p = 1;
@@ -472,7 +121,7 @@ MODLE_DEV u32 pow2_ceil(u32 x) {
   return p;
 }
 
-MODLE_DEV void bitonic_sort_u64(u64* keys, u32 m_pow2) {
+MODLE_DEV_NOINLINE void bitonic_sort_u64(u64* keys, u32 m_pow2) {
   const u32 lane = wave::lane();
   const u32 half = m_pow2 / 2;
   for (u32 k = 2; k <= m_pow2; k <<= 1) {
@@ -495,32 +144,33 @@ MODLE_DEV void bitonic_sort_u64(u64* keys, u32 m_pow2) {
   }
 }
 
-// full comparator: position, binding epoch (rev: older first, fwd: younger first), position in
-// the incoming rank array (`where`, by LEF id)
+// full comparator on (pos, id) pairs: position, binding epoch (rev: older first, fwd: younger
+// first), previous rank (`where`, by LEF id)
 template <bool FWD>
-MODLE_DEV bool rank_pair_out_of_order(const Workspace& ws, const u32* pos, const u32* where, u32 a,
-                                      u32 b) {
-  const u32 pa = pos[a], pb = pos[b];
+MODLE_DEV bool rank_pair_out_of_order(const Workspace& ws, const u32* where, u32 pa, u32 ida,
+                                      u32 pb, u32 idb) {
   if (pa != pb) return pa > pb;
-  const u32 ea = ws.epoch[a], eb = ws.epoch[b];
+  const u32 ea = ws.epoch[ida], eb = ws.epoch[idb];
   if (ea != eb) return FWD ? ea < eb : ea > eb;
-  return where[a] > where[b];
+  return where[ida] > where[idb];
 }
 
 // all_new: treat every entry as newly bound (full sort; used by the phase-level test entry point)
 template <bool FWD>
-MODLE_DEV void rank_update(Cell& c, u32 epoch_now, bool all_new) {
+MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
   Workspace& ws = c.ws;
-  const u32 n = c.n_active;
+  const u32 n = wave::uniform(c.n_active);
   if (n < 2) return;
   const u32 lane = wave::lane();
-  u32* rank = FWD ? ws.fwd_rank : ws.rev_rank;
-  const u32* pos = FWD ? ws.fwd_pos : ws.rev_pos;
-  u32* old_ids = ws.tmp_a;
-  u32* old_pos = ws.tmp_b;
-  u32* new_ids = ws.tmp_c;
-  u32* where = ws.tmp_d;
-  u64* keys = ws.sort_keys;
+  u32*& pos = FWD ? ws.f_pos : ws.r_pos;
+  u32*& ids = FWD ? ws.f_id : ws.r_id;
+  const u32* marks = FWD ? ws.f_move : ws.r_move;
+  u32* where = FWD ? ws.f_rank : ws.r_rank;  // previous ranks until the final scatter
+  u32* old_pos = ws.tmp[2];
+  u32* old_id = ws.tmp[3];
+  u32* new_id = ws.tmp[4];
+  u64* keys_lds = c.lds.sort_lds;
+  u64* keys_glb = ws.sort_keys;
 
   // 1. stable split.  A carried-over unit that is no longer in order (its position is below the
   //    running maximum of the carried-over units before it; this can happen after
@@ -531,11 +181,10 @@ MODLE_DEV void rank_update(Cell& c, u32 epoch_now, bool all_new) {
   for (u32 base = 0; base < n; base += 64) {
     const u32 k = base + lane;
     const bool act = k < n;
-    const u32 id = act ? rank[k] : 0;
-    const u32 P = act ? pos[id] : 0;
-    const bool fresh = act && (all_new || ws.epoch[id] == epoch_now);
+    const u32 P = act ? pos[k] : 0;
+    const u32 id = act ? ids[k] : 0;
+    const bool fresh = act && (all_new || marks[k] == NEW_MARK);
     const bool carried = act && !fresh;
-    // exclusive prefix maximum of the carried-over positions
     u32 pm = carried ? P : 0;
 #pragma unroll
     for (u32 s = 1; s < 64; s <<= 1) {
@@ -550,15 +199,15 @@ MODLE_DEV void rank_update(Cell& c, u32 epoch_now, bool all_new) {
     const bool is_old = carried && !displaced;
     const u64 mn = wave::ballot(is_new);
     const u64 mo = wave::ballot(is_old);
-    if (act) where[id] = k;
     if (is_new) {
       const u32 j = n_new + static_cast<u32>(wave::popc64(mn & lanemask_lt(lane)));
-      new_ids[j] = id;
-      keys[j] = (static_cast<u64>(P) << 32) | j;
+      new_id[j] = id;
+      const u64 key = (static_cast<u64>(P) << 32) | j;
+      if (j < SORT_LDS_CAP) keys_lds[j] = key; else keys_glb[j] = key;
     }
     if (is_old) {
       const u32 j = n_old + static_cast<u32>(wave::popc64(mo & lanemask_lt(lane)));
-      old_ids[j] = id;
+      old_id[j] = id;
       old_pos[j] = P;
     }
     n_new += static_cast<u32>(wave::popc64(mn));
@@ -566,16 +215,28 @@ MODLE_DEV void rank_update(Cell& c, u32 epoch_now, bool all_new) {
     run_max = umax(run_max, incl_last);
   }
   wave::sync_mem();
+  if (n_old + n_new != n) {
+    c.error = ERR_INTERNAL;  // cannot happen: every active unit is either carried over or new
+    return;
+  }
+  // when nothing is new the order is unchanged and step 4 works in place
+  u32* out_pos = n_new != 0 ? ws.tmp[0] : pos;
+  u32* out_id = n_new != 0 ? ws.tmp[1] : ids;
   if (n_new != 0) {
     // 2. sort the new units by (position, previous rank)
+    u64* keys = keys_lds;
     const u32 m2 = pow2_ceil(n_new);
+    if (n_new > SORT_LDS_CAP) {
+      keys = keys_glb;
+      for (u32 base = 0; base < SORT_LDS_CAP; base += 64) keys_glb[base + lane] = keys_lds[base + lane];
+    }
     for (u32 base = n_new; base < m2; base += 64) {
       const u32 k = base + lane;
       if (k < m2) keys[k] = ~u64(0);
     }
     wave::sync_mem();
     if (m2 > 1) bitonic_sort_u64(keys, m2);
-    // 3. merge by cross-ranking (kept units are sorted; equal positions are ordered later)
+    // 3. merge by cross-ranking (kept units are sorted; equal positions are ordered in step 4)
     for (u32 base = 0; base < n_old; base += 64) {
       const u32 a = base + lane;
       if (a < n_old) {
@@ -586,7 +247,8 @@ MODLE_DEV void rank_update(Cell& c, u32 epoch_now, bool all_new) {
           const u32 mid = (lo + hi) >> 1;
           if (keys[mid] < thr) lo = mid + 1; else hi = mid;
         }
-        rank[a + lo] = old_ids[a];
+        out_pos[a + lo] = p;
+        out_id[a + lo] = old_id[a];
       }
     }
     for (u32 base = 0; base < n_new; base += 64) {
@@ -601,7 +263,8 @@ MODLE_DEV void rank_update(Cell& c, u32 epoch_now, bool all_new) {
           const bool before = FWD ? (q < p) : (q <= p);
           if (before) lo = mid + 1; else hi = mid;
         }
-        rank[b + lo] = new_ids[static_cast<u32>(key)];
+        out_pos[b + lo] = p;
+        out_id[b + lo] = new_id[static_cast<u32>(key)];
       }
     }
     wave::sync_mem();
@@ -609,11 +272,23 @@ MODLE_DEV void rank_update(Cell& c, u32 epoch_now, bool all_new) {
   // 4. order equal positions (epoch rule, then previous rank) with a stable odd-even
   //    transposition; normally nothing moves
   bool bad = false;
+  u32 carry_p = 0, carry_i = 0;
   for (u32 base = 0; base < n; base += 64) {
     const u32 k = base + lane;
-    const bool chk = k >= 1 && k < n;
-    const bool b = chk && rank_pair_out_of_order<FWD>(ws, pos, where, rank[k - 1], rank[k]);
+    const bool act = k < n;
+    const u32 P = act ? out_pos[k] : 0;
+    const u32 I = act ? out_id[k] : 0;
+    const u32 pp_in = wave::shfl_up(P, 1), pi_in = wave::shfl_up(I, 1);
+    const u32 Pp = lane > 0 ? pp_in : carry_p;
+    const u32 Ip = lane > 0 ? pi_in : carry_i;
+    bool b = false;
+    if (act && k >= 1) {
+      if (Pp > P) b = true;
+      else if (Pp == P) b = rank_pair_out_of_order<FWD>(ws, where, Pp, Ip, P, I);
+    }
     bad = wave::any(b) || bad;
+    carry_p = wave::bcast(P, 63);
+    carry_i = wave::bcast(I, 63);
   }
   while (bad) {
     bad = false;
@@ -622,10 +297,13 @@ MODLE_DEV void rank_update(Cell& c, u32 epoch_now, bool all_new) {
         const u32 k = base + 2 * lane + parity;
         bool sw = false;
         if (k + 1 < n) {
-          const u32 a = rank[k], b = rank[k + 1];
-          if (rank_pair_out_of_order<FWD>(ws, pos, where, a, b)) {
-            rank[k] = b;
-            rank[k + 1] = a;
+          const u32 pa = out_pos[k], pb = out_pos[k + 1];
+          const u32 ia = out_id[k], ib = out_id[k + 1];
+          if (rank_pair_out_of_order<FWD>(ws, where, pa, ia, pb, ib)) {
+            out_pos[k] = pb;
+            out_pos[k + 1] = pa;
+            out_id[k] = ib;
+            out_id[k + 1] = ia;
             sw = true;
           }
         }
@@ -634,25 +312,39 @@ MODLE_DEV void rank_update(Cell& c, u32 epoch_now, bool all_new) {
       wave::sync_mem();
     }
   }
+  // 5. publish: inverse permutation, then the new arrays become current
+  for (u32 base = 0; base < n; base += 64) {
+    const u32 k = base + lane;
+    if (k < n) where[out_id[k]] = k;
+  }
+  if (n_new != 0) {
+    swap_ptr(pos, ws.tmp[0]);
+    swap_ptr(ids, ws.tmp[1]);
+  }
+  wave::sync_mem();
 }
 
 // =============================================================================================
-// generate_moves (reference: simulation.cpp:272-330)
+// generate_moves (reference: simulation.cpp:272-330).  Draws are made in LEF-id order (the
+// reference's stream order) and scattered to the unit's slot in rank order.
 // =============================================================================================
 MODLE_DEV u32 move_from_normal(f64 unit, f64 speed, f64 std) {
   const f64 v = unit * std + speed;
   return static_cast<u32>(static_cast<u64>(wave::f_round(v > 0.0 ? v : 0.0)));
 }
 
-MODLE_DEV void generate_moves_dir(Cell& c, u32* moves, f64 speed, f64 std) {
+template <bool FWD>
+MODLE_DEV_NOINLINE void generate_moves_dir(Cell& c, f64 speed, f64 std) {
   Workspace& ws = c.ws;
-  const u32 n = c.n_active;
+  const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
+  u32* moves = FWD ? ws.f_move : ws.r_move;
+  const u32* rank = FWD ? ws.f_rank : ws.r_rank;
   if (std == 0.0) {
     const u32 move_int = static_cast<u32>(static_cast<u64>(wave::f_round(speed)));
     for (u32 base = 0; base < n; base += 64) {
       const u32 i = base + lane;
-      if (i < n) moves[i] = ws.epoch[i] != UNBOUND ? move_int : 0;
+      if (i < n) moves[rank[i]] = ws.epoch[i] != UNBOUND ? move_int : 0;
     }
     return;
   }
@@ -662,6 +354,7 @@ MODLE_DEV void generate_moves_dir(Cell& c, u32* moves, f64 speed, f64 std) {
     const u32 i = i0 + lane;
     const bool act = lane < cntb;
     const bool bnd = act && ws.epoch[i] != UNBOUND;
+    const u32 slot = act ? rank[i] : 0;
     const u64 bm = wave::ballot(bnd);
     const u32 ndraw = static_cast<u32>(wave::popc64(bm));
     rng_ensure(c.g, ndraw);
@@ -674,7 +367,7 @@ MODLE_DEV void generate_moves_dir(Cell& c, u32* moves, f64 speed, f64 std) {
     f64 unit = (bucket & 1u) ? x : -x;
     const u64 slow = wave::ballot(bnd && !fast);
     if (slow == 0) {
-      if (act) moves[i] = bnd ? move_from_normal(unit, speed, std) : 0;
+      if (act) moves[slot] = bnd ? move_from_normal(unit, speed, std) : 0;
       c.g.pos += ndraw;
       i0 += cntb;
     } else {
@@ -683,7 +376,7 @@ MODLE_DEV void generate_moves_dir(Cell& c, u32* moves, f64 speed, f64 std) {
       c.g.pos += static_cast<u32>(wave::popc64(bm & lanemask_lt(f)));
       const f64 exact = unit_normal_exact(c.g, c.lds);
       if (lane == f) unit = exact;
-      if (act && lane <= f) moves[i] = bnd ? move_from_normal(unit, speed, std) : 0;
+      if (act && lane <= f) moves[slot] = bnd ? move_from_normal(unit, speed, std) : 0;
       i0 += f + 1;
     }
   }
@@ -691,19 +384,22 @@ MODLE_DEV void generate_moves_dir(Cell& c, u32* moves, f64 speed, f64 std) {
 
 // =============================================================================================
 // adjust_moves_of_consecutive_extr_units (reference: simulation.cpp:350-407) as two segmented
-// scans over rank order, plus clamp_moves (reference: simulation.cpp:332-347).
+// scans over rank order, fused with clamp_moves (reference: simulation.cpp:332-347).
 //
 // rev units, ranks high -> low:  land'[k] = min(land[k], land'[k+1] - 1) while both units are
 // bound and neither reaches the 5'-end.  With d[k] = land[k] - k this is a segmented suffix
 // minimum of d.  The reference tests "unit k+1 reaches the 5'-end" on the *updated* move of
 // k+1; the scan uses the original move and the (rare, chromosome-end only) cases where the
 // update changes the answer are replayed sequentially from the first affected rank.
+// `do_adjust` / `do_clamp` exist for the phase-level test entry point.
 // =============================================================================================
-MODLE_DEV void adjust_moves_rev(Cell& c, const u32* mv_in, u32* mv_out) {
+MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp) {
   Workspace& ws = c.ws;
-  const u32 n = c.n_active;
+  const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
   const u64 start = c.iv->start;
+  const u32* mv_in = ws.r_move;
+  u32* mv_out = ws.tmp[0];
   const u32 nbatch = (n + 63) / 64;
   i64 carry_d = 0;
   bool carry_ok = false, carry_cross = false;
@@ -711,11 +407,10 @@ MODLE_DEV void adjust_moves_rev(Cell& c, const u32* mv_in, u32* mv_out) {
   for (u32 bi = nbatch; bi-- > 0;) {
     const u32 k = bi * 64 + lane;
     const bool act = k < n;
-    const u32 id = act ? ws.rev_rank[k] : 0;
-    const u32 P = act ? ws.rev_pos[id] : 0;
-    const u32 M = act ? mv_in[id] : 0;
-    const bool bnd = act && ws.epoch[id] != UNBOUND;
-    const bool okself = bnd && static_cast<u64>(P) > start + M;
+    const u32 P = act ? ws.r_pos[k] : UNBOUND;
+    const u32 M = act ? mv_in[k] : 0;
+    const bool bnd = act && P != UNBOUND;
+    const bool okself = do_adjust && bnd && static_cast<u64>(P) > start + M;
     const i64 d = okself ? static_cast<i64>(P - M) - static_cast<i64>(k) : 0;
     const bool ok_next_in = wave::shfl_down(okself, 1);
     const bool ok_next = lane < 63 ? ok_next_in : carry_ok;
@@ -734,8 +429,8 @@ MODLE_DEV void adjust_moves_rev(Cell& c, const u32* mv_in, u32* mv_out) {
     if (cont) val = imin64(val, carry_d);
     u32 Mnew = M;
     if (okself) Mnew = P - static_cast<u32>(val + static_cast<i64>(k));
-    if (act) mv_out[id] = Mnew;
     const bool cross = okself && static_cast<u64>(P) <= start + Mnew;
+    if (act) mv_out[k] = (bnd && do_clamp) ? umin(Mnew, P - static_cast<u32>(start)) : Mnew;
     const bool cross_next_in = wave::shfl_down(cross, 1);
     const bool cross_next = lane < 63 ? cross_next_in : carry_cross;
     const u64 vm = wave::ballot(link && cross_next);
@@ -748,27 +443,30 @@ MODLE_DEV void adjust_moves_rev(Cell& c, const u32* mv_in, u32* mv_out) {
   if (viol_rank >= 0) {
     // sequential replay (reference loop) from the first rank whose decision the scan got wrong
     for (u32 i = static_cast<u32>(viol_rank); i > 0; --i) {
-      const u32 i1 = ws.rev_rank[i - 1], i2 = ws.rev_rank[i];
-      u32 M1 = mv_in[i1];
-      if (ws.epoch[i1] != UNBOUND && ws.epoch[i2] != UNBOUND) {
-        const u32 M2 = mv_out[i2];
-        const u64 P1 = ws.rev_pos[i1], P2 = ws.rev_pos[i2];
+      u32 M1 = mv_in[i - 1];
+      const u64 P1 = ws.r_pos[i - 1], P2 = ws.r_pos[i];
+      if (P1 != UNBOUND && P2 != UNBOUND) {
+        const u32 M2 = mv_out[i];
         if (!(P1 <= start + M1 || P2 <= start + M2)) {
           const u64 pos1 = P1 - M1, pos2 = P2 - M2;
           if (pos2 <= pos1) M1 += static_cast<u32>(pos1 - pos2) + 1;
         }
+        if (do_clamp) M1 = umin(M1, static_cast<u32>(P1 - start));
       }
-      mv_out[i1] = M1;
+      mv_out[i - 1] = M1;
     }
     wave::sync_mem();
   }
+  swap_ptr(ws.r_move, ws.tmp[0]);
 }
 
-MODLE_DEV void adjust_moves_fwd(Cell& c, const u32* mv_in, u32* mv_out) {
+MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp) {
   Workspace& ws = c.ws;
-  const u32 n = c.n_active;
+  const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
   const u64 last = static_cast<u64>(c.iv->end) - 1;
+  const u32* mv_in = ws.f_move;
+  u32* mv_out = ws.tmp[0];
   const u32 nbatch = (n + 63) / 64;
   i64 carry_d = 0;
   bool carry_ok = false, carry_cross = false;
@@ -776,11 +474,10 @@ MODLE_DEV void adjust_moves_fwd(Cell& c, const u32* mv_in, u32* mv_out) {
   for (u32 bi = 0; bi < nbatch; ++bi) {
     const u32 k = bi * 64 + lane;
     const bool act = k < n;
-    const u32 id = act ? ws.fwd_rank[k] : 0;
-    const u32 P = act ? ws.fwd_pos[id] : 0;
-    const u32 M = act ? mv_in[id] : 0;
-    const bool bnd = act && ws.epoch[id] != UNBOUND;
-    const bool okself = bnd && static_cast<u64>(P) + M <= last;
+    const u32 P = act ? ws.f_pos[k] : UNBOUND;
+    const u32 M = act ? mv_in[k] : 0;
+    const bool bnd = act && P != UNBOUND;
+    const bool okself = do_adjust && bnd && static_cast<u64>(P) + M <= last;
     const i64 d = okself ? static_cast<i64>(static_cast<u64>(P) + M) - static_cast<i64>(k) : 0;
     const bool ok_prev_in = wave::shfl_up(okself, 1);
     const bool ok_prev = lane > 0 ? ok_prev_in : carry_ok;
@@ -799,8 +496,8 @@ MODLE_DEV void adjust_moves_fwd(Cell& c, const u32* mv_in, u32* mv_out) {
     if (cont) val = imax64(val, carry_d);
     u32 Mnew = M;
     if (okself) Mnew = static_cast<u32>(val + static_cast<i64>(k) - static_cast<i64>(P));
-    if (act) mv_out[id] = Mnew;
     const bool cross = okself && static_cast<u64>(P) + Mnew > last;
+    if (act) mv_out[k] = (bnd && do_clamp) ? umin(Mnew, static_cast<u32>(last - P)) : Mnew;
     const bool cross_prev_in = wave::shfl_up(cross, 1);
     const bool cross_prev = lane > 0 ? cross_prev_in : carry_cross;
     const u64 vm = wave::ballot(link && cross_prev);
@@ -813,60 +510,39 @@ MODLE_DEV void adjust_moves_fwd(Cell& c, const u32* mv_in, u32* mv_out) {
   wave::sync_mem();
   if (viol_rank >= 0) {
     for (u32 i = static_cast<u32>(viol_rank) + 1; i < n; ++i) {
-      const u32 i1 = ws.fwd_rank[i - 1], i2 = ws.fwd_rank[i];
-      u32 M2 = mv_in[i2];
-      if (ws.epoch[i1] != UNBOUND && ws.epoch[i2] != UNBOUND) {
-        const u32 M1 = mv_out[i1];
-        const u64 P1 = ws.fwd_pos[i1], P2 = ws.fwd_pos[i2];
+      u32 M2 = mv_in[i];
+      const u64 P1 = ws.f_pos[i - 1], P2 = ws.f_pos[i];
+      if (P1 != UNBOUND && P2 != UNBOUND) {
+        const u32 M1 = mv_out[i - 1];
         if (!(P1 + M1 > last || P2 + M2 > last)) {
           const u64 pos1 = P1 + M1, pos2 = P2 + M2;
           if (pos1 >= pos2) M2 += static_cast<u32>(pos1 - pos2) + 1;
         }
+        if (do_clamp) M2 = umin(M2, static_cast<u32>(last - P2));
       }
-      mv_out[i2] = M2;
+      mv_out[i] = M2;
     }
     wave::sync_mem();
   }
-}
-
-MODLE_DEV void clamp_moves(Cell& c, const u32* rev_in, const u32* fwd_in) {
-  Workspace& ws = c.ws;
-  const u32 n = c.n_active;
-  const u32 lane = wave::lane();
-  for (u32 base = 0; base < n; base += 64) {
-    const u32 i = base + lane;
-    if (i < n) {
-      u32 rm = rev_in[i], fm = fwd_in[i];
-      if (ws.epoch[i] != UNBOUND) {
-        rm = umin(rm, ws.rev_pos[i] - c.iv->start);
-        fm = umin(fm, c.iv->end - ws.fwd_pos[i] - 1);
-      }
-      ws.rev_moves[i] = rm;
-      ws.fwd_moves[i] = fm;
-    }
-  }
-  wave::sync_mem();
+  swap_ptr(ws.f_move, ws.tmp[0]);
 }
 
 MODLE_DEV void phase_generate_moves(Cell& c, bool burnin_completed) {
   const Params& p = *c.p;
-  generate_moves_dir(c, c.ws.rev_moves, burnin_completed ? p.rev_speed : p.rev_speed_burnin,
-                     p.rev_std);
-  generate_moves_dir(c, c.ws.fwd_moves, burnin_completed ? p.fwd_speed : p.fwd_speed_burnin,
-                     p.fwd_std);
+  generate_moves_dir<false>(c, burnin_completed ? p.rev_speed : p.rev_speed_burnin, p.rev_std);
+  generate_moves_dir<true>(c, burnin_completed ? p.fwd_speed : p.fwd_speed_burnin, p.fwd_std);
   wave::sync_mem();
-  adjust_moves_rev(c, c.ws.rev_moves, c.ws.tmp_a);
-  adjust_moves_fwd(c, c.ws.fwd_moves, c.ws.tmp_b);
-  clamp_moves(c, c.ws.tmp_a, c.ws.tmp_b);
+  adjust_moves_rev(c, true, true);
+  adjust_moves_fwd(c, true, true);
 }
 
 // =============================================================================================
 // ExtrusionBarriers::init_states / next_state (reference: extrusion_barriers.cpp:145-161,
 // 219-230)
 // =============================================================================================
-MODLE_DEV void barriers_init_states(Cell& c) {
+MODLE_DEV_NOINLINE void barriers_init_states(Cell& c) {
   const Interval& iv = *c.iv;
-  const u32 nb = iv.n_barriers;
+  const u32 nb = wave::uniform(iv.n_barriers);
   const u32 lane = wave::lane();
   for (u32 base = 0; base < nb; base += 64) {
     const u32 i = base + lane;
@@ -884,9 +560,9 @@ MODLE_DEV void barriers_init_states(Cell& c) {
   wave::sync_mem();
 }
 
-MODLE_DEV void barriers_next_state(Cell& c) {
+MODLE_DEV_NOINLINE void barriers_next_state(Cell& c) {
   const Interval& iv = *c.iv;
-  const u32 nb = iv.n_barriers;
+  const u32 nb = wave::uniform(iv.n_barriers);
   const u32 lane = wave::lane();
   for (u32 base = 0; base < nb; base += 64) {
     const u32 i = base + lane;
@@ -914,22 +590,19 @@ struct BoundaryCounts {
 };
 
 // detect_units_at_interval_boundaries (reference: simulation_detect_collisions.cpp:25-120)
-MODLE_DEV BoundaryCounts detect_boundaries(Cell& c) {
+MODLE_DEV_NOINLINE BoundaryCounts detect_boundaries(Cell& c) {
   Workspace& ws = c.ws;
-  const u32 n = c.n_active;
+  const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
   const u32 start = c.iv->start, last = c.iv->end - 1;
-  const u32 first_fwd_pos = ws.fwd_pos[ws.fwd_rank[0]];
+  const u32 first_fwd_pos = ws.f_pos[0];
   // position of the last bound unit in rev rank order
   u32 last_rev_pos = 0;
   for (u32 top = n; top > 0;) {
     const u32 cnt = umin(64u, top);
-    const u32 k = top - 1 - lane;  // descending
     const bool act = lane < cnt;
-    const u32 id = act ? ws.rev_rank[k] : 0;
-    const bool bnd = act && ws.epoch[id] != UNBOUND;
-    const u32 P = bnd ? ws.rev_pos[id] : 0;
-    const u64 m = wave::ballot(bnd);
+    const u32 P = act ? ws.r_pos[top - 1 - lane] : UNBOUND;  // descending ranks
+    const u64 m = wave::ballot(act && P != UNBOUND);
     if (m != 0) {
       last_rev_pos = wave::bcast(P, static_cast<u32>(wave::ctz64(m)));
       break;
@@ -942,16 +615,15 @@ MODLE_DEV BoundaryCounts detect_boundaries(Cell& c) {
   for (u32 base = 0; base < n; base += 64) {
     const u32 k = base + lane;
     const bool act = k < n;
-    const u32 id = act ? ws.rev_rank[k] : 0;
-    const u32 P = act ? ws.rev_pos[id] : 0;
-    const u32 M = act ? ws.rev_moves[id] : 0;
+    const u32 P = act ? ws.r_pos[k] : 0;
+    const u32 M = act ? ws.r_move[k] : 0;
     const bool at = act && P == start;
     const bool brk_b = act && !at && P > first_fwd_pos;
     const bool brk_c = act && !at && !brk_b && P - M == start;
     const u64 stop = wave::ballot(brk_b || brk_c);
     const u32 s = stop != 0 ? static_cast<u32>(wave::ctz64(stop)) : 64u;
     const bool mark = act && ((lane < s && at) || (lane == s && brk_c));
-    if (mark) ws.rev_coll[id] = mark5;
+    if (mark) ws.r_coll[k] = mark5;
     out.n5 += static_cast<u32>(wave::popc64(wave::ballot(mark)));
     if (stop != 0) break;
   }
@@ -960,10 +632,9 @@ MODLE_DEV BoundaryCounts detect_boundaries(Cell& c) {
     const u32 cnt = umin(64u, top - 1);
     const u32 k = top - 1 - lane;
     const bool act = lane < cnt;
-    const u32 id = act ? ws.fwd_rank[k] : 0;
-    const bool bnd = act && ws.epoch[id] != UNBOUND;
-    const u32 P = act ? ws.fwd_pos[id] : 0;
-    const u32 M = act ? ws.fwd_moves[id] : 0;
+    const u32 P = act ? ws.f_pos[k] : 0;
+    const u32 M = act ? ws.f_move[k] : 0;
+    const bool bnd = act && P != UNBOUND;
     const bool unb = act && !bnd;
     const bool at = bnd && P == last;
     const bool brk_b = bnd && !at && P < last_rev_pos;
@@ -971,7 +642,7 @@ MODLE_DEV BoundaryCounts detect_boundaries(Cell& c) {
     const u64 stop = wave::ballot(brk_b || brk_c);
     const u32 s = stop != 0 ? static_cast<u32>(wave::ctz64(stop)) : 64u;
     const bool mark = (lane < s && at) || (lane == s && brk_c);
-    if (mark) ws.fwd_coll[id] = mark3;
+    if (mark) ws.f_coll[k] = mark3;
     out.n3 += static_cast<u32>(wave::popc64(wave::ballot(mark || (lane < s && unb))));
     if (stop != 0) break;
     top -= cnt;
@@ -980,33 +651,23 @@ MODLE_DEV BoundaryCounts detect_boundaries(Cell& c) {
   return out;
 }
 
-MODLE_DEV u32 lower_bound_u32(const u32* a, u32 n, u32 key) {  // first index with a[i] >= key
-  u32 lo = 0, hi = n;
-  while (lo < hi) {
-    const u32 mid = (lo + hi) >> 1;
-    if (a[mid] < key) lo = mid + 1; else hi = mid;
-  }
-  return lo;
-}
-
 // detect_lef_bar_collisions (reference: simulation_detect_collisions.cpp:123-247), evaluated
 // per extrusion unit: barrier b is tested against the first rev unit downstream of it (first fwd
 // unit upstream), so the barriers that can stall the unit of rank j are those between the unit
 // of rank j-1 and itself that lie within its move.  Bernoulli trials (pblock not in {0,1}) are
 // numbered in the reference's order: barriers ascending for rev units, descending for fwd units.
 template <bool FWD>
-MODLE_DEV void detect_lef_bar(Cell& c, BoundaryCounts bc) {
+MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
   Workspace& ws = c.ws;
   const Interval& iv = *c.iv;
   const Params& p = *c.p;
-  const u32 n = c.n_active;
-  const u32 nb = iv.n_barriers;
+  const u32 n = wave::uniform(c.n_active);
+  const u32 nb = wave::uniform(iv.n_barriers);
   if (nb == 0) return;
   const u32 lane = wave::lane();
-  const u32* rank = FWD ? ws.fwd_rank : ws.rev_rank;
-  const u32* pos = FWD ? ws.fwd_pos : ws.rev_pos;
-  const u32* moves = FWD ? ws.fwd_moves : ws.rev_moves;
-  u32* coll = FWD ? ws.fwd_coll : ws.rev_coll;
+  const u32* pos = FWD ? ws.f_pos : ws.r_pos;
+  const u32* moves = FWD ? ws.f_move : ws.r_move;
+  u32* coll = FWD ? ws.f_coll : ws.r_coll;
   const u32 major_dir = FWD ? DIR_FWD : DIR_REV;
   const bool trials = !((p.pblock_major == 1.0 || p.pblock_major == 0.0) &&
                         (p.pblock_minor == 1.0 || p.pblock_minor == 0.0));
@@ -1022,10 +683,9 @@ MODLE_DEV void detect_lef_bar(Cell& c, BoundaryCounts bc) {
     const bool act = kk >= 0 && kk < static_cast<i64>(n);
     if (!wave::any(act)) break;
     const u32 k = act ? static_cast<u32>(kk) : 0;
-    const u32 id = act ? rank[k] : 0;
-    const u32 P = act ? pos[id] : 0;
-    const u32 M = act ? moves[id] : 0;
-    const bool bnd = act && ws.epoch[id] != UNBOUND;
+    const u32 P = act ? pos[k] : 0;
+    const u32 M = act ? moves[k] : 0;
+    const bool bnd = act && P != UNBOUND;
     // neighbour towards which the barriers are shadowed (rank k-1 for rev, k+1 for fwd)
     const u32 nbr_in = wave::shfl_up(P, 1);
     const bool first = (bi == 0 && lane == 0);
@@ -1037,16 +697,16 @@ MODLE_DEV void detect_lef_bar(Cell& c, BoundaryCounts bc) {
         // prev <= bpos < P and P - bpos <= M
         const u32 reach = P - M;  // M <= P - start after clamping
         const u32 lo_pos = first ? reach : umax(reach, nbr);
-        b_lo = lower_bound_u32(iv.bar_pos, nb, lo_pos);
-        b_hi = lower_bound_u32(iv.bar_pos, nb, P);
+        b_lo = bar_lower_bound(iv, lo_pos);
+        b_hi = b_lo;
+        while (b_hi < nb && iv.bar_pos[b_hi] < P) ++b_hi;
       } else {
         // P < bpos <= next and bpos - P <= M
         const u64 reach = static_cast<u64>(P) + M;
         const u64 hi_pos = first ? reach : umin64(reach, nbr);
-        b_lo = lower_bound_u32(iv.bar_pos, nb, P + 1);
-        b_hi = hi_pos >= 0xFFFFFFFFull ? nb
-                                        : lower_bound_u32(iv.bar_pos, nb,
-                                                          static_cast<u32>(hi_pos) + 1);
+        b_lo = bar_lower_bound(iv, static_cast<u64>(P) + 1);
+        b_hi = b_lo;
+        while (b_hi < nb && iv.bar_pos[b_hi] <= hi_pos) ++b_hi;
       }
     }
     // number of Bernoulli trials this unit consumes
@@ -1088,7 +748,7 @@ MODLE_DEV void detect_lef_bar(Cell& c, BoundaryCounts bc) {
       }
       if (hit) winner = b;  // later visits overwrite earlier ones
     }
-    if (winner != 0xFFFFFFFFu) coll[id] = cw_make(winner, EV_COLLISION | EV_LEF_BAR);
+    if (winner != 0xFFFFFFFFu) coll[k] = cw_make(winner, EV_COLLISION | EV_LEF_BAR);
     c.g.pos += total;
     carry_pos = wave::bcast(P, 63);
   }
@@ -1126,38 +786,62 @@ MODLE_DEV u32 stalling_barrier_pos(const Interval& iv, u32 word) {
 // evaluated per rev unit: the merge loop pairs the rev unit of rank j with the last fwd unit
 // strictly upstream of it, provided j is the first rev unit downstream of that fwd unit and the
 // fwd unit is not the last one the loop is allowed to look at.
-MODLE_DEV void detect_primary(Cell& c, BoundaryCounts bc, const u32* fwd_sorted) {
+//
+// With `fuse_correct`, correct_moves_for_primary_lef_lef_collisions (reference:
+// simulation_correct_moves.cpp:53-121) is applied on the spot: every unit takes part in at most
+// one pair and the pair's corrected moves depend only on the two units (original moves, or
+// "distance to the stalling barrier - 1" for a unit that stays stalled by a barrier, which is
+// what correct_moves_for_lef_bar_collisions stores for it).
+MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_correct) {
   Workspace& ws = c.ws;
   const Params& p = *c.p;
-  const u32 n = c.n_active;
+  const Interval& iv = *c.iv;
+  const u32 n = wave::uniform(c.n_active);
   if (bc.n5 == n || bc.n3 == n) return;
   const u32 lane = wave::lane();
   const u32 i2 = bc.n3 == 0 ? n : n - (bc.n3 - 1);
   const bool trials = p.p_bypass != 0.0;
   const f64 p_collide = 1.0 - p.p_bypass;
   const u32 prim = EV_COLLISION | EV_LEF_LEF_PRIMARY;
+  u32* stage = c.lds.stage;
   u32 carry_pos = 0;
+  u32 carry_pf = 0;  // fwd units strictly upstream of the last rev unit handled so far
   for (u32 base = bc.n5; base < n; base += 64) {
     const u32 k = base + lane;
     const bool act = k < n;
-    const u32 rev_idx = act ? ws.rev_rank[k] : 0;
-    const u32 R = act ? ws.rev_pos[rev_idx] : 0;
+    const u32 R = act ? ws.r_pos[k] : UNBOUND;
     const u32 prev_in = wave::shfl_up(R, 1);
     const u32 Rprev = lane > 0 ? prev_in : carry_pos;
-    bool cand = false;
-    u32 fwd_idx = 0, F = 0, rev_move = 0, fwd_move = 0;
+    // pf = number of fwd units strictly upstream of R.  pf is monotone in the rank, so a slice
+    // of the sorted fwd positions starting at the previous batch's value is staged in LDS and
+    // searched there; lanes whose answer lies beyond the slice search device memory.
+    const u32 w0 = carry_pf > 0 ? carry_pf - 1 : 0;
+    wave::lockstep();
+    for (u32 t = lane; t < STAGE_CAP; t += 64) stage[t] = (w0 + t < n) ? ws.f_pos[w0 + t] : UNBOUND;
+    wave::sync_mem();
+    u32 pf = 0;
     if (act) {
-      const u32 pf = lower_bound_u32(fwd_sorted, n, R);  // fwd units strictly upstream of R
-      if (pf >= 1 && pf < i2) {
-        F = fwd_sorted[pf - 1];
-        const bool first_after = (k == bc.n5) || Rprev <= F;
-        if (first_after) {
-          fwd_idx = ws.fwd_rank[pf - 1];
-          rev_move = ws.rev_moves[rev_idx];
-          fwd_move = ws.fwd_moves[fwd_idx];
-          const u32 delta = R - F;  // > 0 by construction
-          cand = static_cast<u64>(delta) < static_cast<u64>(rev_move) + fwd_move;
-        }
+      u32 lo = 0, hi = STAGE_CAP;
+      while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if (stage[mid] < R) lo = mid + 1; else hi = mid;
+      }
+      if (lo == STAGE_CAP && w0 + STAGE_CAP < n) {
+        pf = lower_bound_u32(ws.f_pos, n, R);
+      } else {
+        pf = umin(w0 + lo, n);
+      }
+    }
+    bool cand = false;
+    u32 F = 0, rev_move = 0, fwd_move = 0;
+    if (act && pf >= 1 && pf < i2) {
+      F = ws.f_pos[pf - 1];
+      const bool first_after = (k == bc.n5) || Rprev <= F;
+      if (first_after) {
+        rev_move = ws.r_move[k];
+        fwd_move = ws.f_move[pf - 1];
+        const u32 delta = R - F;  // > 0 by construction
+        cand = static_cast<u64>(delta) < static_cast<u64>(rev_move) + fwd_move;
       }
     }
     const u64 cm = wave::ballot(cand);
@@ -1170,81 +854,87 @@ MODLE_DEV void detect_primary(Cell& c, BoundaryCounts bc, const u32* fwd_sorted)
       c.g.pos += cnt;
     }
     if (hit) {
+      const u32 kf = pf - 1;
+      const u32 rev_id = ws.r_id[k], fwd_id = ws.f_id[kf];
       u32 cpos_rev, cpos_fwd;
       lef_lef_collision_pos(R, F, rev_move, fwd_move, cpos_rev, cpos_fwd);
-      const u32 rc = ws.rev_coll[rev_idx], fc = ws.fwd_coll[fwd_idx];
+      const u32 rc = ws.r_coll[k], fc = ws.f_coll[kf];
       const bool rev_occ = cw_occurred(rc), fwd_occ = cw_occurred(fc);
+      bool both = false;
       if (!rev_occ && !fwd_occ) {
-        ws.rev_coll[rev_idx] = cw_make(fwd_idx, prim);
-        ws.fwd_coll[fwd_idx] = cw_make(rev_idx, prim);
+        ws.r_coll[k] = cw_make(fwd_id, prim);
+        ws.f_coll[kf] = cw_make(rev_id, prim);
+        both = true;
       } else if (rev_occ && !fwd_occ) {
-        const u32 barrier_pos = stalling_barrier_pos(*c.iv, rc);
-        if (cpos_fwd > barrier_pos) ws.rev_coll[rev_idx] = cw_make(fwd_idx, prim);
-        ws.fwd_coll[fwd_idx] = cw_make(rev_idx, prim);
+        const u32 barrier_pos = stalling_barrier_pos(iv, rc);
+        ws.f_coll[kf] = cw_make(rev_id, prim);
+        if (cpos_fwd > barrier_pos) {
+          // the LEF-LEF collision happens before the predicted LEF-BAR one
+          ws.r_coll[k] = cw_make(fwd_id, prim);
+          both = true;
+        } else if (fuse_correct && cw_occurred_as(rc, EV_LEF_BAR)) {
+          // fwd unit runs into a rev unit that stays stalled 1 bp downstream of its barrier
+          const u32 rev_move_stalled = (R - barrier_pos) - 1;
+          ws.f_move[kf] = (R - rev_move_stalled) - F - 1;
+        }
       } else if (!rev_occ && fwd_occ) {
-        const u32 barrier_pos = stalling_barrier_pos(*c.iv, fc);
-        ws.rev_coll[rev_idx] = cw_make(fwd_idx, prim);
-        if (cpos_rev < barrier_pos) ws.fwd_coll[fwd_idx] = cw_make(rev_idx, prim);
+        const u32 barrier_pos = stalling_barrier_pos(iv, fc);
+        ws.r_coll[k] = cw_make(fwd_id, prim);
+        if (cpos_rev < barrier_pos) {
+          ws.f_coll[kf] = cw_make(rev_id, prim);
+          both = true;
+        } else if (fuse_correct && cw_occurred_as(fc, EV_LEF_BAR)) {
+          const u32 fwd_move_stalled = (barrier_pos - F) - 1;
+          ws.r_move[k] = R - (F + fwd_move_stalled) - 1;
+        }
+      }
+      if (both && fuse_correct) {
+        ws.r_move[k] = R - cpos_rev;
+        ws.f_move[kf] = cpos_fwd - F;
       }
     }
     carry_pos = wave::bcast(R, 63);
-  }
-  wave::sync_mem();
-}
-
-// correct_moves_for_lef_bar_collisions (reference: simulation_correct_moves.cpp:19-50)
-MODLE_DEV void correct_moves_lef_bar(Cell& c) {
-  Workspace& ws = c.ws;
-  const u32 n = c.n_active;
-  const u32 lane = wave::lane();
-  for (u32 base = 0; base < n; base += 64) {
-    const u32 i = base + lane;
-    if (i < n) {
-      const u32 rc = ws.rev_coll[i], fc = ws.fwd_coll[i];
-      if (cw_occurred_as(rc, EV_LEF_BAR))
-        ws.rev_moves[i] = (ws.rev_pos[i] - c.iv->bar_pos[cw_index(rc)]) - 1;
-      if (cw_occurred_as(fc, EV_LEF_BAR))
-        ws.fwd_moves[i] = (c.iv->bar_pos[cw_index(fc)] - ws.fwd_pos[i]) - 1;
-    }
+    // last active lane's pf (inactive lanes hold 0)
+    const u64 am = wave::ballot(act);
+    carry_pf = wave::bcast(pf, static_cast<u32>(63 - wave::clz64(am)));
   }
   wave::sync_mem();
 }
 
 // correct_moves_for_primary_lef_lef_collisions (reference: simulation_correct_moves.cpp:53-121)
-// Every unit takes part in at most one primary pair, so the two reference loops parallelise
-// over LEF ids.
-MODLE_DEV void correct_moves_primary(Cell& c) {
+// as a stand-alone pass; only used by the phase-level test entry point when the reference's
+// hook sequence runs it separately from detection.
+MODLE_DEV_NOINLINE void correct_moves_primary_standalone(Cell& c) {
   Workspace& ws = c.ws;
-  const u32 n = c.n_active;
+  const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
   for (u32 base = 0; base < n; base += 64) {
-    const u32 r = base + lane;
-    if (r < n) {
-      const u32 rc = ws.rev_coll[r];
+    const u32 k = base + lane;
+    if (k < n) {
+      const u32 rc = ws.r_coll[k];
       if (cw_occurred_as(rc, EV_LEF_LEF_PRIMARY)) {
-        const u32 f = cw_index(rc);
-        const u32 fc = ws.fwd_coll[f];
+        const u32 kf = ws.f_rank[cw_index(rc)];
+        const u32 fc = ws.f_coll[kf];
         if (cw_occurred_as(fc, EV_LEF_LEF_PRIMARY)) {
           u32 p1, p2;
-          lef_lef_collision_pos(ws.rev_pos[r], ws.fwd_pos[f], ws.rev_moves[r], ws.fwd_moves[f],
-                                p1, p2);
-          ws.rev_moves[r] = ws.rev_pos[r] - p1;
-          ws.fwd_moves[f] = p2 - ws.fwd_pos[f];
+          lef_lef_collision_pos(ws.r_pos[k], ws.f_pos[kf], ws.r_move[k], ws.f_move[kf], p1, p2);
+          ws.r_move[k] = ws.r_pos[k] - p1;
+          ws.f_move[kf] = p2 - ws.f_pos[kf];
         } else if (cw_occurred_as(fc, EV_LEF_BAR)) {
-          ws.rev_moves[r] = ws.rev_pos[r] - (ws.fwd_pos[f] + ws.fwd_moves[f]) - 1;
+          ws.r_move[k] = ws.r_pos[k] - (ws.f_pos[kf] + ws.f_move[kf]) - 1;
         }
       }
     }
   }
   wave::sync_mem();
   for (u32 base = 0; base < n; base += 64) {
-    const u32 f = base + lane;
-    if (f < n) {
-      const u32 fc = ws.fwd_coll[f];
+    const u32 k = base + lane;
+    if (k < n) {
+      const u32 fc = ws.f_coll[k];
       if (cw_occurred_as(fc, EV_LEF_LEF_PRIMARY)) {
-        const u32 r = cw_index(fc);
-        if (cw_occurred_as(ws.rev_coll[r], EV_LEF_BAR))
-          ws.fwd_moves[f] = (ws.rev_pos[r] - ws.rev_moves[r]) - ws.fwd_pos[f] - 1;
+        const u32 kr = ws.r_rank[cw_index(fc)];
+        if (cw_occurred_as(ws.r_coll[kr], EV_LEF_BAR))
+          ws.f_move[k] = (ws.r_pos[kr] - ws.r_move[kr]) - ws.f_pos[k] - 1;
       }
     }
   }
@@ -1257,51 +947,52 @@ MODLE_DEV void correct_moves_primary(Cell& c) {
 // is loaded into registers, a vector test discards the ranks that cannot be candidates and the
 // rest are walked in order with lane broadcasts.  Ranks whose collision was avoided are
 // appended to `list` (rank positions, visiting order) for fix_secondary.
+//
+// correct_moves_for_lef_bar_collisions (reference: simulation_correct_moves.cpp:19-50) is fused
+// into the load: a unit stalled by a barrier gets move = distance - 1.  (It has to come after
+// primary detection, which tests the uncorrected moves.)
 template <bool FWD>
-MODLE_DEV u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, u32 list_cap,
-                                bool& overflow) {
+MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, u32 list_cap,
+                                bool& overflow, bool correct_lef_bar, bool do_secondary) {
   Workspace& ws = c.ws;
   const Params& p = *c.p;
-  const u32 n = c.n_active;
+  const Interval& iv = *c.iv;
+  const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
-  const u32* rank = FWD ? ws.fwd_rank : ws.rev_rank;
-  const u32* pos = FWD ? ws.fwd_pos : ws.rev_pos;
-  u32* moves = FWD ? ws.fwd_moves : ws.rev_moves;
-  u32* coll = FWD ? ws.fwd_coll : ws.rev_coll;
+  const u32* pos = FWD ? ws.f_pos : ws.r_pos;
+  const u32* ids = FWD ? ws.f_id : ws.r_id;
+  u32* moves = FWD ? ws.f_move : ws.r_move;
+  u32* coll = FWD ? ws.f_coll : ws.r_coll;
   const bool trials = p.p_bypass != 0.0;
   const f64 p_collide = 1.0 - p.p_bypass;
   u32 n_list = 0;
-  // rev: i = max(1, n5) .. n-1 ascending, U1 = rank i-1 (blocker), U2 = rank i
-  // fwd: i = (n - min(n3, n3-1) - 1) .. 1 descending, U2 = rank i (blocker), U1 = rank i-1
-  // In both cases the "follower" is visited in order and its blocker is the previously visited
-  // neighbour; `f` below indexes followers.
+  // rev: followers i = max(1, n5) .. n-1 ascending, blocker = rank i-1
+  // fwd: followers i-1 for i = (n - min(n3, n3-1) - 1) .. 1 descending, blocker = rank i
   const i64 f_first = FWD ? static_cast<i64>(bc.n3 == 0 ? n - 1 : n - bc.n3) - 1
                           : static_cast<i64>(umax(1u, bc.n5));
-  const i64 f_last = FWD ? 0 : static_cast<i64>(n) - 1;  // inclusive
-  const i64 count = FWD ? f_first - f_last + 1 : f_last - f_first + 1;
-  if (count <= 0) return 0;
-  // blocker state carried from one batch to the next
-  u32 carry_pos, carry_move, carry_coll, carry_id;
-  {
-    const u32 kb = static_cast<u32>(FWD ? f_first + 1 : f_first - 1);
-    carry_id = rank[kb];
-    carry_pos = pos[carry_id];
-    carry_move = moves[carry_id];
-    carry_coll = coll[carry_id];
-  }
-  for (i64 done = 0; done < count; done += 64) {
-    const i64 kk = FWD ? f_first - done - lane : f_first + done + lane;
-    const bool act = done + lane < count;
+  // every rank is visited in direction order (so that every LEF-BAR move gets corrected); only
+  // ranks from f_first on (in visiting order) can be followers
+  u32 carry_pos = 0, carry_move = 0, carry_coll = 0, carry_id = 0;
+  const u32 nbatch = (n + 63) / 64;
+  for (u32 bi = 0; bi < nbatch; ++bi) {
+    const i64 kk = FWD ? static_cast<i64>(n) - 1 - static_cast<i64>(bi) * 64 - lane
+                       : static_cast<i64>(bi) * 64 + lane;
+    const bool act = kk >= 0 && kk < static_cast<i64>(n);
     const u32 k = act ? static_cast<u32>(kk) : 0;
-    const u32 id = act ? rank[k] : 0;
-    const u32 P = act ? pos[id] : 0;
-    u32 M = act ? moves[id] : 0;
-    u32 C = act ? coll[id] : 0;
-    const u32 M0 = M, C0 = C;
+    const u32 P = act ? pos[k] : 0;
+    const u32 id = act ? ids[k] : 0;
+    const u32 M0 = act ? moves[k] : 0;
+    const u32 C0 = act ? coll[k] : 0;
+    u32 M = M0, C = C0;
+    if (correct_lef_bar && act && cw_occurred_as(C, EV_LEF_BAR)) {
+      const u32 bp = iv.bar_pos[cw_index(C)];
+      M = (FWD ? bp - P : P - bp) - 1;
+    }
+    const bool follower = do_secondary && act && (FWD ? (kk <= f_first) : (kk >= f_first));
     // vector pre-filter: follower free and able to reach the blocker's current position
     const u32 bp_in = wave::shfl_up(P, 1);
     const u32 blocker_pos = lane > 0 ? bp_in : carry_pos;
-    const bool pot = act && !cw_occurred(C) &&
+    const bool pot = follower && !cw_occurred(C) &&
                      (FWD ? static_cast<u64>(P) + M >= blocker_pos
                           : static_cast<u64>(P) - M <= blocker_pos);
     u64 todo = wave::ballot(pot);
@@ -1340,8 +1031,8 @@ MODLE_DEV u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, u32 list_
       }
     }
     if (act && (M != M0 || C != C0)) {
-      moves[id] = M;
-      coll[id] = C;
+      moves[k] = M;
+      coll[k] = C;
     }
     carry_pos = wave::bcast(P, 63);
     carry_move = wave::bcast(M, 63);
@@ -1353,113 +1044,97 @@ MODLE_DEV u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, u32 list_
 }
 
 // fix_secondary_lef_lef_collisions (reference: simulation_detect_collisions.cpp:517-644).
-// Rare (one entry per avoided secondary collision); replayed sequentially, uniformly.
-MODLE_DEV void fix_secondary_rev(Cell& c, const u32* list, u32 n_list) {
+// Rare (one entry per avoided secondary collision); replayed sequentially, uniformly.  The two
+// units trade places: slots i-1 and i of the rank-ordered arrays are rewritten.
+MODLE_DEV_NOINLINE void fix_secondary_rev(Cell& c, const u32* list, u32 n_list) {
   Workspace& ws = c.ws;
   const u32 start = c.iv->start;
   const u32 sec = EV_LEF_LEF_SECONDARY;
   for (u32 q = 0; q < n_list; ++q) {  // list is in ascending rank order
     const u32 i = list[q];
-    const u32 idx2 = ws.rev_rank[i];
-    if (!cw_avoided_as(ws.rev_coll[idx2], sec)) continue;
-    const u32 idx1 = ws.rev_rank[i - 1];
-    const u32 pos1 = ws.rev_pos[idx1] - ws.rev_moves[idx1];
-    u32 m2 = 0;
-    if (ws.rev_pos[idx2] > pos1 + 1) m2 = ws.rev_pos[idx2] - (pos1 + 1);
-    const u32 c2 = cw_make(idx1, EV_COLLISION | sec);
-    const u32 p1 = ws.rev_pos[idx1], p2 = ws.rev_pos[idx2];
-    const u32 np1 = umin(ws.fwd_pos[idx1], p2);
-    const u32 np2 = umin(ws.fwd_pos[idx2], p1);
-    const u32 c1 = ws.rev_coll[idx1];
-    const u32 m1 = ws.rev_moves[idx1];
+    if (!cw_avoided_as(ws.r_coll[i], sec)) continue;
+    const u32 id1 = ws.r_id[i - 1], id2 = ws.r_id[i];
+    const u32 p1 = ws.r_pos[i - 1], p2 = ws.r_pos[i];
+    const u32 m1 = ws.r_move[i - 1];
+    const u32 c1 = ws.r_coll[i - 1];
+    const u32 pos1 = p1 - m1;
+    const u32 m2 = p2 > pos1 + 1 ? p2 - (pos1 + 1) : 0;
+    const u32 c2 = cw_make(id1, EV_COLLISION | sec);
+    const u32 np1 = umin(ws.f_pos[ws.f_rank[id1]], p2);
+    const u32 np2 = umin(ws.f_pos[ws.f_rank[id2]], p1);
     wave::lockstep();
-    // swapped collisions / moves, then re-clamp
-    ws.rev_pos[idx1] = np1;
-    ws.rev_pos[idx2] = np2;
-    ws.rev_coll[idx1] = c2;
-    ws.rev_coll[idx2] = c1;
-    ws.rev_moves[idx1] = umin(np1 - start, m2);
-    ws.rev_moves[idx2] = umin(np2 - start, m1);
-    ws.rev_rank[i - 1] = idx2;
-    ws.rev_rank[i] = idx1;
+    // unit 2 moves to slot i-1 with unit 1's old collision / move, unit 1 to slot i
+    ws.r_id[i - 1] = id2;
+    ws.r_pos[i - 1] = np2;
+    ws.r_coll[i - 1] = c1;
+    ws.r_move[i - 1] = umin(np2 - start, m1);
+    ws.r_id[i] = id1;
+    ws.r_pos[i] = np1;
+    ws.r_coll[i] = c2;
+    ws.r_move[i] = umin(np1 - start, m2);
+    ws.r_rank[id2] = i - 1;
+    ws.r_rank[id1] = i;
     wave::sync_mem();
   }
 }
 
-MODLE_DEV void fix_secondary_fwd(Cell& c, const u32* list, u32 n_list) {
+MODLE_DEV_NOINLINE void fix_secondary_fwd(Cell& c, const u32* list, u32 n_list) {
   Workspace& ws = c.ws;
   const u32 last = c.iv->end - 1;
   const u32 sec = EV_LEF_LEF_SECONDARY;
   for (u32 q = n_list; q-- > 0;) {  // list is in descending rank order; the fix loop ascends
     const u32 i = list[q];
-    const u32 idx1 = ws.fwd_rank[i];
-    if (!cw_avoided_as(ws.fwd_coll[idx1], sec)) continue;
-    const u32 idx2 = ws.fwd_rank[i + 1];
-#ifdef MODLE_TRACE
-    if (wave::lane() == 0 && getenv("MO_TRACE_FIX"))
-      fprintf(stderr, "FIXF i=%u idx1=%u idx2=%u c1=%x c2=%x p1=%u p2=%u m1=%u m2=%u\n", i, idx1,
-              idx2, ws.fwd_coll[idx1], ws.fwd_coll[idx2], ws.fwd_pos[idx1], ws.fwd_pos[idx2],
-              ws.fwd_moves[idx1], ws.fwd_moves[idx2]);
-#endif
-    const u32 pos2 = ws.fwd_pos[idx2] + ws.fwd_moves[idx2];
-    u32 m1 = 0;
-    if (pos2 > ws.fwd_pos[idx1] + 1) m1 = pos2 - (ws.fwd_pos[idx1] + 1);
-    const u32 c1 = cw_make(idx2, EV_COLLISION | sec);
-    const u32 p1 = ws.fwd_pos[idx1], p2 = ws.fwd_pos[idx2];
-    const u32 np1 = umax(ws.rev_pos[idx1], p2);
-    const u32 np2 = umax(ws.rev_pos[idx2], p1);
-    const u32 c2 = ws.fwd_coll[idx2];
-    const u32 m2 = ws.fwd_moves[idx2];
+    if (!cw_avoided_as(ws.f_coll[i], sec)) continue;
+    const u32 id1 = ws.f_id[i], id2 = ws.f_id[i + 1];
+    const u32 p1 = ws.f_pos[i], p2 = ws.f_pos[i + 1];
+    const u32 m2 = ws.f_move[i + 1];
+    const u32 c2 = ws.f_coll[i + 1];
+    const u32 pos2 = p2 + m2;
+    const u32 m1 = pos2 > p1 + 1 ? pos2 - (p1 + 1) : 0;
+    const u32 c1 = cw_make(id2, EV_COLLISION | sec);
+    const u32 np1 = umax(ws.r_pos[ws.r_rank[id1]], p2);
+    const u32 np2 = umax(ws.r_pos[ws.r_rank[id2]], p1);
     wave::lockstep();
-    ws.fwd_pos[idx1] = np1;
-    ws.fwd_pos[idx2] = np2;
-    ws.fwd_coll[idx1] = c2;
-    ws.fwd_coll[idx2] = c1;
-    ws.fwd_moves[idx1] = umin(last - np1, m2);
-    ws.fwd_moves[idx2] = umin(last - np2, m1);
-    ws.fwd_rank[i] = idx2;
-    ws.fwd_rank[i + 1] = idx1;
+    ws.f_id[i] = id2;
+    ws.f_pos[i] = np2;
+    ws.f_coll[i] = c1;
+    ws.f_move[i] = umin(last - np2, m1);
+    ws.f_id[i + 1] = id1;
+    ws.f_pos[i + 1] = np1;
+    ws.f_coll[i + 1] = c2;
+    ws.f_move[i + 1] = umin(last - np1, m2);
+    ws.f_rank[id2] = i;
+    ws.f_rank[id1] = i + 1;
     wave::sync_mem();
   }
 }
 
-MODLE_DEV void build_sorted_positions(Cell& c, const u32* rank, const u32* pos, u32* out) {
-  const u32 n = c.n_active;
-  const u32 lane = wave::lane();
-  for (u32 base = 0; base < n; base += 64) {
-    const u32 k = base + lane;
-    if (k < n) out[k] = pos[rank[k]];
-  }
-  wave::sync_mem();
-}
-
 MODLE_DEV void clear_collisions(Cell& c) {
-  const u32 n = c.n_active;
+  const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
   for (u32 base = 0; base < n; base += 64) {
     const u32 i = base + lane;
     if (i < n) {
-      c.ws.rev_coll[i] = 0;
-      c.ws.fwd_coll[i] = 0;
+      c.ws.r_coll[i] = 0;
+      c.ws.f_coll[i] = 0;
     }
   }
   wave::sync_mem();
 }
 
-// returns false when the per-wave list overflowed (the cell is then flagged as failed)
+// returns false when an internal capacity was exceeded (the cell is then flagged as failed)
 MODLE_DEV bool phase_process_collisions(Cell& c) {
   const BoundaryCounts bc = detect_boundaries(c);
   detect_lef_bar<false>(c, bc);
   detect_lef_bar<true>(c, bc);
-  build_sorted_positions(c, c.ws.fwd_rank, c.ws.fwd_pos, c.ws.tmp_c);
-  detect_primary(c, bc, c.ws.tmp_c);
-  correct_moves_lef_bar(c);
-  correct_moves_primary(c);
+  detect_primary(c, bc, true);
   bool overflow = false;
-  u32* list_rev = c.lds.list;
-  u32* list_fwd = c.lds.list + LIST_CAP / 2;
-  const u32 nr = process_secondary<false>(c, bc, list_rev, LIST_CAP / 2, overflow);
-  const u32 nf = process_secondary<true>(c, bc, list_fwd, LIST_CAP / 2, overflow);
+  // avoided secondary collisions are listed in device scratch: one entry per unit at most
+  u32* list_rev = c.ws.tmp[5];
+  u32* list_fwd = c.ws.tmp[6];
+  const u32 cap = c.ws.capacity_lefs;
+  const u32 nr = process_secondary<false>(c, bc, list_rev, cap, overflow, true, true);
+  const u32 nf = process_secondary<true>(c, bc, list_fwd, cap, overflow, true, true);
   if (overflow) c.error = ERR_LIST_OVERFLOW;
   if (c.error != 0) return false;
   if (nr != 0) fix_secondary_rev(c, list_rev, nr);
@@ -1470,22 +1145,48 @@ MODLE_DEV bool phase_process_collisions(Cell& c) {
 // =============================================================================================
 // extrude + release_lefs (reference: simulation.cpp:498-521, 553-601)
 // =============================================================================================
-MODLE_DEV void phase_extrude_and_release(Cell& c, bool burnin_completed) {
+MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed) {
   Workspace& ws = c.ws;
   const Params& p = *c.p;
-  const u32 n = c.n_active;
+  const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
   const f64 base_p = burnin_completed ? p.p_release : p.p_release_burnin;
+  // extrude in rank order; units stalled by a barrier that blocks their own direction ("hard"
+  // stalls) are reported to their LEF through stall[id]
+  for (u32 base = 0; base < n; base += 64) {
+    const u32 k = base + lane;
+    if (k < n) {
+      const u32 P = ws.r_pos[k];
+      if (P != UNBOUND) {
+        ws.r_pos[k] = P - ws.r_move[k];
+        const u32 rc = ws.r_coll[k];
+        if (cw_occurred_as(rc, EV_LEF_BAR) && c.iv->bar_dir[cw_index(rc)] == DIR_REV)
+          ws.stall[ws.r_id[k]] = 1;
+      }
+    }
+  }
+  wave::sync_mem();
+  for (u32 base = 0; base < n; base += 64) {
+    const u32 k = base + lane;
+    if (k < n) {
+      const u32 P = ws.f_pos[k];
+      if (P != UNBOUND) {
+        ws.f_pos[k] = P + ws.f_move[k];
+        const u32 fc = ws.f_coll[k];
+        if (cw_occurred_as(fc, EV_LEF_BAR) && c.iv->bar_dir[cw_index(fc)] == DIR_FWD)
+          ws.stall[ws.f_id[k]] += 1;
+      }
+    }
+  }
+  wave::sync_mem();
   for (u32 base = 0; base < n; base += 64) {
     const u32 i = base + lane;
     const bool act = i < n;
     const bool bnd = act && ws.epoch[i] != UNBOUND;
     f64 prob = 0.0;
-    if (bnd) {
-      const u32 rc = ws.rev_coll[i], fc = ws.fwd_coll[i];
-      u32 hard = 0;
-      if (cw_occurred_as(rc, EV_LEF_BAR)) hard += c.iv->bar_dir[cw_index(rc)] == DIR_REV;
-      if (cw_occurred_as(fc, EV_LEF_BAR)) hard += c.iv->bar_dir[cw_index(fc)] == DIR_FWD;
+    if (act) {
+      const u32 hard = ws.stall[i];
+      ws.stall[i] = 0;
       const f64 affinity =
           hard == 0 ? 1.0 : (hard == 1 ? 1.0 / p.soft_stall_mult : 1.0 / p.hard_stall_mult);
       prob = affinity * base_p;
@@ -1497,15 +1198,10 @@ MODLE_DEV void phase_extrude_and_release(Cell& c, bool burnin_completed) {
     const u32 k = static_cast<u32>(wave::popc64(dm & lanemask_lt(lane)));
     const bool rel = draws && bernoulli_raw(rng_peek(c.g, c.g.pos + k), prob);
     c.g.pos += cnt;
-    if (bnd) {
-      if (rel) {
-        ws.rev_pos[i] = UNBOUND;
-        ws.fwd_pos[i] = UNBOUND;
-        ws.epoch[i] = UNBOUND;
-      } else {
-        ws.rev_pos[i] -= ws.rev_moves[i];
-        ws.fwd_pos[i] += ws.fwd_moves[i];
-      }
+    if (rel) {
+      ws.epoch[i] = UNBOUND;
+      ws.r_pos[ws.r_rank[i]] = UNBOUND;
+      ws.f_pos[ws.f_rank[i]] = UNBOUND;
     }
   }
   wave::sync_mem();
@@ -1540,28 +1236,28 @@ struct EventEval {
   u64 a, b;         // the two genomic coordinates to register
 };
 
-// lef_within_bound / randomize_extrusion_unit_positions / pos_within_bound
-// (reference: register_contacts.cpp:23-63)
-MODLE_DEV bool sample_lef_pair(const Cell& c, u32 i, f64 u1, f64 u2, bool noisify, f64& p1,
-                               f64& p2) {
+// lef_within_bound (reference: register_contacts.cpp:23-29); returns the unit positions
+MODLE_DEV bool lef_samplable(const Cell& c, u32 i, u32& rev, u32& fwd) {
   const Workspace& ws = c.ws;
+  const u32 lo = c.iv->start + 1, hi = c.iv->end - 1;
+  if (ws.epoch[i] == UNBOUND) return false;
+  rev = ws.r_pos[ws.r_rank[i]];
+  fwd = ws.f_pos[ws.f_rank[i]];
+  return rev > lo && rev < hi && fwd > lo && fwd < hi;
+}
+
+// randomize_extrusion_unit_positions / pos_within_bound (reference: register_contacts.cpp:31-63)
+MODLE_DEV bool sample_lef_pair(const Cell& c, u32 rev, u32 fwd, f64 u1, f64 u2, bool noisify,
+                               f64& p1, f64& p2) {
   const Params& p = *c.p;
   const f64 n1 = noisify ? genextreme_from_canonical(u1, p.gev_mu, p.gev_sigma, p.gev_xi) : 0.0;
-  const f64 a = static_cast<f64>(ws.rev_pos[i]) - n1;
+  const f64 a = static_cast<f64>(rev) - n1;
   const f64 n2 = noisify ? genextreme_from_canonical(u2, p.gev_mu, p.gev_sigma, p.gev_xi) : 0.0;
-  const f64 b = static_cast<f64>(ws.fwd_pos[i]) + n2;
+  const f64 b = static_cast<f64>(fwd) + n2;
   p1 = b < a ? b : a;
   p2 = b < a ? a : b;
   const f64 lo = static_cast<f64>(c.iv->start + 1), hi = static_cast<f64>(c.iv->end - 1);
   return p1 >= lo && p2 >= lo && p1 < hi && p2 < hi;
-}
-
-MODLE_DEV bool lef_samplable(const Cell& c, u32 i) {
-  const Workspace& ws = c.ws;
-  const u32 lo = c.iv->start + 1, hi = c.iv->end - 1;
-  if (ws.epoch[i] == UNBOUND) return false;
-  const u32 r = ws.rev_pos[i], f = ws.fwd_pos[i];
-  return r > lo && r < hi && f > lo && f < hi;
 }
 
 template <int KIND>
@@ -1573,13 +1269,13 @@ MODLE_DEV EventEval eval_event_fast(const Cell& c, u64 q, u64 lef_range, u64 lef
     e.need_exact = true;
     return e;
   }
-  const u32 i = static_cast<u32>(r);
-  if (!lef_samplable(c, i)) return e;  // consumed = 1
+  u32 rev = 0, fwd = 0;
+  if (!lef_samplable(c, static_cast<u32>(r), rev, fwd)) return e;  // consumed = 1
   const u32 nz = noisify ? 2u : 0u;
   const f64 u1 = noisify ? canonical_raw(rng_peek(c.g, q + 1)) : 0.0;
   const f64 u2 = noisify ? canonical_raw(rng_peek(c.g, q + 2)) : 0.0;
   f64 p1, p2;
-  const bool inb = sample_lef_pair(c, i, u1, u2, noisify, p1, p2);
+  const bool inb = sample_lef_pair(c, rev, fwd, u1, u2, noisify, p1, p2);
   e.consumed = 1 + nz;
   if (!inb) return e;
   const u64 a = static_cast<u64>(p1), b = static_cast<u64>(p2);
@@ -1612,15 +1308,15 @@ MODLE_DEV EventEval eval_event_fast(const Cell& c, u64 q, u64 lef_range, u64 lef
 
 // one sampling event replayed sequentially from g.pos; uniform
 template <int KIND>
-MODLE_DEV EventEval eval_event_exact(Cell& c, u64 lef_range, u64 lef_bucket, bool noisify) {
+MODLE_DEV_NOINLINE EventEval eval_event_exact(Cell& c, u64 lef_range, u64 lef_bucket, bool noisify) {
   EventEval e{0, false, false, 0, 0};
   const u64 r = lef_range == 0 ? 0 : uniform_int_exact(c.g, lef_range, lef_bucket);
-  const u32 i = static_cast<u32>(r);
-  if (!lef_samplable(c, i)) return e;
+  u32 rev = 0, fwd = 0;
+  if (!lef_samplable(c, static_cast<u32>(r), rev, fwd)) return e;
   const f64 u1 = noisify ? canonical_raw(rng_next(c.g)) : 0.0;
   const f64 u2 = noisify ? canonical_raw(rng_next(c.g)) : 0.0;
   f64 p1, p2;
-  if (!sample_lef_pair(c, i, u1, u2, noisify, p1, p2)) return e;
+  if (!sample_lef_pair(c, rev, fwd, u1, u2, noisify, p1, p2)) return e;
   const u64 a = static_cast<u64>(p1), b = static_cast<u64>(p2);
   e.ok = true;
   if (KIND != EV_TAD) {
@@ -1658,7 +1354,7 @@ MODLE_DEV void commit_event(const Cell& c, const EventEval& e) {
 
 // runs `n_events` sampling events of one kind; returns the number of registrations
 template <int KIND>
-MODLE_DEV u64 run_events(Cell& c, u64 n_events) {
+MODLE_DEV_NOINLINE u64 run_events(Cell& c, u64 n_events) {
   if (n_events == 0) return 0;
   const u32 lane = wave::lane();
   const bool noisify = (c.p->sampling_strategy & CS_NOISIFY) != 0;
@@ -1737,18 +1433,24 @@ MODLE_DEV u64 phase_sample_contacts(Cell& c, u64 events_per_epoch, u64 num_targe
 // =============================================================================================
 // Burn-in (reference: simulation.cpp:795-894)
 // =============================================================================================
-MODLE_DEV void compute_loop_size_stats(Cell& c) {
+MODLE_DEV_NOINLINE void compute_loop_size_stats(Cell& c) {
   // reference: simulation.cpp:795-819 and stats/descriptive_impl.hpp:22-31, 63-101.  The mean is
   // a sum of integers below 2^53 (order independent); the squared deviations are accumulated
-  // strictly left to right like std::accumulate.
+  // strictly left to right in LEF-id order like std::accumulate.
   Workspace& ws = c.ws;
-  const u32 n = c.n_active;
+  const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
   const u32 cap = c.p->hist_len;
+  u32* loop_size = ws.tmp[0];
   u64 part = 0;
   for (u32 base = 0; base < n; base += 64) {
     const u32 i = base + lane;
-    if (i < n) part += static_cast<u64>(ws.fwd_pos[i] - ws.rev_pos[i]);
+    if (i < n) {
+      // released LEFs have both units at UNBOUND: loop size 0, like the reference
+      const u32 ls = ws.f_pos[ws.f_rank[i]] - ws.r_pos[ws.r_rank[i]];
+      loop_size[i] = ls;
+      part += ls;
+    }
   }
 #pragma unroll
   for (u32 s = 1; s < 64; s <<= 1) {
@@ -1757,17 +1459,19 @@ MODLE_DEV void compute_loop_size_stats(Cell& c) {
   }
   const u64 total = wave::bcast(part, 0);
   const f64 avg = static_cast<f64>(total) / static_cast<f64>(n);
-  f64* terms = reinterpret_cast<f64*>(ws.sort_keys);
+  // strictly sequential accumulation: every lane computes its term, the terms of a batch are
+  // then folded in lane order through broadcasts (no memory round trip)
+  f64 ssd = 0.0;
   for (u32 base = 0; base < n; base += 64) {
     const u32 i = base + lane;
+    f64 term = 0.0;
     if (i < n) {
-      const f64 d = static_cast<f64>(static_cast<u64>(ws.fwd_pos[i] - ws.rev_pos[i])) - avg;
-      terms[i] = d * d;
+      const f64 d = static_cast<f64>(static_cast<u64>(loop_size[i])) - avg;
+      term = d * d;
     }
+    const u32 cnt = umin(64u, n - base);
+    for (u32 l = 0; l < cnt; ++l) ssd = ssd + wave::bcast(term, l);
   }
-  wave::sync_mem();
-  f64 ssd = 0.0;
-  for (u32 i = 0; i < n; ++i) ssd = ssd + terms[i];
   const f64 std = wave::f_sqrt(ssd / static_cast<f64>(n));
   // push_back with pop_front at capacity (two deque<double>)
   f64* cfx = ws.hist;
@@ -1808,7 +1512,7 @@ MODLE_DEV bool series_is_stable(const Cell& c, const f64* buf) {
   return r >= 0.95 && r <= 1.05;
 }
 
-MODLE_DEV bool evaluate_burnin(const Cell& c) {
+MODLE_DEV_NOINLINE bool evaluate_burnin(const Cell& c) {
   // reference: simulation.cpp:821-864
   const u32 cap = c.p->hist_len;
   if (c.hist_len != cap) return false;
@@ -1819,52 +1523,109 @@ MODLE_DEV bool evaluate_burnin(const Cell& c) {
 // =============================================================================================
 // Cell driver (reference: simulation.cpp:896-986)
 // =============================================================================================
-MODLE_DEV void reset_cell_buffers(Cell& c) {
+MODLE_DEV_NOINLINE void reset_cell_buffers(Cell& c) {
   // State::reset_buffers (reference: simulation.cpp:617-627)
   Workspace& ws = c.ws;
-  const u32 L = c.n_lefs;
+  const u32 L = wave::uniform(c.n_lefs);
   const u32 lane = wave::lane();
   for (u32 base = 0; base < L; base += 64) {
     const u32 i = base + lane;
     if (i < L) {
-      ws.rev_pos[i] = UNBOUND;
-      ws.fwd_pos[i] = UNBOUND;
+      ws.r_pos[i] = UNBOUND;
+      ws.f_pos[i] = UNBOUND;
       ws.epoch[i] = UNBOUND;
-      ws.rev_rank[i] = i;
-      ws.fwd_rank[i] = i;
-      ws.rev_moves[i] = 0;
-      ws.fwd_moves[i] = 0;
-      ws.rev_coll[i] = 0;
-      ws.fwd_coll[i] = 0;
+      ws.r_id[i] = i;
+      ws.f_id[i] = i;
+      ws.r_rank[i] = i;
+      ws.f_rank[i] = i;
+      ws.r_move[i] = 0;
+      ws.f_move[i] = 0;
+      ws.r_coll[i] = 0;
+      ws.f_coll[i] = 0;
+      ws.stall[i] = 0;
     }
   }
   wave::sync_mem();
 }
 
-// Simulates one (interval, cell) task on the calling wave.  Returns 0 or a non-zero status when
-// an internal capacity was exceeded (the host turns that into an error).
-MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& task,
-                            const Workspace& ws, const WaveLds& lds, CellResult& res,
-                            u32 debug_stage = 0) {
-#define MODLE_STAGE(k) \
-  if (debug_stage == (k)) { res.epochs = (k); return 0; }
-  Cell c;
+// LEFs n_old .. n_new-1 become active.  They have never been ranked: their slots are the
+// identity (the reference's iota-initialised rank buffers, simulation.cpp:617-620); the id
+// arrays are re-initialised here because they are double-buffered by rank_update.
+MODLE_DEV void activate_lefs(Cell& c, u32 n_old, u32 n_new) {
+  const u32 lane = wave::lane();
+  for (u32 base = n_old; base < n_new; base += 64) {
+    const u32 k = base + lane;
+    if (k < n_new) {
+      c.ws.r_id[k] = k;
+      c.ws.f_id[k] = k;
+    }
+  }
+  c.n_active = n_new;
+  wave::sync_mem();
+}
+
+MODLE_DEV void init_cell(Cell& c, const Params& p, const Interval& iv, const Workspace& ws,
+                         const WaveLds& lds, u32 n_lefs, const u64 prng[4]) {
   c.p = &p;
   c.iv = &iv;
   c.ws = ws;
   c.lds = lds;
-  c.n_lefs = task.num_lefs;
+  c.n_lefs = n_lefs;
   c.n_active = 0;
   c.hist_len = 0;
   c.hist_head = 0;
   c.error = 0;
   c.g.ring = lds.ring;
   c.g.jump = lds.jump_table;
-  MODLE_STAGE(1)
-  rng_init(c.g, task.prng);
-  MODLE_STAGE(2)
+  rng_init(c.g, prng);
+}
+
+// Diagnostic trace (enabled by the host with MODLE_HIP_TRACE_SHM): after selected phases of every
+// epoch, order-sensitive checksums of the unit arrays and the PRNG position are stored, so that
+// a run on the GPU can be compared phase by phase with a run under the CPU lane emulator.
+constexpr u32 TRACE_STAGES = 8;
+constexpr u32 TRACE_WORDS_PER_STAGE = 6;
+MODLE_DEV_NOINLINE void trace_stage(Cell& c, u64 epoch, u32 stage) {
+  u64* tr = c.lds.trace;
+  if (tr == nullptr || epoch >= c.lds.trace_cap) return;
+  const u32 lane = wave::lane();
+  u64 s[4] = {0, 0, 0, 0};
+  for (u32 base = 0; base < c.n_active; base += 64) {
+    const u32 k = base + lane;
+    if (k < c.n_active) {
+      const u64 w = k + 1;
+      s[0] += w * c.ws.r_pos[k] + c.ws.r_id[k];
+      s[1] += w * c.ws.f_pos[k] + c.ws.f_id[k];
+      s[2] += w * c.ws.r_move[k];
+      s[3] += w * c.ws.f_move[k];
+    }
+  }
+#pragma unroll
+  for (u32 q = 0; q < 4; ++q) {
+#pragma unroll
+    for (u32 d = 1; d < 64; d <<= 1) {
+      const u64 o = wave::shfl_down(s[q], d);
+      if (lane + d < 64) s[q] += o;
+    }
+  }
+  if (lane == 0) {
+    u64* rec = tr + (epoch * TRACE_STAGES + stage) * TRACE_WORDS_PER_STAGE;
+    rec[0] = c.g.pos;
+    rec[1] = s[0];
+    rec[2] = s[1];
+    rec[3] = s[2];
+    rec[4] = s[3];
+    rec[5] = (static_cast<u64>(c.n_active) << 32) | (stage + 1);
+  }
+}
+
+// Simulates one (interval, cell) task on the calling wave.  Returns 0 or a non-zero status when
+// an internal capacity was exceeded (the host turns that into an error).
+MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& task,
+                            const Workspace& ws, const WaveLds& lds, CellResult& res) {
+  Cell c;
+  init_cell(c, p, iv, ws, lds, task.num_lefs, task.prng);
   reset_cell_buffers(c);
-  MODLE_STAGE(3)
 
   u64 epoch = 0, num_burnin_epochs = 0, num_contacts = 0;
   u64 sum_active = 0, events_done = 0, sim_epochs = 0;
@@ -1874,12 +1635,10 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
       static_cast<f64>(task.num_lefs) / static_cast<f64>(p.burnin_target_epochs_for_lef_activation);
 
   barriers_init_states(c);
-  MODLE_STAGE(4)
   if (p.skip_burnin) {
-    c.n_active = c.n_lefs;
+    activate_lefs(c, 0, c.n_lefs);
     burnin_completed = true;
   }
-  bool first_ranking = true;
   for (;; ++epoch) {
     if (p.target_contact_density >= 0) {
       if (num_contacts >= task.num_target_contacts) break;
@@ -1893,69 +1652,55 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
         if (c.n_active != c.n_lefs) {
           const u64 k = poisson_exact(c.g, lef_binding_rate_burnin);
           const u64 na = static_cast<u64>(c.n_active) + k;
-          c.n_active = na < c.n_lefs ? static_cast<u32>(na) : c.n_lefs;
+          activate_lefs(c, c.n_active, na < c.n_lefs ? static_cast<u32>(na) : c.n_lefs);
         } else {
           compute_loop_size_stats(c);
           burnin_completed = evaluate_burnin(c);
           burnin_completed = burnin_completed && epoch > p.min_burnin_epochs;
           if (!burnin_completed && epoch >= p.max_burnin_epochs) {
             burnin_completed = true;
-            c.n_active = c.n_lefs;
+            activate_lefs(c, c.n_active, c.n_lefs);
           }
         }
       } while (c.n_active == 0);
     }
-
-    MODLE_STAGE(5)
-    if (debug_stage >= 100 && epoch == debug_stage - 100) {
-      res.epochs = epoch;
-      res.burnin_epochs = burnin_completed ? 1 : 0;
-      res.num_contacts = c.n_active;
-      return 0;
+    phase_bind(c, static_cast<u32>(epoch));
+    trace_stage(c, epoch, 0);
+    rank_update<false>(c, false);
+    rank_update<true>(c, false);
+    trace_stage(c, epoch, 1);
+    if (c.error != 0) {
+      status = c.error;
+      break;
     }
-    const u32 epoch32 = static_cast<u32>(epoch);
-    phase_bind(c, epoch32);
-    MODLE_STAGE(6)
-    rank_update<false>(c, epoch32, first_ranking);
-    rank_update<true>(c, epoch32, first_ranking);
-    first_ranking = false;
-    MODLE_STAGE(7)
 
     if (burnin_completed) {
       num_contacts += phase_sample_contacts(c, task.contacts_per_epoch, task.num_target_contacts,
                                             num_contacts, events_done);
+      trace_stage(c, epoch, 5);
       if (task.num_target_contacts != 0 && num_contacts >= task.num_target_contacts) break;
     }
 
     sum_active += c.n_active;
     ++sim_epochs;
     phase_generate_moves(c, burnin_completed);
-    MODLE_STAGE(8)
+    trace_stage(c, epoch, 2);
     barriers_next_state(c);
     clear_collisions(c);
-    MODLE_STAGE(9)
-    if (!phase_process_collisions(c)) {
+    const bool coll_ok = phase_process_collisions(c);
+    trace_stage(c, epoch, 3);
+    if (!coll_ok) {
       status = c.error;
       break;
     }
-#ifdef MODLE_TRACE
-    if (wave::lane() == 0 && getenv("MO_TRACE") && getenv("MO_TRACE_EPOCH") &&
-        (u64)atoll(getenv("MO_TRACE_EPOCH")) == epoch) {
-      for (u32 i = 0; i < c.n_active; ++i)
-        fprintf(stderr, "D %u %u %u %u %u %u:%u %u:%u\n", i, c.ws.rev_pos[i], c.ws.fwd_pos[i],
-                c.ws.rev_moves[i], c.ws.fwd_moves[i], c.ws.rev_coll[i] >> 24,
-                c.ws.rev_coll[i] & 0xFFFFFF, c.ws.fwd_coll[i] >> 24, c.ws.fwd_coll[i] & 0xFFFFFF);
-    }
-#endif
-    MODLE_STAGE(10)
     phase_extrude_and_release(c, burnin_completed);
-    MODLE_STAGE(11)
+    trace_stage(c, epoch, 4);
 #ifdef MODLE_TRACE
     {
       u64 sr = 0, sf = 0;
       for (u32 i = 0; i < c.n_active; ++i) {
-        sr += c.ws.rev_pos[i];
-        sf += c.ws.fwd_pos[i];
+        sr += c.ws.r_pos[i];
+        sf += c.ws.f_pos[i];
       }
       if (wave::lane() == 0 && getenv("MO_TRACE"))
         fprintf(stderr, "T %llu %llu %llu %llu %u %llu\n", (unsigned long long)epoch,
@@ -1965,6 +1710,7 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
 #endif
   }
 
+  trace_stage(c, epoch, 6);
   res.epochs = epoch;
   res.burnin_epochs = num_burnin_epochs;
   res.num_contacts = num_contacts;
@@ -1978,26 +1724,35 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
 
 // =============================================================================================
 // Phase-level entry point (mirrors Simulation::test_* hooks, reference: simulation.hpp:413-567)
+//
+// The caller's arrays use the reference's layout: positions / binding epochs / moves / collision
+// words indexed by LEF id plus two rank arrays (LEF id at every rank).  They arrive in scratch
+// arrays (`TestImage`), are converted to the rank-ordered device layout, the requested passes
+// run, and the result is converted back.
 // =============================================================================================
 constexpr u32 PH_RANK = 0x001, PH_RANK_INIT = 0x002, PH_ADJUST = 0x004, PH_CLAMP = 0x008,
               PH_BOUNDARIES = 0x010, PH_LEF_BAR = 0x020, PH_PRIMARY = 0x040,
               PH_CORRECT_LEF_BAR = 0x080, PH_CORRECT_PRIMARY = 0x100, PH_SECONDARY = 0x200,
               PH_FIX_SECONDARY = 0x400, PH_USE_BOUNDARY_COUNTS = 0x800;
 
+struct TestImage {  // all by LEF id except the two rank arrays; n entries each
+  u32 *rev_pos, *fwd_pos, *epoch, *rev_rank, *fwd_rank, *rev_moves, *fwd_moves, *rev_coll,
+      *fwd_coll;
+};
+
 // rank positions whose unit carries an "avoided secondary collision" mark, in the order
 // process_secondary would have produced them
 template <bool FWD>
 MODLE_DEV u32 collect_avoided(Cell& c, u32* list, u32 cap) {
-  const u32 n = c.n_active;
+  const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
-  const u32* rank = FWD ? c.ws.fwd_rank : c.ws.rev_rank;
-  const u32* coll = FWD ? c.ws.fwd_coll : c.ws.rev_coll;
+  const u32* coll = FWD ? c.ws.f_coll : c.ws.r_coll;
   u32 cnt = 0;
   for (u32 base = 0; base < n; base += 64) {
     const u32 off = base + lane;
     const bool act = off < n;
     const u32 k = FWD ? (n - 1 - off) : off;
-    const bool hit = act && cw_avoided_as(coll[rank[act ? k : 0]], EV_LEF_LEF_SECONDARY) &&
+    const bool hit = act && cw_avoided_as(coll[act ? k : 0], EV_LEF_LEF_SECONDARY) &&
                      (FWD ? k + 1 < n : k >= 1);
     const u64 m = wave::ballot(hit);
     if (hit) {
@@ -2011,61 +1766,42 @@ MODLE_DEV u32 collect_avoided(Cell& c, u32* list, u32 cap) {
 }
 
 MODLE_DEV u32 run_test_phases(const Params& p, const Interval& iv, const Workspace& ws,
-                              const WaveLds& lds, u32 mask, u32 n, const u64 prng[4],
-                              u64& raws_consumed) {
+                              const WaveLds& lds, const TestImage& img, u32 mask, u32 n,
+                              const u64 prng[4], u64& raws_consumed) {
   Cell c;
-  c.p = &p;
-  c.iv = &iv;
-  c.ws = ws;
-  c.lds = lds;
-  c.n_lefs = n;
+  init_cell(c, p, iv, ws, lds, n, prng);
   c.n_active = n;
-  c.hist_len = 0;
-  c.hist_head = 0;
-  c.error = 0;
-  c.g.ring = lds.ring;
-  c.g.jump = lds.jump_table;
-  rng_init(c.g, prng);
   const u32 lane = wave::lane();
-  if (mask & PH_RANK) {
-    if (mask & PH_RANK_INIT) {
-      for (u32 base = 0; base < n; base += 64) {
-        const u32 i = base + lane;
-        if (i < n) {
-          c.ws.rev_rank[i] = i;
-          c.ws.fwd_rank[i] = i;
-        }
-      }
-      wave::sync_mem();
+  // reference layout -> device layout
+  for (u32 base = 0; base < n; base += 64) {
+    const u32 k = base + lane;
+    if (k < n) {
+      const bool init = (mask & PH_RANK) && (mask & PH_RANK_INIT);
+      const u32 rid = init ? k : img.rev_rank[k];
+      const u32 fid = init ? k : img.fwd_rank[k];
+      c.ws.r_id[k] = rid;
+      c.ws.r_pos[k] = img.rev_pos[rid];
+      c.ws.r_move[k] = img.rev_moves[rid];
+      c.ws.r_coll[k] = img.rev_coll[rid];
+      c.ws.r_rank[rid] = k;
+      c.ws.f_id[k] = fid;
+      c.ws.f_pos[k] = img.fwd_pos[fid];
+      c.ws.f_move[k] = img.fwd_moves[fid];
+      c.ws.f_coll[k] = img.fwd_coll[fid];
+      c.ws.f_rank[fid] = k;
+      c.ws.epoch[k] = img.epoch[k];
+      c.ws.stall[k] = 0;
     }
-    rank_update<false>(c, 0, true);
-    rank_update<true>(c, 0, true);
   }
-  if (mask & PH_ADJUST) {
-    adjust_moves_rev(c, c.ws.rev_moves, c.ws.tmp_a);
-    adjust_moves_fwd(c, c.ws.fwd_moves, c.ws.tmp_b);
-    if (mask & PH_CLAMP) {
-      clamp_moves(c, c.ws.tmp_a, c.ws.tmp_b);
-    } else {
-      for (u32 base = 0; base < n; base += 64) {
-        const u32 i = base + lane;
-        if (i < n) {
-          c.ws.rev_moves[i] = c.ws.tmp_a[i];
-          c.ws.fwd_moves[i] = c.ws.tmp_b[i];
-        }
-      }
-      wave::sync_mem();
-    }
-  } else if (mask & PH_CLAMP) {
-    for (u32 base = 0; base < n; base += 64) {
-      const u32 i = base + lane;
-      if (i < n) {
-        c.ws.tmp_a[i] = c.ws.rev_moves[i];
-        c.ws.tmp_b[i] = c.ws.fwd_moves[i];
-      }
-    }
-    wave::sync_mem();
-    clamp_moves(c, c.ws.tmp_a, c.ws.tmp_b);
+  wave::sync_mem();
+  if (mask & PH_RANK) {
+    // positions only: move / collision arrays are not meaningful across a re-ranking
+    rank_update<false>(c, true);
+    rank_update<true>(c, true);
+  }
+  if (mask & (PH_ADJUST | PH_CLAMP)) {
+    adjust_moves_rev(c, (mask & PH_ADJUST) != 0, (mask & PH_CLAMP) != 0);
+    adjust_moves_fwd(c, (mask & PH_ADJUST) != 0, (mask & PH_CLAMP) != 0);
   }
   BoundaryCounts bc{0, 0};
   if (mask & PH_BOUNDARIES) {
@@ -2076,28 +1812,52 @@ MODLE_DEV u32 run_test_phases(const Params& p, const Interval& iv, const Workspa
     detect_lef_bar<false>(c, bc);
     detect_lef_bar<true>(c, bc);
   }
-  if (mask & PH_PRIMARY) {
-    build_sorted_positions(c, c.ws.fwd_rank, c.ws.fwd_pos, c.ws.tmp_c);
-    detect_primary(c, bc, c.ws.tmp_c);
-  }
-  if (mask & PH_CORRECT_LEF_BAR) correct_moves_lef_bar(c);
-  if (mask & PH_CORRECT_PRIMARY) correct_moves_primary(c);
-  u32* list_rev = c.lds.list;
-  u32* list_fwd = c.lds.list + LIST_CAP / 2;
+  // the reference's hook sequences run "correct LEF-BAR moves" before "correct primary moves";
+  // with both requested the fused forms are equivalent, otherwise run them stand-alone
+  const bool fuse = (mask & PH_CORRECT_PRIMARY) && (mask & PH_CORRECT_LEF_BAR) && (mask & PH_PRIMARY);
+  if (mask & PH_PRIMARY) detect_primary(c, bc, fuse);
+  u32* list_rev = c.ws.tmp[5];
+  u32* list_fwd = c.ws.tmp[6];
+  const u32 cap = c.ws.capacity_lefs;
   u32 nr = 0, nf = 0;
   bool overflow = false;
+  if (!fuse && (mask & PH_CORRECT_LEF_BAR)) {
+    (void)process_secondary<false>(c, bc, list_rev, cap, overflow, true, false);
+    (void)process_secondary<true>(c, bc, list_fwd, cap, overflow, true, false);
+  }
+  if (!fuse && (mask & PH_CORRECT_PRIMARY)) correct_moves_primary_standalone(c);
   if (mask & PH_SECONDARY) {
-    nr = process_secondary<false>(c, bc, list_rev, LIST_CAP / 2, overflow);
-    nf = process_secondary<true>(c, bc, list_fwd, LIST_CAP / 2, overflow);
+    nr = process_secondary<false>(c, bc, list_rev, cap, overflow, fuse, true);
+    nf = process_secondary<true>(c, bc, list_fwd, cap, overflow, fuse, true);
+  } else if (fuse) {
+    (void)process_secondary<false>(c, bc, list_rev, cap, overflow, true, false);
+    (void)process_secondary<true>(c, bc, list_fwd, cap, overflow, true, false);
   }
   if (mask & PH_FIX_SECONDARY) {
     if (!(mask & PH_SECONDARY)) {
-      nr = collect_avoided<false>(c, list_rev, LIST_CAP / 2);
-      nf = collect_avoided<true>(c, list_fwd, LIST_CAP / 2);
+      nr = collect_avoided<false>(c, list_rev, cap);
+      nf = collect_avoided<true>(c, list_fwd, cap);
     }
     if (nr != 0) fix_secondary_rev(c, list_rev, nr);
     if (nf != 0) fix_secondary_fwd(c, list_fwd, nf);
   }
+  // device layout -> reference layout
+  wave::sync_mem();
+  for (u32 base = 0; base < n; base += 64) {
+    const u32 k = base + lane;
+    if (k < n) {
+      const u32 rid = c.ws.r_id[k], fid = c.ws.f_id[k];
+      img.rev_rank[k] = rid;
+      img.fwd_rank[k] = fid;
+      img.rev_pos[rid] = c.ws.r_pos[k];
+      img.rev_moves[rid] = c.ws.r_move[k];
+      img.rev_coll[rid] = c.ws.r_coll[k];
+      img.fwd_pos[fid] = c.ws.f_pos[k];
+      img.fwd_moves[fid] = c.ws.f_move[k];
+      img.fwd_coll[fid] = c.ws.f_coll[k];
+    }
+  }
+  wave::sync_mem();
   raws_consumed = c.g.pos;
   return overflow ? ERR_LIST_OVERFLOW : c.error;
 }

@@ -1,0 +1,402 @@
+// sim_rng.h -- PRNG block generator and distributions of the device code (first half of the
+// per-cell simulation; sim_device.h holds the epoch loop).
+//
+// One wavefront simulates one cell: the per-epoch loop of
+// Simulation::simulate_one_cell (reference: src/libmodle/cpu/simulation.cpp:896-986) written for
+// a 64-lane wave.  Included after a `wave` backend (wave_hip.h on the GPU).
+//
+// Conventions
+//   * "uniform" values are identical in all 64 lanes; every collective (ballot / shuffle / sync)
+//     is issued from wave-uniform control flow.
+//   * Per-cell state lives in the wave's Workspace (device memory), indexed by LEF id with two
+//     rank arrays giving the 5'->3' order of rev / fwd units, like the reference's State buffers
+//     (reference: src/libmodle/cpu/include/modle/simulation.hpp:86-94) but with 32-bit fields.
+//   * The cell's single xoshiro256++ stream is produced in blocks of RNG_BLOCK raw outputs by
+//     all 64 lanes (lane l owns RNG_CHUNK consecutive outputs of every block and hops to its
+//     chunk of the next block with a GF(2) jump table) and consumed strictly in the reference's
+//     order; draws whose raw-output count is data dependent are resolved with a
+//     speculate / verify / restart scheme so the stream position of every draw is exact.
+#pragma once
+#include "sim_types.h"
+
+namespace modle_dev {
+
+// =============================================================================================
+// small helpers
+// =============================================================================================
+MODLE_DEV u64 lanemask_lt(u32 lane) { return (u64(1) << lane) - 1; }
+MODLE_DEV u32 cw_make(u32 idx, u32 ev) { return (idx & CW_INDEX_MASK) | (ev << CW_SHIFT); }
+MODLE_DEV u32 cw_event(u32 c) { return c >> CW_SHIFT; }
+MODLE_DEV u32 cw_index(u32 c) { return c & CW_INDEX_MASK; }
+MODLE_DEV bool cw_occurred(u32 c) { return (cw_event(c) & EV_COLLISION) != 0; }
+MODLE_DEV bool cw_occurred_as(u32 c, u32 what) { return cw_event(c) == (what | EV_COLLISION); }
+MODLE_DEV bool cw_avoided_as(u32 c, u32 what) { return !cw_occurred(c) && cw_event(c) == what; }
+MODLE_DEV u32 umin(u32 a, u32 b) { return a < b ? a : b; }
+MODLE_DEV u32 umax(u32 a, u32 b) { return a > b ? a : b; }
+MODLE_DEV u64 umin64(u64 a, u64 b) { return a < b ? a : b; }
+MODLE_DEV i64 imin64(i64 a, i64 b) { return a < b ? a : b; }
+MODLE_DEV i64 imax64(i64 a, i64 b) { return a > b ? a : b; }
+
+constexpr f64 TWO64 = 18446744073709551616.0;
+constexpr f64 TWO_M64 = 5.42101086242752217e-20;
+constexpr f64 TWO_M56 = 1.387778780781445675529539585113525390625e-17;
+constexpr f64 DBL_EPS = 2.220446049250313e-16;
+
+// =============================================================================================
+// PRNG: xoshiro256++ block generator (reference stream: random.hpp:26-32)
+// =============================================================================================
+struct Rng {
+  u64 s0, s1, s2, s3;  // per lane: state at the start of this lane's chunk of the NEXT block
+  u64* ring;           // RNG_RING raws (LDS)
+  const u64* jump;     // T^RNG_BLOCK nibble table (LDS)
+  u64 gen_end;         // uniform: raws [gen_end - RNG_RING, gen_end) are in the ring
+  u64 pos;             // uniform: stream position of the next raw to be consumed
+};
+
+MODLE_DEV u64 rotl64(u64 x, int k) { return (x << k) | (x >> (64 - k)); }
+
+MODLE_DEV u64 xo_next(u64& s0, u64& s1, u64& s2, u64& s3) {
+  const u64 result = rotl64(s0 + s3, 23) + s0;
+  const u64 t = s1 << 17;
+  s2 ^= s0;
+  s3 ^= s1;
+  s1 ^= s2;
+  s0 ^= s3;
+  s2 ^= t;
+  s3 = rotl64(s3, 45);
+  return result;
+}
+
+MODLE_DEV u32 ring_index(u64 p) {
+  const u32 off = static_cast<u32>(p) & (RNG_BLOCK - 1);
+  const u32 blk = (static_cast<u32>(p) / RNG_BLOCK) & 1u;
+  // chunk-local XOR swizzle: lanes writing element t of their chunks hit distinct LDS banks
+  return blk * RNG_BLOCK + (off ^ ((off / RNG_CHUNK) & (RNG_CHUNK - 1)));
+}
+
+MODLE_DEV void rng_jump(Rng& g) {
+  u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  const u64 w[4] = {g.s0, g.s1, g.s2, g.s3};
+#pragma unroll
+  for (int wi = 0; wi < 4; ++wi) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const u32 v = static_cast<u32>(w[wi] >> (4 * k)) & 15u;
+      const u64* row = g.jump + ((wi * 16 + k) * 16 + v) * 4;
+      a0 ^= row[0];
+      a1 ^= row[1];
+      a2 ^= row[2];
+      a3 ^= row[3];
+    }
+  }
+  g.s0 = a0;
+  g.s1 = a1;
+  g.s2 = a2;
+  g.s3 = a3;
+}
+
+MODLE_DEV_NOINLINE void rng_gen_block(Rng& g) {
+  wave::lockstep();  // other lanes may still be reading the block that is about to be replaced
+  const u32 lane = wave::lane();
+  u64 a0 = g.s0, a1 = g.s1, a2 = g.s2, a3 = g.s3;
+  const u32 base = ((static_cast<u32>(g.gen_end) / RNG_BLOCK) & 1u) * RNG_BLOCK + RNG_CHUNK * lane;
+#pragma unroll
+  for (u32 t = 0; t < RNG_CHUNK; ++t) {
+    g.ring[base + (t ^ (lane & (RNG_CHUNK - 1)))] = xo_next(a0, a1, a2, a3);
+  }
+  rng_jump(g);
+  g.gen_end += RNG_BLOCK;
+  wave::sync_mem();
+}
+
+MODLE_DEV void rng_init(Rng& g, const u64 state[4]) {
+  const u32 lane = wave::lane();
+  g.s0 = state[0];
+  g.s1 = state[1];
+  g.s2 = state[2];
+  g.s3 = state[3];
+  // lane l starts RNG_CHUNK * l outputs into the stream
+  for (u32 k = 0; k < RNG_CHUNK * 63; ++k) {
+    if (k < RNG_CHUNK * lane) (void)xo_next(g.s0, g.s1, g.s2, g.s3);
+  }
+  g.gen_end = 0;
+  g.pos = 0;
+}
+
+// makes raws [pos, pos + k) readable (k <= RNG_BLOCK); uniform
+MODLE_DEV void rng_ensure(Rng& g, u32 k) {
+  while (g.gen_end < g.pos + k) rng_gen_block(g);
+}
+MODLE_DEV u64 rng_peek(const Rng& g, u64 p) { return g.ring[ring_index(p)]; }
+// uniform: next raw of the stream
+MODLE_DEV u64 rng_next(Rng& g) {
+  rng_ensure(g, 1);
+  return wave::uniform(rng_peek(g, g.pos++));
+}
+// =============================================================================================
+// Distributions (Boost.Random 1.88 semantics on a 64-bit engine; reference aliases:
+// src/common/include/modle/common/random.hpp:34-53).  "exact" routines are executed uniformly by
+// the whole wave and consume the stream sequentially; "fast" forms evaluate one speculative draw
+// per lane from a raw output that has already been fetched.
+// =============================================================================================
+MODLE_DEV bool bernoulli_raw(u64 raw, f64 p) { return static_cast<f64>(raw) <= p * TWO64; }
+MODLE_DEV f64 canonical_raw(u64 raw) {
+  f64 r = static_cast<f64>(raw) / TWO64;
+  if (r == 1.0) r -= DBL_EPS / 2;
+  return r;
+}
+MODLE_DEV f64 uniform01_exact(Rng& g) {
+  for (;;) {
+    const f64 r = static_cast<f64>(rng_next(g)) * TWO_M64;
+    if (r < 1.0) return r;
+  }
+}
+MODLE_DEV u64 uniform_int_bucket(u64 range) {
+  u64 bucket = ~u64(0) / (range + 1);
+  if (~u64(0) % (range + 1) == range) ++bucket;
+  return bucket;
+}
+// uniform_int_distribution<u64>{0, range}, range != 0 and != 2^64-1
+MODLE_DEV u64 uniform_int_exact(Rng& g, u64 range, u64 bucket) {
+  for (;;) {
+    const u64 r = rng_next(g) / bucket;
+    if (r <= range) return r;
+  }
+}
+
+MODLE_DEV f64 int_float_pair8(u64 raw, u32& bucket) {
+  bucket = static_cast<u32>(raw) & 0xFFu;
+  const u64 u = raw & ~((u64(1) << 11) - 1);
+  return static_cast<f64>(u >> 8) * TWO_M56;
+}
+
+MODLE_DEV f64 unit_exponential_exact(Rng& g, const WaveLds& lds) {
+  f64 shift = 0.0;
+  for (;;) {
+    u32 i;
+    const f64 u = int_float_pair8(rng_next(g), i);
+    const f64 x = u * lds.zig_exp_x[i];
+    if (x < lds.zig_exp_x[i + 1]) return shift + x;
+    if (i == 0) {
+      shift += lds.zig_exp_x[1];
+    } else {
+      const f64 y01 = uniform01_exact(g);
+      const f64 y = lds.zig_exp_y[i] + y01 * (lds.zig_exp_y[i + 1] - lds.zig_exp_y[i]);
+      const f64 y_above_ubound =
+          (lds.zig_exp_x[i] - lds.zig_exp_x[i + 1]) * y01 - (lds.zig_exp_x[i] - x);
+      const f64 y_above_lbound =
+          y - (lds.zig_exp_y[i + 1] + (lds.zig_exp_x[i + 1] - x) * lds.zig_exp_y[i + 1]);
+      if (y_above_ubound < 0 && (y_above_lbound < 0 || y < wave::f_exp(-x))) return x + shift;
+    }
+  }
+}
+
+// boost unit_normal_distribution; uniform, consumes from g.pos
+MODLE_DEV_NOINLINE f64 unit_normal_exact(Rng& g, const WaveLds& lds) {
+  for (;;) {
+    u32 b;
+    const f64 u = int_float_pair8(rng_next(g), b);
+    const f64 sign = (b & 1u) ? 1.0 : -1.0;
+    const u32 i = b >> 1;
+    const f64 x = u * lds.zig_norm_x[i];
+    if (x < lds.zig_norm_x[i + 1]) return x * sign;
+    if (i == 0) {
+      const f64 tail_start = lds.zig_norm_x[1];
+      for (;;) {
+        const f64 tx = unit_exponential_exact(g, lds) / tail_start;
+        const f64 ty = unit_exponential_exact(g, lds);
+        if (2 * ty > tx * tx) return (tx + tail_start) * sign;
+      }
+    }
+    const f64 y01 = uniform01_exact(g);
+    const f64 xi = lds.zig_norm_x[i], xi1 = lds.zig_norm_x[i + 1];
+    const f64 yi = lds.zig_norm_y[i], yi1 = lds.zig_norm_y[i + 1];
+    const f64 y = yi + y01 * (yi1 - yi);
+    const f64 chord = (xi - xi1) * y01 - (xi - x);
+    const f64 tangent = y - (yi + (xi - x) * yi * xi);
+    const f64 y_above_ubound = (xi >= 1) ? chord : tangent;
+    const f64 y_above_lbound = (xi >= 1) ? tangent : chord;
+    if (y_above_ubound < 0 && (y_above_lbound < 0 || y < wave::f_exp(-(x * x / 2)))) {
+      return x * sign;
+    }
+  }
+}
+
+// boost poisson_distribution<size_t, double>; uniform
+MODLE_DEV_NOINLINE u64 poisson_exact(Rng& g, f64 mean) {
+  if (mean < 10) {
+    f64 p = wave::f_exp(-mean);
+    u64 x = 0;
+    f64 u = uniform01_exact(g);
+    while (u > p) {
+      u = u - p;
+      ++x;
+      p = mean * p / static_cast<f64>(x);
+    }
+    return x;
+  }
+  const f64 log_fact[10] = {0.0,
+                            0.0,
+                            0.69314718055994529,
+                            1.7917594692280550,
+                            3.1780538303479458,
+                            4.7874917427820458,
+                            6.5792512120101012,
+                            8.5251613610654147,
+                            10.604602902745251,
+                            12.801827480081469};
+  const f64 smu = wave::f_sqrt(mean);
+  const f64 b = 0.931 + 2.53 * smu;
+  const f64 a = -0.059 + 0.02483 * b;
+  const f64 inv_alpha = 1.1239 + 1.1328 / (b - 3.4);
+  const f64 v_r = 0.9277 - 3.6224 / (b - 2);
+  for (;;) {
+    f64 u;
+    f64 v = uniform01_exact(g);
+    if (v <= 0.86 * v_r) {
+      u = v / v_r - 0.43;
+      return static_cast<u64>(
+          wave::f_floor((2 * a / (0.5 - wave::f_abs(u)) + b) * u + mean + 0.445));
+    }
+    if (v >= v_r) {
+      u = uniform01_exact(g) - 0.5;
+    } else {
+      u = v / v_r - 0.93;
+      u = ((u < 0) ? -0.5 : 0.5) - u;
+      v = uniform01_exact(g) * v_r;
+    }
+    const f64 us = 0.5 - wave::f_abs(u);
+    if (us < 0.013 && v > us) continue;
+    const f64 k = wave::f_floor((2 * a / us + b) * u + mean + 0.445);
+    v = v * inv_alpha / (a / (us * us) + b);
+    const f64 log_sqrt_2pi = 0.91893853320467267;
+    if (k >= 10) {
+      if (wave::f_log(v * smu) <= (k + 0.5) * wave::f_log(mean / k) - mean - log_sqrt_2pi + k -
+                                      (1 / 12. - (1 / 360. - 1 / (1260. * k * k)) / (k * k)) / k) {
+        return static_cast<u64>(k);
+      }
+    } else if (k >= 0) {
+      f64 lf = 0.0;
+      const int ki = static_cast<int>(k);
+#pragma unroll
+      for (int t = 0; t < 10; ++t) lf = (t == ki) ? log_fact[t] : lf;
+      if (wave::f_log(v) <= k * wave::f_log(mean) - mean - lf) return static_cast<u64>(k);
+    }
+  }
+}
+
+MODLE_DEV f64 binom_fc(i64 k) {
+  const f64 table[10] = {0.08106146679532726, 0.04134069595540929, 0.02767792568499834,
+                         0.02079067210376509, 0.01664469118982119, 0.01387612882307075,
+                         0.01189670994589177, 0.01041126526197209, 0.009255462182712733,
+                         0.008330563433362871};
+  if (k < 10) {
+    f64 v = 0.0;
+#pragma unroll
+    for (int t = 0; t < 10; ++t) v = (t == static_cast<int>(k)) ? table[t] : v;
+    return v;
+  }
+  const f64 ikp1 = 1.0 / static_cast<f64>(k + 1);
+  return (1.0 / 12 - (1.0 / 360 - (1.0 / 1260) * (ikp1 * ikp1)) * (ikp1 * ikp1)) * ikp1;
+}
+
+// boost binomial_distribution<ptrdiff_t, double>{t, p}; uniform
+MODLE_DEV_NOINLINE i64 binomial_exact(Rng& g, i64 t, f64 p_) {
+  const f64 p = (0.5 < p_) ? (1 - p_) : p_;
+  const i64 m = static_cast<i64>(static_cast<f64>(t + 1) * p);
+  i64 k;
+  if (m < 11) {
+    const f64 q = 1 - p;
+    const f64 s = p / q;
+    const f64 a = static_cast<f64>(t + 1) * s;
+    f64 r = wave::f_pow(1 - p, static_cast<f64>(t));
+    f64 u = uniform01_exact(g);
+    k = 0;
+    while (u > r) {
+      u = u - r;
+      ++k;
+      const f64 r1 = ((a / static_cast<f64>(k)) - s) * r;
+      if (r1 < DBL_EPS && r1 < r) break;
+      r = r1;
+    }
+    return (0.5 < p_) ? t - k : k;
+  }
+  const f64 r = p / (1 - p);
+  const f64 nr = static_cast<f64>(t + 1) * r;
+  const f64 npq = static_cast<f64>(t) * p * (1 - p);
+  const f64 sqrt_npq = wave::f_sqrt(npq);
+  const f64 b = 1.15 + 2.53 * sqrt_npq;
+  const f64 a = -0.0873 + 0.0248 * b + 0.01 * p;
+  const f64 c = static_cast<f64>(t) * p + 0.5;
+  const f64 alpha = (2.83 + 5.1 / b) * sqrt_npq;
+  const f64 v_r = 0.92 - 4.2 / b;
+  const f64 u_rv_r = 0.86 * v_r;
+  for (;;) {
+    f64 u;
+    f64 v = uniform01_exact(g);
+    if (v <= u_rv_r) {
+      u = v / v_r - 0.43;
+      k = static_cast<i64>(wave::f_floor((2 * a / (0.5 - wave::f_abs(u)) + b) * u + c));
+      break;
+    }
+    if (v >= v_r) {
+      u = uniform01_exact(g) - 0.5;
+    } else {
+      u = v / v_r - 0.93;
+      u = ((u < 0) ? -0.5 : 0.5) - u;
+      v = uniform01_exact(g) * v_r;
+    }
+    const f64 us = 0.5 - wave::f_abs(u);
+    k = static_cast<i64>(wave::f_floor((2 * a / us + b) * u + c));
+    if (k < 0 || k > t) continue;
+    v = v * alpha / (a / (us * us) + b);
+    const i64 kmi = k > m ? k - m : m - k;
+    const f64 km = static_cast<f64>(kmi);
+    if (km <= 15) {
+      f64 f = 1;
+      if (m < k) {
+        i64 i = m;
+        do {
+          ++i;
+          f = f * (nr / static_cast<f64>(i) - r);
+        } while (i != k);
+      } else if (m > k) {
+        i64 i = k;
+        do {
+          ++i;
+          v = v * (nr / static_cast<f64>(i) - r);
+        } while (i != m);
+      }
+      if (v <= f) break;
+      continue;
+    }
+    v = wave::f_log(v);
+    const f64 rho = (km / npq) * (((km / 3. + 0.625) * km + 1. / 6) / npq + 0.5);
+    const f64 tt = -km * km / (2 * npq);
+    if (v < tt - rho) break;
+    if (v > tt + rho) continue;
+    const i64 nm = t - m + 1;
+    const f64 h = (static_cast<f64>(m) + 0.5) *
+                      wave::f_log(static_cast<f64>(m + 1) / (r * static_cast<f64>(nm))) +
+                  binom_fc(m) + binom_fc(t - m);
+    const i64 nk = t - k + 1;
+    if (v <= h +
+                 static_cast<f64>(t + 1) *
+                     wave::f_log(static_cast<f64>(nm) / static_cast<f64>(nk)) +
+                 (static_cast<f64>(k) + 0.5) *
+                     wave::f_log(static_cast<f64>(nk) * r / static_cast<f64>(k + 1)) -
+                 binom_fc(k) - binom_fc(t - k)) {
+      break;
+    }
+  }
+  return (0.5 < p_) ? t - k : k;
+}
+
+// genextreme_value_distribution (reference: genextreme_value_distribution.hpp:87-105)
+MODLE_DEV f64 genextreme_from_canonical(f64 u, f64 mu, f64 sigma, f64 xi) {
+  if (xi == 0.0) return (mu - sigma) * wave::f_log(-wave::f_log(u));
+  return mu + (sigma * (1.0 - wave::f_pow(-wave::f_log(u), xi))) / xi;
+}
+
+
+}  // namespace modle_dev

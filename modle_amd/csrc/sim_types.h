@@ -76,7 +76,13 @@ struct Interval {
   u64* occupancy_1d;         // ncols words or nullptr
   u64* missed_updates;       // one counter
   u64 nrows, ncols;
+  // bar_bucket[b] = index of the first barrier at or after start + (b << bucket_shift); lets a
+  // unit find the barriers next to it with one lookup instead of a binary search
+  const u32* bar_bucket;
+  u32 bucket_shift;
+  u32 n_buckets;
 };
+constexpr u32 BAR_BUCKET_SHIFT = 13;
 
 struct Task {
   u32 interval;
@@ -94,18 +100,27 @@ struct CellResult {
   u64 sum_active_lefs, sampling_events, sim_epochs;
 };
 
-// Per-wave scratch in device memory (sized for the largest task of the launch).
+// Per-wave state in device memory (sized for the largest task of the launch).
+//
+// Extrusion units are stored in RANK ORDER (5'->3'), rev and fwd units separately, so that the
+// passes that walk the units in genomic order (move adjustment, every collision pass, extrusion)
+// read and write contiguous memory.  What the reference indexes by LEF id (binding epoch, the
+// PRNG draw order of moves / release / bind) lives in id-ordered arrays, with the two inverse
+// permutations r_rank / f_rank connecting the views.
+constexpr u32 NUM_TMP = 8;
 struct Workspace {
-  u32 *rev_pos, *fwd_pos, *epoch;       // by LEF id
-  u32 *rev_rank, *fwd_rank;             // LEF ids in 5'->3' order of their rev / fwd unit
-  u32 *rev_moves, *fwd_moves;           // by LEF id
-  u32 *rev_coll, *fwd_coll;             // collision words by LEF id
-  u32 *tmp_a, *tmp_b, *tmp_c, *tmp_d;   // L words each
+  u32 *r_pos, *r_id, *r_move, *r_coll;  // rev units, by rev rank
+  u32 *f_pos, *f_id, *f_move, *f_coll;  // fwd units, by fwd rank
+  u32 *epoch, *r_rank, *f_rank, *stall; // by LEF id
+  u32* tmp[NUM_TMP];                    // L words each
   u64* sort_keys;                       // pow2ceil(L) words
   f64* hist;                            // 2 * hist_len doubles (burn-in history)
   u8* bar_active;                       // n_barriers bytes
   u32 capacity_lefs, capacity_barriers;
 };
+constexpr u32 NUM_STATE_ARRAYS = 12 + NUM_TMP;
+// marker left in r_move / f_move by bind: "this unit was (re)bound this epoch"
+constexpr u32 NEW_MARK = 0xFFFFFFFFu;
 
 // LDS-resident (or host-emulated) per-wave context.
 struct WaveLds {
@@ -116,7 +131,13 @@ struct WaveLds {
   const f64* zig_exp_x;   // 257
   const f64* zig_exp_y;   // 257
   u32* list;              // small per-wave list (LIST_CAP entries)
+  u64* sort_lds;          // SORT_LDS_CAP keys (ranking of newly bound units)
+  u32* stage;             // STAGE_CAP words (staged slice of sorted positions)
+  u64* trace;             // optional per-epoch trace (4 words per epoch) or nullptr
+  u32 trace_cap;          // epochs the trace buffer holds
 };
 constexpr u32 LIST_CAP = 256;
+constexpr u32 SORT_LDS_CAP = 512;
+constexpr u32 STAGE_CAP = 256;
 
 }  // namespace modle_dev

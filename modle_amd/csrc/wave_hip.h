@@ -10,7 +10,14 @@
 #include <stdint.h>
 
 #define MODLE_DEV __device__ __forceinline__
+// Phase functions are inlined into the kernel by default: a wave-uniform value stays in scalar
+// registers across phases and wave-uniform branches compile to scalar branches.  MODLE_OUTLINE
+// turns them into real calls (shorter builds while debugging).
+#ifdef MODLE_OUTLINE
 #define MODLE_DEV_NOINLINE __device__ __noinline__
+#else
+#define MODLE_DEV_NOINLINE __device__ __forceinline__
+#endif
 
 namespace wave {
 
@@ -22,10 +29,46 @@ template <class T>
 MODLE_DEV T shfl(T v, unsigned src) {
   return __shfl(v, static_cast<int>(src), 64);
 }
-// value held by lane `src` (src must be wave-uniform)
+// Declares a value that is identical in all lanes to the compiler (v_readfirstlane): it then lives
+// in scalar registers and branches on it are scalar branches instead of exec-mask regions.  (The
+// CPU lane emulator checks that the lanes really agree.)
+MODLE_DEV uint32_t uniform(uint32_t v) {
+  return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)));
+}
+MODLE_DEV int32_t uniform(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+MODLE_DEV uint64_t uniform(uint64_t v) {
+  const uint32_t lo = uniform(static_cast<uint32_t>(v));
+  const uint32_t hi = uniform(static_cast<uint32_t>(v >> 32));
+  return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+MODLE_DEV int64_t uniform(int64_t v) { return static_cast<int64_t>(uniform(static_cast<uint64_t>(v))); }
+MODLE_DEV bool uniform(bool v) { return uniform(static_cast<uint32_t>(v)) != 0; }
+MODLE_DEV double uniform(double v) {
+  return __longlong_as_double(static_cast<long long>(uniform(static_cast<uint64_t>(__double_as_longlong(v)))));
+}
 template <class T>
-MODLE_DEV T bcast(T v, unsigned src) {
-  return __shfl(v, static_cast<int>(src), 64);
+MODLE_DEV T* uniform(T* p) {
+  return reinterpret_cast<T*>(uniform(reinterpret_cast<uint64_t>(p)));
+}
+
+// value held by lane `src` (src must be wave-uniform); the result is wave-uniform (v_readlane)
+MODLE_DEV uint32_t bcast(uint32_t v, unsigned src) {
+  return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), static_cast<int>(src)));
+}
+MODLE_DEV int32_t bcast(int32_t v, unsigned src) {
+  return __builtin_amdgcn_readlane(v, static_cast<int>(src));
+}
+MODLE_DEV uint64_t bcast(uint64_t v, unsigned src) {
+  const uint32_t lo = bcast(static_cast<uint32_t>(v), src);
+  const uint32_t hi = bcast(static_cast<uint32_t>(v >> 32), src);
+  return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+MODLE_DEV int64_t bcast(int64_t v, unsigned src) {
+  return static_cast<int64_t>(bcast(static_cast<uint64_t>(v), src));
+}
+MODLE_DEV bool bcast(bool v, unsigned src) { return bcast(static_cast<uint32_t>(v), src) != 0; }
+MODLE_DEV double bcast(double v, unsigned src) {
+  return __longlong_as_double(static_cast<long long>(bcast(static_cast<uint64_t>(__double_as_longlong(v)), src)));
 }
 // lane l receives the value of lane l+delta (own value when out of range)
 template <class T>

@@ -123,6 +123,10 @@ def emu_lib():
                                       [C.c_size_t, u64p, u8p, u8p, C.POINTER(C.c_uint64),
                                        C.POINTER(C.c_uint64)])
         L.emu_test_phases.restype = C.c_int
+        L.emu_set_lane_schedule.argtypes = [C.c_uint]
+        L.emu_set_lane_schedule.restype = None
+        # lane schedule of the emulator (0 = ascending, 1 = descending, n = random permutation n)
+        L.emu_set_lane_schedule(int(os.environ.get("MODLE_EMU_SCHEDULE", "0")))
         _emu = L
     return _emu
 

@@ -1,6 +1,7 @@
 // emu_api.cpp -- runs the product's device code (modle_amd/csrc/sim_device.h) under the CPU lane
 // emulator.  TEST INFRASTRUCTURE: lets the kernel logic be stepped against the oracle without a
 // GPU.  It is not a fallback of the product (the product refuses to run without the HIP path).
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,12 +17,24 @@
 
 using namespace modle_dev;
 
+#if defined(__has_feature)
+#if __has_feature(memory_sanitizer)
+#include <sanitizer/msan_interface.h>
+#define EMU_MARK_UNINIT(ptr, bytes) __msan_allocated_memory((ptr), (bytes))
+#endif
+#endif
+#ifndef EMU_MARK_UNINIT
+#define EMU_MARK_UNINIT(ptr, bytes) ((void)0)
+#endif
+
 namespace {
 
 struct LdsImage {
   std::vector<u64> ring;
   std::vector<u64> jump;
   std::vector<u32> list;
+  std::vector<u64> sort_lds;
+  std::vector<u32> stage;
   WaveLds view() {
     WaveLds l;
     l.ring = ring.data();
@@ -31,15 +44,31 @@ struct LdsImage {
     l.zig_exp_x = ZIG_EXP_X;
     l.zig_exp_y = ZIG_EXP_Y;
     l.list = list.data();
+    l.sort_lds = sort_lds.data();
+    l.stage = stage.data();
+    l.trace = nullptr;
+    l.trace_cap = 0;
     return l;
   }
-  LdsImage() : ring(RNG_RING), jump(modle_host::build_jump_table(RNG_BLOCK)), list(LIST_CAP) {}
+  LdsImage()
+      : ring(RNG_RING),
+        jump(modle_host::build_jump_table(RNG_BLOCK)),
+        list(LIST_CAP),
+        sort_lds(SORT_LDS_CAP),
+        stage(STAGE_CAP) {
+    // on the device these scratch regions start with whatever the previous kernel left there
+    EMU_MARK_UNINIT(ring.data(), ring.size() * 8);
+    EMU_MARK_UNINIT(list.data(), list.size() * 4);
+    EMU_MARK_UNINIT(sort_lds.data(), sort_lds.size() * 8);
+    EMU_MARK_UNINIT(stage.data(), stage.size() * 4);
+  }
 };
 
 struct IntervalImage {
   std::vector<u32> bar_pos;
   std::vector<u8> bar_dir;
   std::vector<f64> stp_a, stp_i, occ;
+  std::vector<u32> buckets;
   u64 missed = 0;
   Interval iv;
   IntervalImage(u64 start, u64 end, const u64* pos, const u8* dir, const f64* sa, const f64* si,
@@ -64,6 +93,10 @@ struct IntervalImage {
     iv.missed_updates = &missed;
     iv.nrows = nrows;
     iv.ncols = ncols;
+    buckets = modle_host::build_barrier_buckets(start, end, bar_pos);
+    iv.bar_bucket = buckets.data();
+    iv.bucket_shift = BAR_BUCKET_SHIFT;
+    iv.n_buckets = static_cast<u32>(buckets.size());
   }
 };
 
@@ -92,6 +125,7 @@ struct PhaseJob {
   const Interval* iv;
   Workspace ws;
   WaveLds lds;
+  TestImage img;
   u32 mask, n;
   u64 prng[4];
   u64 raws;
@@ -101,7 +135,7 @@ struct PhaseJob {
 void phase_body(void* arg) {
   PhaseJob* j = static_cast<PhaseJob*>(arg);
   u64 raws = 0;
-  const u32 st = run_test_phases(*j->p, *j->iv, j->ws, j->lds, j->mask, j->n, j->prng, raws);
+  const u32 st = run_test_phases(*j->p, *j->iv, j->ws, j->lds, j->img, j->mask, j->n, j->prng, raws);
   if (wave::lane() == 0) {
     j->raws = raws;
     j->status = st;
@@ -111,6 +145,8 @@ void phase_body(void* arg) {
 }  // namespace
 
 extern "C" {
+
+void emu_set_lane_schedule(unsigned schedule) { wave_emu::set_lane_schedule(schedule); }
 
 int emu_simulate_interval(const modle_hip_config* cfg, uint64_t start, uint64_t end,
                           const uint64_t* bar_pos, const uint8_t* bar_dir,
@@ -131,7 +167,14 @@ int emu_simulate_interval(const modle_hip_config* cfg, uint64_t start, uint64_t 
   LdsImage lds;
   const auto layout = modle_host::workspace_layout(static_cast<u32>(max_lefs),
                                                    static_cast<u32>(n_barriers), p.hist_len);
-  std::vector<uint64_t> wsmem(layout.total_bytes / 8 + 1);
+  // device memory is not zero-initialised: poison the scratch so that reads of never-written
+  // entries show up here as they would on the GPU
+  std::vector<uint64_t> wsmem(layout.total_bytes / 8 + 1, 0xDEADBEEFCAFEF00Dull);
+  EMU_MARK_UNINIT(wsmem.data(), wsmem.size() * 8);
+  std::fill(lds.ring.begin(), lds.ring.end(), 0xDEADBEEFCAFEF00Dull);
+  std::fill(lds.list.begin(), lds.list.end(), 0xDEADBEEFu);
+  std::fill(lds.sort_lds.begin(), lds.sort_lds.end(), 0xDEADBEEFCAFEF00Dull);
+  std::fill(lds.stage.begin(), lds.stage.end(), 0xDEADBEEFu);
   int rc = MODLE_HIP_OK;
   for (size_t t = 0; t < n_tasks; ++t) {
     Task task;
@@ -144,11 +187,25 @@ int emu_simulate_interval(const modle_hip_config* cfg, uint64_t start, uint64_t 
     memcpy(task.prng, tasks[t].prng, sizeof(task.prng));
     CellResult r;
     memset(&r, 0, sizeof(r));
+    std::vector<u64> trace;
+    WaveLds view = lds.view();
+    const char* trace_path = t == 0 ? getenv("MODLE_EMU_TRACE") : nullptr;
+    if (trace_path != nullptr) {
+      trace.assign(static_cast<size_t>(4096) * TRACE_STAGES * TRACE_WORDS_PER_STAGE, 0);
+      view.trace = trace.data();
+      view.trace_cap = 4096;
+    }
     CellJob job{&p, &img.iv, &task,
                 modle_host::carve_workspace(wsmem.data(), static_cast<u32>(max_lefs),
                                             static_cast<u32>(n_barriers), p.hist_len),
-                lds.view(), &r, 0};
+                view, &r, 0};
     wave_emu::run_wave(cell_body, &job);
+    if (trace_path != nullptr) {
+      if (FILE* f = fopen(trace_path, "wb")) {
+        fwrite(trace.data(), 8, trace.size(), f);
+        fclose(f);
+      }
+    }
     if (job.status != 0) rc = MODLE_HIP_ERR_STATE;
     if (results != nullptr) memcpy(&results[t], &r, sizeof(r));
   }
@@ -163,40 +220,25 @@ int emu_test_phases(const modle_hip_config* cfg, uint32_t phase_mask, uint64_t s
                     size_t n_barriers, const uint64_t* bar_pos, const uint8_t* bar_dir,
                     const uint8_t* bar_active, uint64_t prng[4], uint64_t* raws_consumed) {
   const Params p = modle_host::make_params(*cfg);
-  IntervalImage img(start, end, bar_pos, bar_dir, nullptr, nullptr, n_barriers, nullptr, 1, 1,
-                    nullptr);
+  IntervalImage img_iv(start, end, bar_pos, bar_dir, nullptr, nullptr, n_barriers, nullptr, 1, 1,
+                       nullptr);
   LdsImage lds;
   const auto layout =
       modle_host::workspace_layout(static_cast<u32>(n), static_cast<u32>(n_barriers), 4);
   std::vector<uint64_t> wsmem(layout.total_bytes / 8 + 1);
   Workspace ws = modle_host::carve_workspace(wsmem.data(), static_cast<u32>(n),
                                              static_cast<u32>(n_barriers), 4);
-  for (size_t i = 0; i < n; ++i) {
-    ws.rev_pos[i] = modle_host::pos_to_dev(rev_pos[i]);
-    ws.fwd_pos[i] = modle_host::pos_to_dev(fwd_pos[i]);
-    ws.epoch[i] = modle_host::pos_to_dev(epoch[i]);
-    ws.rev_rank[i] = static_cast<u32>(rev_rank[i]);
-    ws.fwd_rank[i] = static_cast<u32>(fwd_rank[i]);
-    ws.rev_moves[i] = static_cast<u32>(rev_moves[i]);
-    ws.fwd_moves[i] = static_cast<u32>(fwd_moves[i]);
-    ws.rev_coll[i] = modle_host::coll_to_dev(rev_coll[i]);
-    ws.fwd_coll[i] = modle_host::coll_to_dev(fwd_coll[i]);
-  }
+  std::vector<u32> image(9 * n);
+  TestImage img;
+  modle_host::fill_test_image(image.data(), n, rev_pos, fwd_pos, epoch, rev_rank, fwd_rank,
+                              rev_moves, fwd_moves, rev_coll, fwd_coll, img);
   for (size_t i = 0; i < n_barriers; ++i) ws.bar_active[i] = bar_active[i];
-  PhaseJob job{&p, &img.iv, ws, lds.view(), phase_mask, static_cast<u32>(n), {0, 0, 0, 0}, 0, 0};
+  PhaseJob job{&p, &img_iv.iv, ws, lds.view(), img, phase_mask, static_cast<u32>(n),
+               {0, 0, 0, 0}, 0, 0};
   memcpy(job.prng, prng, sizeof(job.prng));
   wave_emu::run_wave(phase_body, &job);
-  for (size_t i = 0; i < n; ++i) {
-    rev_pos[i] = modle_host::pos_to_abi(ws.rev_pos[i]);
-    fwd_pos[i] = modle_host::pos_to_abi(ws.fwd_pos[i]);
-    epoch[i] = modle_host::pos_to_abi(ws.epoch[i]);
-    rev_rank[i] = ws.rev_rank[i];
-    fwd_rank[i] = ws.fwd_rank[i];
-    rev_moves[i] = ws.rev_moves[i];
-    fwd_moves[i] = ws.fwd_moves[i];
-    rev_coll[i] = modle_host::coll_to_abi(ws.rev_coll[i]);
-    fwd_coll[i] = modle_host::coll_to_abi(ws.fwd_coll[i]);
-  }
+  modle_host::read_test_image(img, n, rev_pos, fwd_pos, epoch, rev_rank, fwd_rank, rev_moves,
+                              fwd_moves, rev_coll, fwd_coll);
   if (raws_consumed != nullptr) *raws_consumed = job.raws;
   return job.status == 0 ? MODLE_HIP_OK : MODLE_HIP_ERR_STATE;
 }

@@ -1,0 +1,52 @@
+// MemorySanitizer driver for the device code under the lane emulator (test infrastructure):
+// runs whole cells so that any read of uninitialised registers / LDS / workspace is reported.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "modle_hip.h"
+
+extern "C" int emu_simulate_interval(const modle_hip_config* cfg, uint64_t start, uint64_t end,
+                                     const uint64_t* bar_pos, const uint8_t* bar_dir,
+                                     const double* bar_stp_active, const double* bar_stp_inactive,
+                                     size_t n_barriers, const modle_hip_task* tasks, size_t n_tasks,
+                                     uint32_t* contacts, uint64_t nrows, uint64_t ncols,
+                                     uint64_t* missed_updates, uint64_t* occupancy,
+                                     modle_hip_cell_result* results);
+
+int main(int argc, char** argv) {
+  const uint64_t size = argc > 1 ? strtoull(argv[1], nullptr, 10) : 5000000;
+  const bool with_barriers = argc > 2 && atoi(argv[2]) != 0;
+  const size_t n_cells = argc > 3 ? strtoull(argv[3], nullptr, 10) : 1;
+  modle_hip_config cfg;
+  modle_hip_config_default(&cfg);
+  cfg.num_cells = 8;
+  cfg.simulate_chromosomes_wo_barriers = 1;
+  if (!with_barriers) cfg.number_of_lefs_per_mbp = 16.0;
+  char err[256];
+  if (modle_hip_config_transform(&cfg, err, sizeof(err)) < 0) return 2;
+  std::vector<uint64_t> bp;
+  std::vector<uint8_t> bd;
+  std::vector<double> sa, si;
+  if (with_barriers) {
+    uint64_t x = 12345;
+    for (uint64_t pos = 20000; pos + 20000 < size; pos += 30000 + (x = x * 6364136223846793005ull + 1442695040888963407ull) % 90000) {
+      bp.push_back(pos);
+      bd.push_back(((x >> 40) & 1) ? '+' : '-');
+      sa.push_back(modle_hip_stp_active_from_occupancy(cfg.barrier_not_occupied_stp, 0.6 + 0.3 * ((x >> 20) % 100) / 100.0));
+      si.push_back(cfg.barrier_not_occupied_stp);
+    }
+  }
+  std::vector<modle_hip_task> tasks(cfg.num_cells);
+  modle_hip_make_tasks(&cfg, "chrT", size, 0, size, 0, tasks.data());
+  uint64_t nr = 0, nc = 0;
+  modle_hip_matrix_shape(&cfg, size, &nr, &nc);
+  std::vector<uint32_t> contacts(nr * nc + 1, 0);
+  std::vector<uint64_t> occ(nc, 0);
+  uint64_t missed = 0;
+  std::vector<modle_hip_cell_result> res(n_cells);
+  const int rc = emu_simulate_interval(&cfg, 0, size, bp.data(), bd.data(), sa.data(), si.data(), bp.size(),
+                                       tasks.data(), n_cells, contacts.data(), nr, nc, &missed, occ.data(), res.data());
+  printf("rc=%d epochs=%llu contacts=%llu barriers=%zu\n", rc, (unsigned long long)res[0].epochs,
+         (unsigned long long)res[0].num_contacts, bp.size());
+  return rc;
+}

@@ -4,6 +4,8 @@
 namespace wave_emu {
 
 thread_local WaveRuntime* g_rt = nullptr;
+static unsigned g_schedule = 0;
+void set_lane_schedule(unsigned schedule) { g_schedule = schedule; }
 
 // callee-saved register context switch (SysV x86-64)
 asm(R"(
@@ -36,7 +38,7 @@ static void lane_entry() {
   rt->done[me] = true;
   int nxt = -1;
   for (int k = 1; k <= kLanes; ++k) {
-    const int c = (me + k) % kLanes;
+    const int c = rt->order[(rt->slot_of[me] + k) % kLanes];
     if (!rt->done[c]) {
       nxt = c;
       break;
@@ -71,10 +73,22 @@ void run_wave(void (*body)(void*), void* arg) {
     for (int k = 0; k < 6; ++k) sp[k] = nullptr;
     rt.lane_sp[l] = sp;
   }
+  for (int l = 0; l < kLanes; ++l) rt.order[l] = g_schedule == 1 ? kLanes - 1 - l : l;
+  if (g_schedule > 1) {
+    uint64_t x = g_schedule;
+    for (int l = kLanes - 1; l > 0; --l) {
+      x = x * 6364136223846793005ull + 1442695040888963407ull;
+      const int j = static_cast<int>((x >> 33) % static_cast<uint64_t>(l + 1));
+      const int t = rt.order[l];
+      rt.order[l] = rt.order[j];
+      rt.order[j] = t;
+    }
+  }
+  for (int l = 0; l < kLanes; ++l) rt.slot_of[rt.order[l]] = l;
   WaveRuntime* prev = g_rt;
   g_rt = &rt;
-  rt.cur = 0;
-  modle_emu_switch(&rt.main_sp, rt.lane_sp[0]);
+  rt.cur = rt.order[0];
+  modle_emu_switch(&rt.main_sp, rt.lane_sp[rt.order[0]]);
   g_rt = prev;
   free(rt.stacks);
 }

@@ -36,6 +36,11 @@ struct WaveRuntime {
   unsigned coll_count[kLanes];
   void (*body)(void*);
   void* arg;
+  // lane schedule: lanes run in the cyclic order order[0], order[1], ...; slot_of is the inverse.
+  // On hardware all lanes execute an instruction together, so a correct kernel must not depend
+  // on which lane runs first between two collectives: tests run it under several schedules.
+  int order[kLanes];
+  int slot_of[kLanes];
 };
 
 extern thread_local WaveRuntime* g_rt;
@@ -47,7 +52,7 @@ inline void yield_next() {
   const int me = rt->cur;
   int nxt = me;
   for (int k = 1; k <= kLanes; ++k) {
-    const int c = (me + k) % kLanes;
+    const int c = rt->order[(rt->slot_of[me] + k) % kLanes];
     if (!rt->done[c]) {
       nxt = c;
       break;
@@ -78,7 +83,9 @@ inline const Slot* collective(uint64_t lo, uint64_t hi, int line) {
   return s;
 }
 
+// schedule: 0 = lanes 0..63, 1 = 63..0, otherwise the seed of a random permutation
 void run_wave(void (*body)(void*), void* arg);
+void set_lane_schedule(unsigned schedule);
 
 }  // namespace wave_emu
 
@@ -107,6 +114,22 @@ MODLE_DEV T shfl(T v, unsigned src, int line = __builtin_LINE()) {
 template <class T>
 MODLE_DEV T bcast(T v, unsigned src, int line = __builtin_LINE()) {
   return shfl(v, src, line);
+}
+// the value must be identical in all lanes (checked)
+template <class T>
+MODLE_DEV T uniform(T v, int line = __builtin_LINE()) {
+  static_assert(sizeof(T) <= 8, "uniform operand too wide");
+  uint64_t w = 0;
+  memcpy(&w, &v, sizeof(T));
+  const wave_emu::Slot* s = wave_emu::collective(w, 0, line);
+  for (int l = 1; l < 64; ++l) {
+    if (s[l].v[0] != s[0].v[0]) {
+      fprintf(stderr, "wave_emu: value declared uniform at line %d differs: lane 0 = %llx, lane %d = %llx\n",
+              line, (unsigned long long)s[0].v[0], l, (unsigned long long)s[l].v[0]);
+      abort();
+    }
+  }
+  return v;
 }
 template <class T>
 MODLE_DEV T shfl_down(T v, unsigned delta, int line = __builtin_LINE()) {
