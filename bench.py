@@ -39,14 +39,40 @@ def parse_args():
     return ap.parse_args()
 
 
+def usable_cores():
+    """CPU cores this process can really use: affinity mask, capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = int(f.read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(cfg, genome, unit, sample_cells):
-    """Times the CPU oracle (oracle/, kind "port") on every host core over a bounded sample:
-    `sample_cells` cells of every chromosome of the workload."""
+    """Times the CPU oracle (oracle/, kind "port") with one thread per usable host core over a
+    bounded sample: `sample_cells` cells (default: three per thread, at most 256) of every chromosome
+    of the workload, all (chromosome, cell) tasks in one thread pool."""
     from modle_amd import api
     from oracle import binding as oracle
 
-    cores = os.cpu_count() or 1
-    sample = sample_cells or max(2, min(cores, 64))
+    cores = usable_cores()
+    sample = sample_cells or max(2, min(3 * cores, 256))  # ~3 cells per thread and chromosome
     jobs = []
     for iv in genome:
         if len(iv["bar_pos"]) == 0 and not cfg.simulate_chromosomes_wo_barriers:

@@ -36,7 +36,7 @@ using namespace modle_dev;
 
 namespace {
 
-constexpr int kWavesPerBlock = 8;
+constexpr int kWavesPerBlock = MODLE_WAVES_PER_CU;
 constexpr int kThreadsPerBlock = kWavesPerBlock * 64;
 
 struct DeviceTables {
@@ -56,6 +56,7 @@ struct SimArgs {
   u64* trace;  // diagnostic per-epoch trace of task 0 (MODLE_HIP_TRACE) or nullptr
   u32 trace_cap;
   u32 pad2_;
+  u64* phase_ticks;  // profiling build only
   char* workspace;
   u64 workspace_stride;
   u32 n_tasks;
@@ -64,14 +65,14 @@ struct SimArgs {
   u32 pad_;
 };
 
-__device__ Workspace device_carve(char* base, u32 max_lefs, u32 max_barriers, u32 hist_len) {
+__device__ __forceinline__ Workspace device_carve(char* base, u32 max_lefs, u32 max_barriers, u32 hist_len) {
   // mirrors modle_host::carve_workspace
   const u64 Lp = (static_cast<u64>(max_lefs) + 63) & ~u64(63);
   u64 pw = 1;
   const u32 ml = max_lefs < 64 ? 64 : max_lefs;
   while (pw < ml) pw <<= 1;
   Workspace ws;
-  char* p = base;
+  char* p = wave::as_global(base);
   ws.sort_keys = reinterpret_cast<u64*>(p);
   p += pw * 8;
   ws.hist = reinterpret_cast<f64*>(p);
@@ -106,7 +107,7 @@ struct BlockLds {
   u32 stage[kWavesPerBlock][STAGE_CAP];
 };
 
-__device__ WaveLds make_wave_lds(BlockLds& s, int wave_in_block) {
+__device__ __forceinline__ WaveLds make_wave_lds(BlockLds& s, int wave_in_block) {
   WaveLds l;
   l.ring = s.ring[wave_in_block];
   l.jump_table = s.jump;
@@ -117,14 +118,17 @@ __device__ WaveLds make_wave_lds(BlockLds& s, int wave_in_block) {
   l.list = s.list[wave_in_block];
   l.sort_lds = s.sort_keys[wave_in_block];
   l.stage = s.stage[wave_in_block];
+  l.phase_ticks = nullptr;
   l.trace = nullptr;
   l.trace_cap = 0;
   return l;
 }
 
-__device__ void load_block_tables(BlockLds& s, const DeviceTables& t, int nthreads) {
-  for (u32 i = threadIdx.x; i < JUMP_TABLE_WORDS; i += nthreads) s.jump[i] = t.jump[i];
-  for (u32 i = threadIdx.x; i < static_cast<u32>(kZigWords); i += nthreads) s.zig[i] = t.zig[i];
+__device__ __forceinline__ void load_block_tables(BlockLds& s, const DeviceTables& t, int nthreads) {
+  const u64* jump = wave::as_global(t.jump);
+  const f64* zig = wave::as_global(t.zig);
+  for (u32 i = threadIdx.x; i < JUMP_TABLE_WORDS; i += nthreads) s.jump[i] = jump[i];
+  for (u32 i = threadIdx.x; i < static_cast<u32>(kZigWords); i += nthreads) s.zig[i] = zig[i];
   __syncthreads();
 }
 
@@ -145,20 +149,21 @@ __global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs
     u32 leader = wave::lane();
     asm volatile("" : "+v"(leader));
     u32 t = 0;
-    if (leader == 0) t = atomicAdd(a.task_counter, 1u);
+    if (leader == 0) t = atomicAdd(wave::as_global(a.task_counter), 1u);
     t = wave::bcast(t, 0);  // scalar from here on: the queue loop is a scalar loop
     if (t >= a.n_tasks) break;  // every wave leaves once the queue is empty
-    const Task task = a.tasks[t];
+    const Task task = wave::as_global(a.tasks)[t];
     CellResult res;
     WaveLds lds_t = lds;
+    lds_t.phase_ticks = wave::as_global(a.phase_ticks);
     if (t == 0 && a.trace != nullptr) {
       lds_t.trace = a.trace;
       lds_t.trace_cap = a.trace_cap;
     }
-    const u32 st = simulate_cell(a.params, a.intervals[task.interval], task, ws, lds_t, res);
+    const u32 st = simulate_cell(a.params, wave::as_global(a.intervals)[task.interval], task, ws, lds_t, res);
     // all lanes store the same words (no lane-dependent branch at the end of the loop body)
-    a.results[t] = res;
-    a.status[t] = st;
+    wave::as_global(a.results)[t] = res;
+    wave::as_global(a.status)[t] = st;
   }
 }
 
@@ -271,6 +276,7 @@ struct modle_hip_handle {
   DevBuf<char> d_workspace;
   DevBuf<u64> d_phase_out;
   DevBuf<u64> d_trace;
+  DevBuf<u64> d_phase_ticks;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   hipStream_t stream = nullptr;
   bool in_flight = false;
@@ -571,6 +577,12 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
       }
     }
   }
+  a.phase_ticks = nullptr;
+#ifdef MODLE_PHASE_TIMERS
+  HIP_TRY(h->d_phase_ticks.ensure(16));
+  HIP_TRY(hipMemsetAsync(h->d_phase_ticks.p, 0, 16 * 8, h->stream));
+  a.phase_ticks = h->d_phase_ticks.p;
+#endif
   a.workspace = h->d_workspace.p;
   a.workspace_stride = layout.total_bytes;
   a.n_tasks = static_cast<u32>(sorted.size());
@@ -592,6 +604,21 @@ int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen) {
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->in_flight = false;
   HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev_start, h->ev_stop));
+#ifdef MODLE_PHASE_TIMERS
+  {
+    static const char* names[16] = {"burnin_stats", "bind", "rank_rev", "rank_fwd", "sample", "gen_moves",
+                                    "adjust_moves", "barriers+clear", "boundaries", "lef_bar", "primary",
+                                    "secondary", "fix_secondary", "extrude_release", "(secondary walk)", "(walk iterations)"};
+    u64 ticks[16];
+    HIP_TRY(hipMemcpy(ticks, h->d_phase_ticks.p, sizeof(ticks), hipMemcpyDeviceToHost));
+    u64 total = 0;
+    for (int i = 0; i < 14; ++i) total += ticks[i];
+    std::fprintf(stderr, "[modle_hip prof] kernel %.1f ms, wave-time per phase (sum over waves, 100 MHz ticks):\n", h->last_ms);
+    for (int i = 0; i < 16; ++i)
+      std::fprintf(stderr, "  %-16s %12.3f s  %5.1f %%\n", names[i], static_cast<double>(ticks[i]) * 1e-8,
+                   total ? 100.0 * static_cast<double>(ticks[i]) / static_cast<double>(total) : 0.0);
+  }
+#endif
   std::vector<CellResult> res(h->n_launched);
   std::vector<u32> status(h->n_launched);
   HIP_TRY(hipMemcpy(res.data(), h->d_results.p, res.size() * sizeof(CellResult),

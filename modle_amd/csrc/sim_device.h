@@ -26,7 +26,24 @@ struct Cell {
   u32 hist_len;   // entries in the burn-in history buffers
   u32 hist_head;  // ring head
   u32 error;      // non-zero when an internal capacity was exceeded (uniform)
+#ifdef MODLE_PHASE_TIMERS
+  u64 ph[16];     // profiling build: time spent per phase (wave::clock ticks)
+#endif
 };
+// Profiling build (make prof): PHASE(c, i, call) accumulates the time of `call` in c.ph[i].
+#ifdef MODLE_PHASE_TIMERS
+#define PHASE(c, i, ...)                          \
+  do {                                            \
+    const u64 ph_t0_ = wave::clock();             \
+    __VA_ARGS__;                                  \
+    (c).ph[i] += wave::clock() - ph_t0_;          \
+  } while (0)
+#else
+#define PHASE(c, i, ...) \
+  do {                   \
+    __VA_ARGS__;         \
+  } while (0)
+#endif
 constexpr u32 ERR_LIST_OVERFLOW = 1;
 constexpr u32 ERR_TRIAL_OVERFLOW = 2;
 constexpr u32 ERR_INTERNAL = 3;
@@ -348,37 +365,43 @@ MODLE_DEV_NOINLINE void generate_moves_dir(Cell& c, f64 speed, f64 std) {
     }
     return;
   }
-  u32 i0 = 0;
-  while (i0 < n) {
-    const u32 cntb = umin(64u, n - i0);
-    const u32 i = i0 + lane;
-    const bool act = lane < cntb;
+  for (u32 base = 0; base < n; base += 64) {
+    const u32 i = base + lane;
+    const bool act = i < n;
     const bool bnd = act && ws.epoch[i] != UNBOUND;
     const u32 slot = act ? rank[i] : 0;
-    const u64 bm = wave::ballot(bnd);
-    const u32 ndraw = static_cast<u32>(wave::popc64(bm));
-    rng_ensure(c.g, ndraw);
-    const u32 k = static_cast<u32>(wave::popc64(bm & lanemask_lt(lane)));
-    u32 bucket;
-    const f64 u = int_float_pair8(rng_peek(c.g, c.g.pos + k), bucket);
-    const u32 layer = bucket >> 1;
-    const f64 x = u * c.lds.zig_norm_x[layer];
-    const bool fast = x < c.lds.zig_norm_x[layer + 1];
-    f64 unit = (bucket & 1u) ? x : -x;
-    const u64 slow = wave::ballot(bnd && !fast);
-    if (slow == 0) {
-      if (act) moves[slot] = bnd ? move_from_normal(unit, speed, std) : 0;
-      c.g.pos += ndraw;
-      i0 += cntb;
-    } else {
-      // lanes before the first slow draw are final; the slow one is replayed exactly
-      const u32 f = static_cast<u32>(wave::ctz64(slow));
-      c.g.pos += static_cast<u32>(wave::popc64(bm & lanemask_lt(f)));
-      const f64 exact = unit_normal_exact(c.g, c.lds);
-      if (lane == f) unit = exact;
-      if (act && lane <= f) moves[slot] = bnd ? move_from_normal(unit, speed, std) : 0;
-      i0 += f + 1;
+    // bound LEFs of the batch still waiting for their draw, in id order.  Every pass gives each
+    // of them the raw output it would get if all draws before it took the fast path; the first
+    // one that needs the slow path is replayed exactly and the ones after it are re-evaluated
+    // at their shifted stream positions (registers only: nothing is re-read from memory).
+    u64 pending = wave::ballot(bnd);
+    u32 mv = 0;
+    while (pending != 0) {
+      const u32 ndraw = static_cast<u32>(wave::popc64(pending));
+      rng_ensure(c.g, ndraw);
+      const bool mine = ((pending >> lane) & 1u) != 0;
+      const u32 k = static_cast<u32>(wave::popc64(pending & lanemask_lt(lane)));
+      u32 bucket;
+      const f64 u = int_float_pair8(rng_peek(c.g, c.g.pos + k), bucket);
+      const u32 layer = bucket >> 1;
+      const f64 x = u * c.lds.zig_norm_x[layer];
+      const bool fast = x < c.lds.zig_norm_x[layer + 1];
+      const f64 unit = (bucket & 1u) ? x : -x;
+      const u64 slow = wave::ballot(mine && !fast);
+      if (slow == 0) {
+        if (mine) mv = move_from_normal(unit, speed, std);
+        c.g.pos += ndraw;
+        pending = 0;
+      } else {
+        const u32 f = static_cast<u32>(wave::ctz64(slow));
+        if (mine && lane < f) mv = move_from_normal(unit, speed, std);
+        c.g.pos += static_cast<u32>(wave::popc64(pending & lanemask_lt(f)));
+        const f64 exact = unit_normal_exact(c.g, c.lds);
+        if (lane == f) mv = move_from_normal(exact, speed, std);
+        pending &= ~((u64(2) << f) - 1);
+      }
     }
+    if (act) moves[slot] = mv;
   }
 }
 
@@ -529,11 +552,10 @@ MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp)
 
 MODLE_DEV void phase_generate_moves(Cell& c, bool burnin_completed) {
   const Params& p = *c.p;
-  generate_moves_dir<false>(c, burnin_completed ? p.rev_speed : p.rev_speed_burnin, p.rev_std);
-  generate_moves_dir<true>(c, burnin_completed ? p.fwd_speed : p.fwd_speed_burnin, p.fwd_std);
-  wave::sync_mem();
-  adjust_moves_rev(c, true, true);
-  adjust_moves_fwd(c, true, true);
+  PHASE(c, 5, generate_moves_dir<false>(c, burnin_completed ? p.rev_speed : p.rev_speed_burnin, p.rev_std);
+        generate_moves_dir<true>(c, burnin_completed ? p.fwd_speed : p.fwd_speed_burnin, p.fwd_std);
+        wave::sync_mem());
+  PHASE(c, 6, adjust_moves_rev(c, true, true); adjust_moves_fwd(c, true, true));
 }
 
 // =============================================================================================
@@ -656,6 +678,36 @@ MODLE_DEV_NOINLINE BoundaryCounts detect_boundaries(Cell& c) {
 // unit upstream), so the barriers that can stall the unit of rank j are those between the unit
 // of rank j-1 and itself that lie within its move.  Bernoulli trials (pblock not in {0,1}) are
 // numbered in the reference's order: barriers ascending for rev units, descending for fwd units.
+//
+// The barriers a batch of 64 consecutive ranks can touch form one index range that continues
+// where the previous batch stopped.  A window of BAR_WIN barriers (position and a flag word:
+// state, blocking direction) is staged in LDS with one coalesced load and all per-unit searches
+// run there; a batch whose units need more than the window falls back to device memory.
+constexpr u32 BAR_WIN = STAGE_CAP / 2;
+
+struct BarView {  // barriers [s0, s1) are staged; everything else is read from device memory
+  const Interval* iv;
+  const u8* active;
+  const u32* st_pos;
+  const u32* st_flag;
+  u32 s0, s1;
+  MODLE_DEV_MEMBER u32 pos(u32 b) const { return (b >= s0 && b < s1) ? st_pos[b - s0] : iv->bar_pos[b]; }
+  // bit 0: active, bits 1..2: blocking direction
+  MODLE_DEV_MEMBER u32 flag(u32 b) const {
+    return (b >= s0 && b < s1) ? st_flag[b - s0]
+                               : (static_cast<u32>(active[b] != 0) | (static_cast<u32>(iv->bar_dir[b]) << 1));
+  }
+};
+
+// first barrier index in [lo, hi) whose position is >= key (hi when there is none)
+MODLE_DEV u32 bar_view_lower_bound(const BarView& v, u32 lo, u32 hi, u64 key) {
+  while (lo < hi) {
+    const u32 mid = (lo + hi) >> 1;
+    if (v.pos(mid) < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
 template <bool FWD>
 MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
   Workspace& ws = c.ws;
@@ -671,10 +723,13 @@ MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
   const u32 major_dir = FWD ? DIR_FWD : DIR_REV;
   const bool trials = !((p.pblock_major == 1.0 || p.pblock_major == 0.0) &&
                         (p.pblock_minor == 1.0 || p.pblock_minor == 0.0));
+  u32* st_pos = c.lds.stage;
+  u32* st_flag = c.lds.stage + BAR_WIN;
   // first / last rank that takes part
   const u32 j_rev0 = bc.n5 == 0 ? 0 : bc.n5 - 1;
   const u32 j_fwd0 = bc.n3 == 0 ? n - 1 : n - bc.n3;
   u32 carry_pos = 0;  // position of the neighbouring unit processed by the previous batch
+  u32 anchor = 0;     // rev: first barrier index the next batch can need; fwd: one past the last
   const u32 nbatch = (n + 63) / 64;
   for (u32 bi = 0; bi < nbatch; ++bi) {
     // rev: ranks ascending; fwd: ranks descending, lane 0 = highest rank of the batch
@@ -690,31 +745,77 @@ MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
     const u32 nbr_in = wave::shfl_up(P, 1);
     const bool first = (bi == 0 && lane == 0);
     const u32 nbr = lane > 0 ? nbr_in : carry_pos;
-    // window of barrier indices [b_lo, b_hi)
-    u32 b_lo = 0, b_hi = 0;
+    // the unit can be stalled by barriers with lo_key <= position < hi_key
+    u64 lo_key = 0, hi_key = 0;
     if (bnd) {
       if (!FWD) {
         // prev <= bpos < P and P - bpos <= M
         const u32 reach = P - M;  // M <= P - start after clamping
-        const u32 lo_pos = first ? reach : umax(reach, nbr);
-        b_lo = bar_lower_bound(iv, lo_pos);
-        b_hi = b_lo;
-        while (b_hi < nb && iv.bar_pos[b_hi] < P) ++b_hi;
+        lo_key = first ? reach : umax(reach, nbr);
+        hi_key = P;
       } else {
         // P < bpos <= next and bpos - P <= M
         const u64 reach = static_cast<u64>(P) + M;
-        const u64 hi_pos = first ? reach : umin64(reach, nbr);
-        b_lo = bar_lower_bound(iv, static_cast<u64>(P) + 1);
+        lo_key = static_cast<u64>(P) + 1;
+        hi_key = (first ? reach : umin64(reach, nbr)) + 1;
+      }
+    }
+    // stage the window.  The first batch locates it through the bucket table (from the first
+    // bound unit in visiting order); later batches continue where the previous one stopped.
+    const u64 bm = wave::ballot(bnd);
+    if (bm == 0) {
+      carry_pos = wave::bcast(P, 63);
+      continue;
+    }
+    if (bi == 0) {
+      const u32 l0 = static_cast<u32>(wave::ctz64(bm));
+      const u64 key = FWD ? wave::bcast(hi_key, l0) : wave::bcast(lo_key, l0);
+      anchor = wave::uniform(bar_lower_bound(iv, key));
+    }
+    BarView v;
+    v.iv = &iv;
+    v.active = ws.bar_active;
+    v.st_pos = st_pos;
+    v.st_flag = st_flag;
+    if (!FWD) {
+      v.s0 = anchor;
+      v.s1 = umin(anchor + BAR_WIN, nb);
+    } else {
+      v.s1 = anchor;
+      v.s0 = anchor > BAR_WIN ? anchor - BAR_WIN : 0;
+    }
+    wave::lockstep();
+    for (u32 t = lane; t < BAR_WIN; t += 64) {
+      const u32 b = v.s0 + t;
+      if (b < v.s1) {
+        st_pos[t] = iv.bar_pos[b];
+        st_flag[t] = static_cast<u32>(ws.bar_active[b] != 0) | (static_cast<u32>(iv.bar_dir[b]) << 1);
+      }
+    }
+    wave::sync_mem();
+    // window of barrier indices [b_lo, b_hi) of this unit.  Searches start inside the staged
+    // range and continue in device memory when they run off its edge (BarView handles both).
+    u32 b_lo = 0, b_hi = 0;
+    if (bnd) {
+      if (!FWD) {
+        b_lo = bar_view_lower_bound(v, v.s0, v.s1, lo_key);
+        if (b_lo == v.s1 && v.s1 < nb) b_lo = bar_view_lower_bound(v, v.s1, nb, lo_key);
         b_hi = b_lo;
-        while (b_hi < nb && iv.bar_pos[b_hi] <= hi_pos) ++b_hi;
+        while (b_hi < nb && v.pos(b_hi) < hi_key) ++b_hi;
+      } else {
+        b_hi = bar_view_lower_bound(v, v.s0, v.s1, hi_key);
+        if (b_hi == v.s0 && v.s0 > 0) b_hi = bar_view_lower_bound(v, 0, v.s0, hi_key);
+        b_lo = b_hi;
+        while (b_lo > 0 && v.pos(b_lo - 1) >= lo_key) --b_lo;
       }
     }
     // number of Bernoulli trials this unit consumes
     u32 ntr = 0;
     if (trials) {
       for (u32 b = b_lo; b < b_hi; ++b) {
-        const f64 pb = iv.bar_dir[b] == major_dir ? p.pblock_major : p.pblock_minor;
-        ntr += (ws.bar_active[b] && pb != 1.0 && pb != 0.0) ? 1u : 0u;
+        const u32 fl = v.flag(b);
+        const f64 pb = (fl >> 1) == major_dir ? p.pblock_major : p.pblock_minor;
+        ntr += ((fl & 1u) && pb != 1.0 && pb != 0.0) ? 1u : 0u;
       }
     }
     // exclusive prefix sum of ntr over lanes
@@ -735,8 +836,9 @@ MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
     u32 t = 0;
     for (u32 q = b_lo; q < b_hi; ++q) {
       const u32 b = FWD ? (b_hi - 1 - (q - b_lo)) : q;  // reference visiting order
-      if (!ws.bar_active[b]) continue;
-      const f64 pb = iv.bar_dir[b] == major_dir ? p.pblock_major : p.pblock_minor;
+      const u32 fl = v.flag(b);
+      if (!(fl & 1u)) continue;
+      const f64 pb = (fl >> 1) == major_dir ? p.pblock_major : p.pblock_minor;
       bool hit;
       if (pb == 1.0) {
         hit = true;
@@ -751,6 +853,9 @@ MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
     if (winner != 0xFFFFFFFFu) coll[k] = cw_make(winner, EV_COLLISION | EV_LEF_BAR);
     c.g.pos += total;
     carry_pos = wave::bcast(P, 63);
+    // where the next batch continues: past the last bound unit's window (rev) / below it (fwd)
+    const u32 l_last = static_cast<u32>(63 - wave::clz64(bm));
+    anchor = FWD ? wave::bcast(b_lo, l_last) : wave::bcast(b_hi, l_last);
   }
   wave::sync_mem();
 }
@@ -995,7 +1100,22 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
     const bool pot = follower && !cw_occurred(C) &&
                      (FWD ? static_cast<u64>(P) + M >= blocker_pos
                           : static_cast<u64>(P) - M <= blocker_pos);
-    u64 todo = wave::ballot(pot);
+    // A follower only needs the serial walk when its blocker is stalled already, or may become
+    // stalled during the walk because it is a candidate itself (cascade): propagate "blocker
+    // may be stalled" along runs of consecutive candidates with scalar bit operations.
+    const u64 potm = wave::ballot(pot);
+    const bool blk_occ_in = wave::shfl_up(cw_occurred(C), 1);
+    const u64 occm = wave::ballot(lane > 0 ? blk_occ_in : cw_occurred(carry_coll));
+    u64 todo = potm & occm;
+    for (;;) {
+      const u64 grown = todo | (potm & (todo << 1));
+      if (grown == todo) break;
+      todo = grown;
+    }
+#ifdef MODLE_PHASE_TIMERS
+    const u64 walk_t0 = wave::clock();
+    c.ph[15] += static_cast<u64>(wave::popc64(todo));
+#endif
     while (todo != 0) {
       const u32 l = static_cast<u32>(wave::ctz64(todo));
       todo &= todo - 1;
@@ -1030,6 +1150,9 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
         ++n_list;
       }
     }
+#ifdef MODLE_PHASE_TIMERS
+    c.ph[14] += wave::clock() - walk_t0;
+#endif
     if (act && (M != M0 || C != C0)) {
       moves[k] = M;
       coll[k] = C;
@@ -1109,36 +1232,24 @@ MODLE_DEV_NOINLINE void fix_secondary_fwd(Cell& c, const u32* list, u32 n_list) 
   }
 }
 
-MODLE_DEV void clear_collisions(Cell& c) {
-  const u32 n = wave::uniform(c.n_active);
-  const u32 lane = wave::lane();
-  for (u32 base = 0; base < n; base += 64) {
-    const u32 i = base + lane;
-    if (i < n) {
-      c.ws.r_coll[i] = 0;
-      c.ws.f_coll[i] = 0;
-    }
-  }
-  wave::sync_mem();
-}
-
 // returns false when an internal capacity was exceeded (the cell is then flagged as failed)
 MODLE_DEV bool phase_process_collisions(Cell& c) {
-  const BoundaryCounts bc = detect_boundaries(c);
-  detect_lef_bar<false>(c, bc);
-  detect_lef_bar<true>(c, bc);
-  detect_primary(c, bc, true);
+  BoundaryCounts bc;
+  PHASE(c, 8, bc = detect_boundaries(c));
+  PHASE(c, 9, detect_lef_bar<false>(c, bc); detect_lef_bar<true>(c, bc));
+  PHASE(c, 10, detect_primary(c, bc, true));
   bool overflow = false;
   // avoided secondary collisions are listed in device scratch: one entry per unit at most
   u32* list_rev = c.ws.tmp[5];
   u32* list_fwd = c.ws.tmp[6];
   const u32 cap = c.ws.capacity_lefs;
-  const u32 nr = process_secondary<false>(c, bc, list_rev, cap, overflow, true, true);
-  const u32 nf = process_secondary<true>(c, bc, list_fwd, cap, overflow, true, true);
+  u32 nr = 0, nf = 0;
+  PHASE(c, 11, nr = process_secondary<false>(c, bc, list_rev, cap, overflow, true, true);
+        nf = process_secondary<true>(c, bc, list_fwd, cap, overflow, true, true));
   if (overflow) c.error = ERR_LIST_OVERFLOW;
   if (c.error != 0) return false;
-  if (nr != 0) fix_secondary_rev(c, list_rev, nr);
-  if (nf != 0) fix_secondary_fwd(c, list_fwd, nf);
+  PHASE(c, 12, if (nr != 0) fix_secondary_rev(c, list_rev, nr);
+        if (nf != 0) fix_secondary_fwd(c, list_fwd, nf));
   return true;
 }
 
@@ -1151,42 +1262,37 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
   const f64 base_p = burnin_completed ? p.p_release : p.p_release_burnin;
-  // extrude in rank order; units stalled by a barrier that blocks their own direction ("hard"
-  // stalls) are reported to their LEF through stall[id]
+  // extrude in rank order (rev and fwd units of the same rank in one step: their loads are
+  // independent); units stalled by a barrier that blocks their own direction ("hard" stalls)
+  // are reported to their LEF through stall[id].  The collision words are consumed here, so
+  // they are cleared on the way (the next epoch starts with clean arrays).
   for (u32 base = 0; base < n; base += 64) {
     const u32 k = base + lane;
     if (k < n) {
-      const u32 P = ws.r_pos[k];
-      if (P != UNBOUND) {
-        ws.r_pos[k] = P - ws.r_move[k];
-        const u32 rc = ws.r_coll[k];
-        if (cw_occurred_as(rc, EV_LEF_BAR) && c.iv->bar_dir[cw_index(rc)] == DIR_REV)
-          ws.stall[ws.r_id[k]] = 1;
-      }
-    }
-  }
-  wave::sync_mem();
-  for (u32 base = 0; base < n; base += 64) {
-    const u32 k = base + lane;
-    if (k < n) {
-      const u32 P = ws.f_pos[k];
-      if (P != UNBOUND) {
-        ws.f_pos[k] = P + ws.f_move[k];
-        const u32 fc = ws.f_coll[k];
-        if (cw_occurred_as(fc, EV_LEF_BAR) && c.iv->bar_dir[cw_index(fc)] == DIR_FWD)
-          ws.stall[ws.f_id[k]] += 1;
-      }
+      const u32 rP = ws.r_pos[k], rM = ws.r_move[k], rc = ws.r_coll[k];
+      const u32 fP = ws.f_pos[k], fM = ws.f_move[k], fc = ws.f_coll[k];
+      if (rP != UNBOUND) ws.r_pos[k] = rP - rM;
+      if (fP != UNBOUND) ws.f_pos[k] = fP + fM;
+      if (rc != 0) ws.r_coll[k] = 0;
+      if (fc != 0) ws.f_coll[k] = 0;
+      if (rP != UNBOUND && cw_occurred_as(rc, EV_LEF_BAR) && c.iv->bar_dir[cw_index(rc)] == DIR_REV)
+        wave::atomic_inc_u32(&ws.stall[ws.r_id[k]]);
+      if (fP != UNBOUND && cw_occurred_as(fc, EV_LEF_BAR) && c.iv->bar_dir[cw_index(fc)] == DIR_FWD)
+        wave::atomic_inc_u32(&ws.stall[ws.f_id[k]]);
     }
   }
   wave::sync_mem();
   for (u32 base = 0; base < n; base += 64) {
     const u32 i = base + lane;
     const bool act = i < n;
-    const bool bnd = act && ws.epoch[i] != UNBOUND;
+    const u32 ep = act ? ws.epoch[i] : UNBOUND;
+    const u32 hard = act ? ws.stall[i] : 0;
+    const u32 kr = act ? ws.r_rank[i] : 0;
+    const u32 kf = act ? ws.f_rank[i] : 0;
+    const bool bnd = ep != UNBOUND;
     f64 prob = 0.0;
     if (act) {
-      const u32 hard = ws.stall[i];
-      ws.stall[i] = 0;
+      if (hard != 0) ws.stall[i] = 0;
       const f64 affinity =
           hard == 0 ? 1.0 : (hard == 1 ? 1.0 / p.soft_stall_mult : 1.0 / p.hard_stall_mult);
       prob = affinity * base_p;
@@ -1200,8 +1306,8 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
     c.g.pos += cnt;
     if (rel) {
       ws.epoch[i] = UNBOUND;
-      ws.r_pos[ws.r_rank[i]] = UNBOUND;
-      ws.f_pos[ws.f_rank[i]] = UNBOUND;
+      ws.r_pos[kr] = UNBOUND;
+      ws.f_pos[kf] = UNBOUND;
     }
   }
   wave::sync_mem();
@@ -1372,7 +1478,8 @@ MODLE_DEV_NOINLINE u64 run_events(Cell& c, u64 n_events) {
       --remaining;
       continue;
     }
-    const u32 cntb = static_cast<u32>(umin64(64, remaining));
+    // one step handles at most as many events as the PRNG ring can serve
+    const u32 cntb = static_cast<u32>(umin64(umin(64u, RNG_BLOCK / stride), remaining));
     rng_ensure(c.g, cntb * stride);
     const bool act = lane < cntb;
     EventEval e{stride, false, false, 0, 0};
@@ -1564,6 +1671,21 @@ MODLE_DEV void activate_lefs(Cell& c, u32 n_old, u32 n_new) {
   wave::sync_mem();
 }
 
+// copy of an interval descriptor whose pointers are known to address device memory
+MODLE_DEV Interval interval_in_device_memory(const Interval& iv) {
+  Interval g = iv;
+  g.bar_pos = wave::as_global(iv.bar_pos);
+  g.bar_dir = wave::as_global(iv.bar_dir);
+  g.bar_stp_active = wave::as_global(iv.bar_stp_active);
+  g.bar_stp_inactive = wave::as_global(iv.bar_stp_inactive);
+  g.bar_occupancy = wave::as_global(iv.bar_occupancy);
+  g.contacts = wave::as_global(iv.contacts);
+  g.occupancy_1d = wave::as_global(iv.occupancy_1d);
+  g.missed_updates = wave::as_global(iv.missed_updates);
+  g.bar_bucket = wave::as_global(iv.bar_bucket);
+  return g;
+}
+
 MODLE_DEV void init_cell(Cell& c, const Params& p, const Interval& iv, const Workspace& ws,
                          const WaveLds& lds, u32 n_lefs, const u64 prng[4]) {
   c.p = &p;
@@ -1575,6 +1697,9 @@ MODLE_DEV void init_cell(Cell& c, const Params& p, const Interval& iv, const Wor
   c.hist_len = 0;
   c.hist_head = 0;
   c.error = 0;
+#ifdef MODLE_PHASE_TIMERS
+  for (int i = 0; i < 16; ++i) c.ph[i] = 0;
+#endif
   c.g.ring = lds.ring;
   c.g.jump = lds.jump_table;
   rng_init(c.g, prng);
@@ -1624,7 +1749,8 @@ MODLE_DEV_NOINLINE void trace_stage(Cell& c, u64 epoch, u32 stage) {
 MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& task,
                             const Workspace& ws, const WaveLds& lds, CellResult& res) {
   Cell c;
-  init_cell(c, p, iv, ws, lds, task.num_lefs, task.prng);
+  const Interval ivg = interval_in_device_memory(iv);
+  init_cell(c, p, ivg, ws, lds, task.num_lefs, task.prng);
   reset_cell_buffers(c);
 
   u64 epoch = 0, num_burnin_epochs = 0, num_contacts = 0;
@@ -1654,8 +1780,7 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
           const u64 na = static_cast<u64>(c.n_active) + k;
           activate_lefs(c, c.n_active, na < c.n_lefs ? static_cast<u32>(na) : c.n_lefs);
         } else {
-          compute_loop_size_stats(c);
-          burnin_completed = evaluate_burnin(c);
+          PHASE(c, 0, compute_loop_size_stats(c); burnin_completed = evaluate_burnin(c));
           burnin_completed = burnin_completed && epoch > p.min_burnin_epochs;
           if (!burnin_completed && epoch >= p.max_burnin_epochs) {
             burnin_completed = true;
@@ -1664,10 +1789,10 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
         }
       } while (c.n_active == 0);
     }
-    phase_bind(c, static_cast<u32>(epoch));
+    PHASE(c, 1, phase_bind(c, static_cast<u32>(epoch)));
     trace_stage(c, epoch, 0);
-    rank_update<false>(c, false);
-    rank_update<true>(c, false);
+    PHASE(c, 2, rank_update<false>(c, false));
+    PHASE(c, 3, rank_update<true>(c, false));
     trace_stage(c, epoch, 1);
     if (c.error != 0) {
       status = c.error;
@@ -1675,8 +1800,9 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
     }
 
     if (burnin_completed) {
-      num_contacts += phase_sample_contacts(c, task.contacts_per_epoch, task.num_target_contacts,
-                                            num_contacts, events_done);
+      PHASE(c, 4, num_contacts += phase_sample_contacts(c, task.contacts_per_epoch,
+                                                        task.num_target_contacts, num_contacts,
+                                                        events_done));
       trace_stage(c, epoch, 5);
       if (task.num_target_contacts != 0 && num_contacts >= task.num_target_contacts) break;
     }
@@ -1685,15 +1811,14 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
     ++sim_epochs;
     phase_generate_moves(c, burnin_completed);
     trace_stage(c, epoch, 2);
-    barriers_next_state(c);
-    clear_collisions(c);
+    PHASE(c, 7, barriers_next_state(c));
     const bool coll_ok = phase_process_collisions(c);
     trace_stage(c, epoch, 3);
     if (!coll_ok) {
       status = c.error;
       break;
     }
-    phase_extrude_and_release(c, burnin_completed);
+    PHASE(c, 13, phase_extrude_and_release(c, burnin_completed));
     trace_stage(c, epoch, 4);
 #ifdef MODLE_TRACE
     {
@@ -1711,6 +1836,12 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
   }
 
   trace_stage(c, epoch, 6);
+#ifdef MODLE_PHASE_TIMERS
+  if (lds.phase_ticks != nullptr && wave::lane() == 0) {
+    for (int i = 0; i < 16; ++i) wave::atomic_add_u64(lds.phase_ticks + i, c.ph[i]);
+  }
+  wave::lockstep();
+#endif
   res.epochs = epoch;
   res.burnin_epochs = num_burnin_epochs;
   res.num_contacts = num_contacts;
@@ -1769,7 +1900,8 @@ MODLE_DEV u32 run_test_phases(const Params& p, const Interval& iv, const Workspa
                               const WaveLds& lds, const TestImage& img, u32 mask, u32 n,
                               const u64 prng[4], u64& raws_consumed) {
   Cell c;
-  init_cell(c, p, iv, ws, lds, n, prng);
+  const Interval ivg = interval_in_device_memory(iv);
+  init_cell(c, p, ivg, ws, lds, n, prng);
   c.n_active = n;
   const u32 lane = wave::lane();
   // reference layout -> device layout

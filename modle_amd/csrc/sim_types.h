@@ -36,7 +36,11 @@ constexpr u32 CS_TAD = 2u;
 constexpr u32 CS_LOOP = 4u;
 
 // PRNG block generator geometry: every lane produces RNG_CHUNK consecutive outputs per block.
-constexpr u32 RNG_CHUNK = 8;
+// MODLE_WAVES_PER_CU (8 or 16) trades per-wave LDS and registers for resident waves.
+#ifndef MODLE_WAVES_PER_CU
+#define MODLE_WAVES_PER_CU 8
+#endif
+constexpr u32 RNG_CHUNK = MODLE_WAVES_PER_CU > 8 ? 4 : 8;
 constexpr u32 RNG_BLOCK = 64 * RNG_CHUNK;      // raws per block
 constexpr u32 RNG_RING = 2 * RNG_BLOCK;        // raws held in LDS per wave
 constexpr u32 JUMP_TABLE_WORDS = 64 * 16 * 4;  // u64 words (32 KiB)
@@ -135,9 +139,10 @@ struct WaveLds {
   u32* stage;             // STAGE_CAP words (staged slice of sorted positions)
   u64* trace;             // optional per-epoch trace (4 words per epoch) or nullptr
   u32 trace_cap;          // epochs the trace buffer holds
+  u64* phase_ticks;       // profiling build: 16 per-phase tick counters (device memory) or nullptr
 };
-constexpr u32 LIST_CAP = 256;
-constexpr u32 SORT_LDS_CAP = 512;
+constexpr u32 LIST_CAP = 64;
+constexpr u32 SORT_LDS_CAP = MODLE_WAVES_PER_CU > 8 ? 256 : 512;
 constexpr u32 STAGE_CAP = 256;
 
 }  // namespace modle_dev

@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 #define MODLE_DEV __device__ __forceinline__
+#define MODLE_DEV_MEMBER __device__ __forceinline__
 // Phase functions are inlined into the kernel by default: a wave-uniform value stays in scalar
 // registers across phases and wave-uniform branches compile to scalar branches.  MODLE_OUTLINE
 // turns them into real calls (shorter builds while debugging).
@@ -21,7 +22,14 @@
 
 namespace wave {
 
-MODLE_DEV unsigned lane() { return __lane_id(); }
+// The lane id is laundered through an empty asm statement: every phase gets a fresh opaque
+// value, so the optimizer cannot hoist the per-lane address arithmetic of all phases out of the
+// epoch loop (which kept hundreds of registers live and spilled them to scratch).
+MODLE_DEV unsigned lane() {
+  unsigned l = __lane_id();
+  asm volatile("" : "+v"(l));
+  return l;
+}
 MODLE_DEV uint64_t ballot(bool p) { return __ballot(p); }
 MODLE_DEV bool any(bool p) { return __ballot(p) != 0; }
 
@@ -29,6 +37,14 @@ template <class T>
 MODLE_DEV T shfl(T v, unsigned src) {
   return __shfl(v, static_cast<int>(src), 64);
 }
+// Declares that a pointer (read from a struct or from memory, where the compiler only knows a
+// generic address) points to device memory: accesses through the result are global_* instead
+// of flat_* instructions (scalar base + lane offset addressing, no coupling with LDS traffic).
+template <class T>
+MODLE_DEV T* as_global(T* p) {
+  return (T*)((__attribute__((address_space(1))) T*)p);
+}
+
 // Declares a value that is identical in all lanes to the compiler (v_readfirstlane): it then lives
 // in scalar registers and branches on it are scalar branches instead of exec-mask regions.  (The
 // CPU lane emulator checks that the lanes really agree.)
@@ -88,6 +104,9 @@ MODLE_DEV void sync_mem() {
 // Lanes run in lockstep on hardware: only a compiler-level scheduling barrier is needed where one
 // lane overwrites data another lane has just read.  (The emulator yields here.)
 MODLE_DEV void lockstep() { __builtin_amdgcn_wave_barrier(); }
+
+// constant-rate (100 MHz) timestamp, for the profiling build
+MODLE_DEV uint64_t clock() { return wall_clock64(); }
 
 MODLE_DEV void atomic_inc_u32(uint32_t* p) { atomicAdd(p, 1u); }
 MODLE_DEV void atomic_add_u64(uint64_t* p, uint64_t v) {

@@ -47,6 +47,7 @@ struct LdsImage {
     l.sort_lds = sort_lds.data();
     l.stage = stage.data();
     l.trace = nullptr;
+    l.phase_ticks = nullptr;
     l.trace_cap = 0;
     return l;
   }

@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
     uint64_t x = 12345;
     for (uint64_t pos = 20000; pos + 20000 < size; pos += 30000 + (x = x * 6364136223846793005ull + 1442695040888963407ull) % 90000) {
       bp.push_back(pos);
-      bd.push_back(((x >> 40) & 1) ? '+' : '-');
+      bd.push_back(((x >> 40) & 1) ? MODLE_HIP_DIR_FWD : MODLE_HIP_DIR_REV);
       sa.push_back(modle_hip_stp_active_from_occupancy(cfg.barrier_not_occupied_stp, 0.6 + 0.3 * ((x >> 20) % 100) / 100.0));
       si.push_back(cfg.barrier_not_occupied_stp);
     }

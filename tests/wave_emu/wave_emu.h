@@ -15,6 +15,7 @@
 #include <string.h>
 
 #define MODLE_DEV static inline __attribute__((always_inline))
+#define MODLE_DEV_MEMBER inline __attribute__((always_inline))
 #define MODLE_DEV_NOINLINE static __attribute__((noinline))
 
 namespace wave_emu {
@@ -115,6 +116,9 @@ template <class T>
 MODLE_DEV T bcast(T v, unsigned src, int line = __builtin_LINE()) {
   return shfl(v, src, line);
 }
+template <class T>
+MODLE_DEV T* as_global(T* p) { return p; }
+
 // the value must be identical in all lanes (checked)
 template <class T>
 MODLE_DEV T uniform(T v, int line = __builtin_LINE()) {
@@ -146,6 +150,8 @@ MODLE_DEV T shfl_up(T v, unsigned delta, int line = __builtin_LINE()) {
 
 MODLE_DEV void sync_mem(int line = __builtin_LINE()) { (void)wave_emu::collective(0, 0, line); }
 MODLE_DEV void lockstep(int line = __builtin_LINE()) { (void)wave_emu::collective(0, 0, line); }
+
+MODLE_DEV uint64_t clock() { return 0; }
 
 MODLE_DEV void atomic_inc_u32(uint32_t* p) { __atomic_fetch_add(p, 1u, __ATOMIC_RELAXED); }
 MODLE_DEV void atomic_add_u64(uint64_t* p, uint64_t v) {
