@@ -72,7 +72,7 @@ inline uint32_t coll_to_dev(uint64_t w) {
 }
 inline uint64_t coll_to_abi(uint32_t w) {
   return static_cast<uint64_t>(w & modle_dev::CW_INDEX_MASK) |
-         (static_cast<uint64_t>(w >> modle_dev::CW_SHIFT) << 56);
+         (static_cast<uint64_t>((w >> modle_dev::CW_SHIFT) & modle_dev::CW_EVENT_MASK) << 56);
 }
 
 inline uint32_t pow2_ceil(uint32_t x) {

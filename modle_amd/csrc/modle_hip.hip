@@ -102,7 +102,7 @@ struct BlockLds {
   u64 jump[JUMP_TABLE_WORDS];
   f64 zig[kZigWords];
   u64 ring[kWavesPerBlock][RNG_RING];
-  u32 list[kWavesPerBlock][LIST_CAP];
+  u64 rng_state[kWavesPerBlock][4 * 64];
   u64 sort_keys[kWavesPerBlock][SORT_LDS_CAP];
   u32 stage[kWavesPerBlock][STAGE_CAP];
 };
@@ -110,12 +110,12 @@ struct BlockLds {
 __device__ __forceinline__ WaveLds make_wave_lds(BlockLds& s, int wave_in_block) {
   WaveLds l;
   l.ring = s.ring[wave_in_block];
+  l.rng_state = s.rng_state[wave_in_block];
   l.jump_table = s.jump;
   l.zig_norm_x = s.zig;
   l.zig_norm_y = s.zig + 129;
   l.zig_exp_x = s.zig + 258;
   l.zig_exp_y = s.zig + 258 + 257;
-  l.list = s.list[wave_in_block];
   l.sort_lds = s.sort_keys[wave_in_block];
   l.stage = s.stage[wave_in_block];
   l.phase_ticks = nullptr;
@@ -608,7 +608,7 @@ int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen) {
   {
     static const char* names[16] = {"burnin_stats", "bind", "rank_rev", "rank_fwd", "sample", "gen_moves",
                                     "adjust_moves", "barriers+clear", "boundaries", "lef_bar", "primary",
-                                    "secondary", "fix_secondary", "extrude_release", "(secondary walk)", "(walk iterations)"};
+                                    "secondary", "fix_secondary", "extrude_release", "(moves: rng blocks)", "(moves: exact normal)"};
     u64 ticks[16];
     HIP_TRY(hipMemcpy(ticks, h->d_phase_ticks.p, sizeof(ticks), hipMemcpyDeviceToHost));
     u64 total = 0;

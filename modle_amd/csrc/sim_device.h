@@ -365,11 +365,23 @@ MODLE_DEV_NOINLINE void generate_moves_dir(Cell& c, f64 speed, f64 std) {
     }
     return;
   }
-  for (u32 base = 0; base < n; base += 64) {
+  constexpr u32 UX = 4;  // batches whose loads are in flight together
+  for (u32 group = 0; group < n; group += 64 * UX) {
+    u32 Eq[UX], Sq[UX];
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 i = group + 64 * u + lane;
+      Eq[u] = i < n ? ws.epoch[i] : UNBOUND;
+      Sq[u] = i < n ? rank[i] : 0;
+    }
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+    const u32 base = group + 64 * u;
+    if (base >= n) break;
     const u32 i = base + lane;
     const bool act = i < n;
-    const bool bnd = act && ws.epoch[i] != UNBOUND;
-    const u32 slot = act ? rank[i] : 0;
+    const bool bnd = act && Eq[u] != UNBOUND;
+    const u32 slot = Sq[u];
     // bound LEFs of the batch still waiting for their draw, in id order.  Every pass gives each
     // of them the raw output it would get if all draws before it took the fast path; the first
     // one that needs the slow path is replayed exactly and the ones after it are re-evaluated
@@ -378,7 +390,13 @@ MODLE_DEV_NOINLINE void generate_moves_dir(Cell& c, f64 speed, f64 std) {
     u32 mv = 0;
     while (pending != 0) {
       const u32 ndraw = static_cast<u32>(wave::popc64(pending));
+#ifdef MODLE_PHASE_TIMERS
+      const u64 gm_t0 = wave::clock();
+#endif
       rng_ensure(c.g, ndraw);
+#ifdef MODLE_PHASE_TIMERS
+      c.ph[14] += wave::clock() - gm_t0;
+#endif
       const bool mine = ((pending >> lane) & 1u) != 0;
       const u32 k = static_cast<u32>(wave::popc64(pending & lanemask_lt(lane)));
       u32 bucket;
@@ -396,12 +414,19 @@ MODLE_DEV_NOINLINE void generate_moves_dir(Cell& c, f64 speed, f64 std) {
         const u32 f = static_cast<u32>(wave::ctz64(slow));
         if (mine && lane < f) mv = move_from_normal(unit, speed, std);
         c.g.pos += static_cast<u32>(wave::popc64(pending & lanemask_lt(f)));
+#ifdef MODLE_PHASE_TIMERS
+        const u64 gm_t1 = wave::clock();
+#endif
         const f64 exact = unit_normal_exact(c.g, c.lds);
+#ifdef MODLE_PHASE_TIMERS
+        c.ph[15] += wave::clock() - gm_t1;
+#endif
         if (lane == f) mv = move_from_normal(exact, speed, std);
         pending &= ~((u64(2) << f) - 1);
       }
     }
     if (act) moves[slot] = mv;
+    }
   }
 }
 
@@ -685,6 +710,14 @@ MODLE_DEV_NOINLINE BoundaryCounts detect_boundaries(Cell& c) {
 // run there; a batch whose units need more than the window falls back to device memory.
 constexpr u32 BAR_WIN = STAGE_CAP / 2;
 
+// Position of the barrier that stalls the unit of rank k (valid where the collision word says
+// LEF-BAR), written by detect_lef_bar for the passes that correct moves.  Lives in ranking
+// scratch, which is idle during the collision passes.
+template <bool FWD>
+MODLE_DEV u32* stalling_barrier_positions(const Workspace& ws) {
+  return FWD ? ws.tmp[4] : ws.tmp[3];
+}
+
 struct BarView {  // barriers [s0, s1) are staged; everything else is read from device memory
   const Interval* iv;
   const u8* active;
@@ -723,6 +756,7 @@ MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
   const u32 major_dir = FWD ? DIR_FWD : DIR_REV;
   const bool trials = !((p.pblock_major == 1.0 || p.pblock_major == 0.0) &&
                         (p.pblock_minor == 1.0 || p.pblock_minor == 0.0));
+  u32* barpos = stalling_barrier_positions<FWD>(ws);
   u32* st_pos = c.lds.stage;
   u32* st_flag = c.lds.stage + BAR_WIN;
   // first / last rank that takes part
@@ -792,7 +826,7 @@ MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
         st_flag[t] = static_cast<u32>(ws.bar_active[b] != 0) | (static_cast<u32>(iv.bar_dir[b]) << 1);
       }
     }
-    wave::sync_mem();
+    wave::sync_lds();
     // window of barrier indices [b_lo, b_hi) of this unit.  Searches start inside the staged
     // range and continue in device memory when they run off its edge (BarView handles both).
     u32 b_lo = 0, b_hi = 0;
@@ -833,6 +867,7 @@ MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
     }
     if (total != 0) rng_ensure(c.g, total);
     u32 winner = 0xFFFFFFFFu;
+    bool winner_hard = false;
     u32 t = 0;
     for (u32 q = b_lo; q < b_hi; ++q) {
       const u32 b = FWD ? (b_hi - 1 - (q - b_lo)) : q;  // reference visiting order
@@ -848,9 +883,15 @@ MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
         hit = bernoulli_raw(rng_peek(c.g, c.g.pos + off + t), pb);
         ++t;
       }
-      if (hit) winner = b;  // later visits overwrite earlier ones
+      if (hit) {  // later visits overwrite earlier ones
+        winner = b;
+        winner_hard = (fl >> 1) == major_dir;
+      }
     }
-    if (winner != 0xFFFFFFFFu) coll[k] = cw_make(winner, EV_COLLISION | EV_LEF_BAR);
+    if (winner != 0xFFFFFFFFu) {
+      coll[k] = cw_make(winner, EV_COLLISION | EV_LEF_BAR) | (winner_hard ? CW_HARD : 0u);
+      barpos[k] = v.pos(winner);
+    }
     c.g.pos += total;
     carry_pos = wave::bcast(P, 63);
     // where the next batch continues: past the last bound unit's window (rev) / below it (fwd)
@@ -923,7 +964,7 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
     const u32 w0 = carry_pf > 0 ? carry_pf - 1 : 0;
     wave::lockstep();
     for (u32 t = lane; t < STAGE_CAP; t += 64) stage[t] = (w0 + t < n) ? ws.f_pos[w0 + t] : UNBOUND;
-    wave::sync_mem();
+    wave::sync_lds();
     u32 pf = 0;
     if (act) {
       u32 lo = 0, hi = STAGE_CAP;
@@ -1061,11 +1102,11 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
                                 bool& overflow, bool correct_lef_bar, bool do_secondary) {
   Workspace& ws = c.ws;
   const Params& p = *c.p;
-  const Interval& iv = *c.iv;
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
   const u32* pos = FWD ? ws.f_pos : ws.r_pos;
   const u32* ids = FWD ? ws.f_id : ws.r_id;
+  const u32* barpos = stalling_barrier_positions<FWD>(ws);
   u32* moves = FWD ? ws.f_move : ws.r_move;
   u32* coll = FWD ? ws.f_coll : ws.r_coll;
   const bool trials = p.p_bypass != 0.0;
@@ -1079,88 +1120,108 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
   // ranks from f_first on (in visiting order) can be followers
   u32 carry_pos = 0, carry_move = 0, carry_coll = 0, carry_id = 0;
   const u32 nbatch = (n + 63) / 64;
-  for (u32 bi = 0; bi < nbatch; ++bi) {
-    const i64 kk = FWD ? static_cast<i64>(n) - 1 - static_cast<i64>(bi) * 64 - lane
-                       : static_cast<i64>(bi) * 64 + lane;
-    const bool act = kk >= 0 && kk < static_cast<i64>(n);
-    const u32 k = act ? static_cast<u32>(kk) : 0;
-    const u32 P = act ? pos[k] : 0;
-    const u32 id = act ? ids[k] : 0;
-    const u32 M0 = act ? moves[k] : 0;
-    const u32 C0 = act ? coll[k] : 0;
-    u32 M = M0, C = C0;
-    if (correct_lef_bar && act && cw_occurred_as(C, EV_LEF_BAR)) {
-      const u32 bp = iv.bar_pos[cw_index(C)];
-      M = (FWD ? bp - P : P - bp) - 1;
+  constexpr u32 UX = 4;  // batches whose loads are in flight together
+  for (u32 bg = 0; bg < nbatch; bg += UX) {
+    u32 Pq[UX], Iq[UX], Mq[UX], Cq[UX], Bq[UX];
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 bi = bg + u;
+      const i64 kk = FWD ? static_cast<i64>(n) - 1 - static_cast<i64>(bi) * 64 - lane
+                         : static_cast<i64>(bi) * 64 + lane;
+      const bool act = kk >= 0 && kk < static_cast<i64>(n);
+      const u32 k = act ? static_cast<u32>(kk) : 0;
+      Pq[u] = act ? pos[k] : 0;
+      Iq[u] = act ? ids[k] : 0;
+      Mq[u] = act ? moves[k] : 0;
+      Cq[u] = act ? coll[k] : 0;
+      Bq[u] = act ? barpos[k] : 0;
     }
-    const bool follower = do_secondary && act && (FWD ? (kk <= f_first) : (kk >= f_first));
-    // vector pre-filter: follower free and able to reach the blocker's current position
-    const u32 bp_in = wave::shfl_up(P, 1);
-    const u32 blocker_pos = lane > 0 ? bp_in : carry_pos;
-    const bool pot = follower && !cw_occurred(C) &&
-                     (FWD ? static_cast<u64>(P) + M >= blocker_pos
-                          : static_cast<u64>(P) - M <= blocker_pos);
-    // A follower only needs the serial walk when its blocker is stalled already, or may become
-    // stalled during the walk because it is a candidate itself (cascade): propagate "blocker
-    // may be stalled" along runs of consecutive candidates with scalar bit operations.
-    const u64 potm = wave::ballot(pot);
-    const bool blk_occ_in = wave::shfl_up(cw_occurred(C), 1);
-    const u64 occm = wave::ballot(lane > 0 ? blk_occ_in : cw_occurred(carry_coll));
-    u64 todo = potm & occm;
-    for (;;) {
-      const u64 grown = todo | (potm & (todo << 1));
-      if (grown == todo) break;
-      todo = grown;
-    }
-#ifdef MODLE_PHASE_TIMERS
-    const u64 walk_t0 = wave::clock();
-    c.ph[15] += static_cast<u64>(wave::popc64(todo));
-#endif
-    while (todo != 0) {
-      const u32 l = static_cast<u32>(wave::ctz64(todo));
-      todo &= todo - 1;
-      // blocker = lane l-1 (current register state) or the carried unit
-      const u32 bP = l > 0 ? wave::bcast(P, l - 1) : carry_pos;
-      const u32 bM = l > 0 ? wave::bcast(M, l - 1) : carry_move;
-      const u32 bC = l > 0 ? wave::bcast(C, l - 1) : carry_coll;
-      const u32 bId = l > 0 ? wave::bcast(id, l - 1) : carry_id;
-      const u32 fP = wave::bcast(P, l);
-      const u32 fM = wave::bcast(M, l);
-      const u32 fK = wave::bcast(k, l);
-      if (!cw_occurred(bC)) continue;
-      const bool geo = FWD ? (static_cast<u64>(fP) + fM >= static_cast<u64>(bP) + bM)
-                           : (static_cast<u64>(fP) - fM <= static_cast<u64>(bP) - bM);
-      if (!geo) continue;
-      bool collide = true;
-      if (trials) collide = bernoulli_raw(rng_next(c.g), p_collide);
-      if (collide) {
-        const u32 move = FWD ? (bP + bM) - fP : fP - (bP - bM);
-        const u32 newM = umin(move, move - 1);
-        if (lane == l) {
-          M = newM;
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 bi = bg + u;
+      if (bi >= nbatch) break;
+      const i64 kk = FWD ? static_cast<i64>(n) - 1 - static_cast<i64>(bi) * 64 - lane
+                         : static_cast<i64>(bi) * 64 + lane;
+      const bool act = kk >= 0 && kk < static_cast<i64>(n);
+      const u32 k = act ? static_cast<u32>(kk) : 0;
+      const u32 P = Pq[u], id = Iq[u], M0 = Mq[u], C0 = Cq[u];
+      u32 M = M0, C = C0;
+      if (correct_lef_bar && act && cw_occurred_as(C, EV_LEF_BAR)) {
+        const u32 bp = Bq[u];
+        M = (FWD ? bp - P : P - bp) - 1;
+      }
+      const bool follower = do_secondary && act && (FWD ? (kk <= f_first) : (kk >= f_first));
+      // vector pre-filter: follower free and able to reach the blocker's current position
+      const u32 bp_in = wave::shfl_up(P, 1);
+      const u32 blocker_pos = lane > 0 ? bp_in : carry_pos;
+      const bool pot = follower && !cw_occurred(C) &&
+                       (FWD ? static_cast<u64>(P) + M >= blocker_pos
+                            : static_cast<u64>(P) - M <= blocker_pos);
+      // A follower only needs a closer look when its blocker is stalled already, or may become
+      // stalled in this pass because it is a candidate itself (cascade): propagate "blocker may
+      // be stalled" along runs of consecutive candidates with scalar bit operations.
+      const u64 potm = wave::ballot(pot);
+      const bool blk_occ_in = wave::shfl_up(cw_occurred(C), 1);
+      const u64 occm = wave::ballot(lane > 0 ? blk_occ_in : cw_occurred(carry_coll));
+      u64 pend = potm & occm;
+      for (;;) {
+        const u64 grown = pend | (potm & (pend << 1));
+        if (grown == pend) break;
+        pend = grown;
+      }
+      // Rounds: a pending lane is ready when its blocker (the lane before it) is not pending any
+      // more; all ready lanes below the first lane that still waits are resolved together, their
+      // Bernoulli draws numbered in lane order (the reference's visiting order).  A batch
+      // without cascades takes one round.
+      while (pend != 0) {
+        const u32 bP_in = wave::shfl_up(P, 1), bM_in = wave::shfl_up(M, 1);
+        const u32 bC_in = wave::shfl_up(C, 1), bI_in = wave::shfl_up(id, 1);
+        const u32 bP = lane > 0 ? bP_in : carry_pos;
+        const u32 bM = lane > 0 ? bM_in : carry_move;
+        const u32 bC = lane > 0 ? bC_in : carry_coll;
+        const u32 bId = lane > 0 ? bI_in : carry_id;
+        const u64 ready = pend & ~(pend << 1);
+        const u64 waiting = pend & ~ready;
+        const u64 now =
+            waiting != 0 ? (ready & lanemask_lt(static_cast<u32>(wave::ctz64(waiting)))) : ready;
+        const bool mine = ((now >> lane) & 1u) != 0;
+        const bool geo = FWD ? (static_cast<u64>(P) + M >= static_cast<u64>(bP) + bM)
+                             : (static_cast<u64>(P) - M <= static_cast<u64>(bP) - bM);
+        const bool draws = mine && cw_occurred(bC) && geo;
+        const u64 dm = wave::ballot(draws);
+        bool collide = draws;
+        if (trials && dm != 0) {
+          const u32 cnt = static_cast<u32>(wave::popc64(dm));
+          rng_ensure(c.g, cnt);
+          const u32 t = static_cast<u32>(wave::popc64(dm & lanemask_lt(lane)));
+          collide = draws && bernoulli_raw(rng_peek(c.g, c.g.pos + t), p_collide);
+          c.g.pos += cnt;
+        }
+        const bool avoided = draws && !collide;
+        if (collide) {
+          const u32 move = FWD ? (bP + bM) - P : P - (bP - bM);
+          M = umin(move, move - 1);
           C = cw_make(bId, EV_COLLISION | EV_LEF_LEF_SECONDARY);
         }
-      } else {
-        if (lane == l) C = cw_make(bId, EV_LEF_LEF_SECONDARY);
-        if (n_list < list_cap) {
-          if (lane == 0) list[n_list] = fK;
-        } else {
-          overflow = true;
+        const u64 am = wave::ballot(avoided);
+        if (avoided) {
+          C = cw_make(bId, EV_LEF_LEF_SECONDARY);
+          const u32 j = n_list + static_cast<u32>(wave::popc64(am & lanemask_lt(lane)));
+          if (j < list_cap) list[j] = k;
         }
-        ++n_list;
+        n_list += static_cast<u32>(wave::popc64(am));
+        if (n_list > list_cap) overflow = true;
+        pend &= ~now;
       }
+      if (act && (M != M0 || C != C0)) {
+        moves[k] = M;
+        coll[k] = C;
+      }
+      carry_pos = wave::bcast(P, 63);
+      carry_move = wave::bcast(M, 63);
+      carry_coll = wave::bcast(C, 63);
+      carry_id = wave::bcast(id, 63);
     }
-#ifdef MODLE_PHASE_TIMERS
-    c.ph[14] += wave::clock() - walk_t0;
-#endif
-    if (act && (M != M0 || C != C0)) {
-      moves[k] = M;
-      coll[k] = C;
-    }
-    carry_pos = wave::bcast(P, 63);
-    carry_move = wave::bcast(M, 63);
-    carry_coll = wave::bcast(C, 63);
-    carry_id = wave::bcast(id, 63);
   }
   wave::sync_mem();
   return n_list;
@@ -1266,19 +1327,35 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
   // independent); units stalled by a barrier that blocks their own direction ("hard" stalls)
   // are reported to their LEF through stall[id].  The collision words are consumed here, so
   // they are cleared on the way (the next epoch starts with clean arrays).
-  for (u32 base = 0; base < n; base += 64) {
-    const u32 k = base + lane;
-    if (k < n) {
-      const u32 rP = ws.r_pos[k], rM = ws.r_move[k], rc = ws.r_coll[k];
-      const u32 fP = ws.f_pos[k], fM = ws.f_move[k], fc = ws.f_coll[k];
-      if (rP != UNBOUND) ws.r_pos[k] = rP - rM;
-      if (fP != UNBOUND) ws.f_pos[k] = fP + fM;
-      if (rc != 0) ws.r_coll[k] = 0;
-      if (fc != 0) ws.f_coll[k] = 0;
-      if (rP != UNBOUND && cw_occurred_as(rc, EV_LEF_BAR) && c.iv->bar_dir[cw_index(rc)] == DIR_REV)
-        wave::atomic_inc_u32(&ws.stall[ws.r_id[k]]);
-      if (fP != UNBOUND && cw_occurred_as(fc, EV_LEF_BAR) && c.iv->bar_dir[cw_index(fc)] == DIR_FWD)
-        wave::atomic_inc_u32(&ws.stall[ws.f_id[k]]);
+  constexpr u32 UX = 4;  // batches whose loads are in flight together
+  for (u32 base = 0; base < n; base += 64 * UX) {
+    u32 rP[UX], rM[UX], rc[UX], fP[UX], fM[UX], fc[UX], rI[UX], fI[UX];
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 k = base + 64 * u + lane;
+      const bool act = k < n;
+      rP[u] = act ? ws.r_pos[k] : UNBOUND;
+      rM[u] = act ? ws.r_move[k] : 0;
+      rc[u] = act ? ws.r_coll[k] : 0;
+      rI[u] = act ? ws.r_id[k] : 0;
+      fP[u] = act ? ws.f_pos[k] : UNBOUND;
+      fM[u] = act ? ws.f_move[k] : 0;
+      fc[u] = act ? ws.f_coll[k] : 0;
+      fI[u] = act ? ws.f_id[k] : 0;
+    }
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 k = base + 64 * u + lane;
+      if (k < n) {
+        if (rP[u] != UNBOUND) ws.r_pos[k] = rP[u] - rM[u];
+        if (fP[u] != UNBOUND) ws.f_pos[k] = fP[u] + fM[u];
+        if (rc[u] != 0) ws.r_coll[k] = 0;
+        if (fc[u] != 0) ws.f_coll[k] = 0;
+        if (rP[u] != UNBOUND && cw_occurred_as(rc[u], EV_LEF_BAR) && (rc[u] & CW_HARD))
+          wave::atomic_inc_u32(&ws.stall[rI[u]]);
+        if (fP[u] != UNBOUND && cw_occurred_as(fc[u], EV_LEF_BAR) && (fc[u] & CW_HARD))
+          wave::atomic_inc_u32(&ws.stall[fI[u]]);
+      }
     }
   }
   wave::sync_mem();
@@ -1702,6 +1779,7 @@ MODLE_DEV void init_cell(Cell& c, const Params& p, const Interval& iv, const Wor
 #endif
   c.g.ring = lds.ring;
   c.g.jump = lds.jump_table;
+  c.g.state = lds.rng_state;
   rng_init(c.g, prng);
 }
 
@@ -1923,6 +2001,17 @@ MODLE_DEV u32 run_test_phases(const Params& p, const Interval& iv, const Workspa
       c.ws.f_rank[fid] = k;
       c.ws.epoch[k] = img.epoch[k];
       c.ws.stall[k] = 0;
+    }
+  }
+  wave::sync_mem();
+  // barrier positions of LEF-BAR words that came with the image (detect_lef_bar writes them
+  // itself when it runs)
+  for (u32 base = 0; base < n; base += 64) {
+    const u32 k = base + lane;
+    if (k < n) {
+      const u32 rc = c.ws.r_coll[k], fc = c.ws.f_coll[k];
+      if (cw_occurred_as(rc, EV_LEF_BAR)) stalling_barrier_positions<false>(c.ws)[k] = stalling_barrier_pos(ivg, rc);
+      if (cw_occurred_as(fc, EV_LEF_BAR)) stalling_barrier_positions<true>(c.ws)[k] = stalling_barrier_pos(ivg, fc);
     }
   }
   wave::sync_mem();

@@ -26,7 +26,7 @@ namespace modle_dev {
 // =============================================================================================
 MODLE_DEV u64 lanemask_lt(u32 lane) { return (u64(1) << lane) - 1; }
 MODLE_DEV u32 cw_make(u32 idx, u32 ev) { return (idx & CW_INDEX_MASK) | (ev << CW_SHIFT); }
-MODLE_DEV u32 cw_event(u32 c) { return c >> CW_SHIFT; }
+MODLE_DEV u32 cw_event(u32 c) { return (c >> CW_SHIFT) & CW_EVENT_MASK; }
 MODLE_DEV u32 cw_index(u32 c) { return c & CW_INDEX_MASK; }
 MODLE_DEV bool cw_occurred(u32 c) { return (cw_event(c) & EV_COLLISION) != 0; }
 MODLE_DEV bool cw_occurred_as(u32 c, u32 what) { return cw_event(c) == (what | EV_COLLISION); }
@@ -46,9 +46,10 @@ constexpr f64 DBL_EPS = 2.220446049250313e-16;
 // PRNG: xoshiro256++ block generator (reference stream: random.hpp:26-32)
 // =============================================================================================
 struct Rng {
-  u64 s0, s1, s2, s3;  // per lane: state at the start of this lane's chunk of the NEXT block
   u64* ring;           // RNG_RING raws (LDS)
   const u64* jump;     // T^RNG_BLOCK nibble table (LDS)
+  u64* state;          // per lane xoshiro state at the start of its chunk of the NEXT block:
+                       // word w of lane l at state[w * 64 + l] (LDS)
   u64 gen_end;         // uniform: raws [gen_end - RNG_RING, gen_end) are in the ring
   u64 pos;             // uniform: stream position of the next raw to be consumed
 };
@@ -74,53 +75,79 @@ MODLE_DEV u32 ring_index(u64 p) {
   return blk * RNG_BLOCK + (off ^ ((off / RNG_CHUNK) & (RNG_CHUNK - 1)));
 }
 
-MODLE_DEV void rng_jump(Rng& g) {
-  u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-  const u64 w[4] = {g.s0, g.s1, g.s2, g.s3};
-#pragma unroll
-  for (int wi = 0; wi < 4; ++wi) {
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const u32 v = static_cast<u32>(w[wi] >> (4 * k)) & 15u;
-      const u64* row = g.jump + ((wi * 16 + k) * 16 + v) * 4;
-      a0 ^= row[0];
-      a1 ^= row[1];
-      a2 ^= row[2];
-      a3 ^= row[3];
-    }
-  }
-  g.s0 = a0;
-  g.s1 = a1;
-  g.s2 = a2;
-  g.s3 = a3;
-}
-
-MODLE_DEV_NOINLINE void rng_gen_block(Rng& g) {
-  wave::lockstep();  // other lanes may still be reading the block that is about to be replaced
+// Produces one block of the stream: every lane emits its RNG_CHUNK outputs into the ring half
+// `ring_base` and hops to its chunk of the next block (state <- T^RNG_BLOCK * state through the
+// nibble table).  A real call: it is reached from every phase that draws, and its registers
+// stay out of the callers' allocation.
+MODLE_DEV_CALL void rng_gen_block_call(MODLE_LDS u64* ring, const MODLE_LDS u64* jump,
+                                       MODLE_LDS u64* state, u32 ring_base) {
   const u32 lane = wave::lane();
-  u64 a0 = g.s0, a1 = g.s1, a2 = g.s2, a3 = g.s3;
-  const u32 base = ((static_cast<u32>(g.gen_end) / RNG_BLOCK) & 1u) * RNG_BLOCK + RNG_CHUNK * lane;
+  u64 a0 = state[0 * 64 + lane], a1 = state[1 * 64 + lane], a2 = state[2 * 64 + lane],
+      a3 = state[3 * 64 + lane];
+  const u64 w[4] = {a0, a1, a2, a3};
+  const u32 base = ring_base + RNG_CHUNK * lane;
 #pragma unroll
   for (u32 t = 0; t < RNG_CHUNK; ++t) {
-    g.ring[base + (t ^ (lane & (RNG_CHUNK - 1)))] = xo_next(a0, a1, a2, a3);
+    ring[base + (t ^ (lane & (RNG_CHUNK - 1)))] = xo_next(a0, a1, a2, a3);
   }
-  rng_jump(g);
+  // T^RNG_BLOCK * state: XOR of one table row per state nibble.  The rows are fetched in groups
+  // (all loads of a group in flight, then folded) -- left alone the compiler waits for every
+  // LDS load before issuing the next one.
+  u64 j0 = 0, j1 = 0, j2 = 0, j3 = 0;
+  constexpr int GROUP = 4;
+#pragma unroll
+  for (int g = 0; g < 64 / GROUP; ++g) {
+    u64 r[GROUP][4];
+#pragma unroll
+    for (int q = 0; q < GROUP; ++q) {
+      const int nib = g * GROUP + q;  // nibble k of state word wi
+      const int wi = nib / 16, k = nib % 16;
+      const u32 v = static_cast<u32>(w[wi] >> (4 * k)) & 15u;
+      const MODLE_LDS u64* row = jump + ((wi * 16 + k) * 16 + v) * 4;
+      r[q][0] = row[0];
+      r[q][1] = row[1];
+      r[q][2] = row[2];
+      r[q][3] = row[3];
+    }
+    wave::sched_fence();
+#pragma unroll
+    for (int q = 0; q < GROUP; ++q) {
+      j0 ^= r[q][0];
+      j1 ^= r[q][1];
+      j2 ^= r[q][2];
+      j3 ^= r[q][3];
+    }
+    wave::sched_fence();
+  }
+  state[0 * 64 + lane] = j0;
+  state[1 * 64 + lane] = j1;
+  state[2 * 64 + lane] = j2;
+  state[3 * 64 + lane] = j3;
+}
+
+MODLE_DEV void rng_gen_block(Rng& g) {
+  wave::lockstep();  // other lanes may still be reading the block that is about to be replaced
+  rng_gen_block_call((MODLE_LDS u64*)g.ring, (const MODLE_LDS u64*)g.jump, (MODLE_LDS u64*)g.state,
+                     ((static_cast<u32>(g.gen_end) / RNG_BLOCK) & 1u) * RNG_BLOCK);
   g.gen_end += RNG_BLOCK;
-  wave::sync_mem();
+  wave::sync_lds();
 }
 
 MODLE_DEV void rng_init(Rng& g, const u64 state[4]) {
   const u32 lane = wave::lane();
-  g.s0 = state[0];
-  g.s1 = state[1];
-  g.s2 = state[2];
-  g.s3 = state[3];
+  u64 s0 = state[0], s1 = state[1], s2 = state[2], s3 = state[3];
   // lane l starts RNG_CHUNK * l outputs into the stream
   for (u32 k = 0; k < RNG_CHUNK * 63; ++k) {
-    if (k < RNG_CHUNK * lane) (void)xo_next(g.s0, g.s1, g.s2, g.s3);
+    if (k < RNG_CHUNK * lane) (void)xo_next(s0, s1, s2, s3);
   }
+  wave::lockstep();
+  g.state[0 * 64 + lane] = s0;
+  g.state[1 * 64 + lane] = s1;
+  g.state[2 * 64 + lane] = s2;
+  g.state[3 * 64 + lane] = s3;
   g.gen_end = 0;
   g.pos = 0;
+  wave::sync_lds();
 }
 
 // makes raws [pos, pos + k) readable (k <= RNG_BLOCK); uniform

@@ -23,6 +23,10 @@ constexpr u32 UNBOUND = 0xFFFFFFFFu;
 // bits, the 5 event flags above them.
 constexpr u32 CW_SHIFT = 24;
 constexpr u32 CW_INDEX_MASK = 0x00FFFFFFu;
+constexpr u32 CW_EVENT_MASK = 0x1Fu;
+// device-only annotation above the event bits: the barrier of this LEF-BAR collision blocks the
+// unit's own direction (a "hard" stall for release_lefs, reference: simulation.cpp:553-601)
+constexpr u32 CW_HARD = 0x20000000u;
 constexpr u32 EV_COLLISION = 0x10u;
 constexpr u32 EV_CHROM_BOUNDARY = 0x08u;
 constexpr u32 EV_LEF_BAR = 0x04u;
@@ -129,19 +133,18 @@ constexpr u32 NEW_MARK = 0xFFFFFFFFu;
 // LDS-resident (or host-emulated) per-wave context.
 struct WaveLds {
   u64* ring;              // RNG_RING raws
+  u64* rng_state;         // xoshiro256++ state of every lane: 4 x 64 words (word-major)
   const u64* jump_table;  // T^RNG_BLOCK nibble table
   const f64* zig_norm_x;  // 129
   const f64* zig_norm_y;  // 129
   const f64* zig_exp_x;   // 257
   const f64* zig_exp_y;   // 257
-  u32* list;              // small per-wave list (LIST_CAP entries)
   u64* sort_lds;          // SORT_LDS_CAP keys (ranking of newly bound units)
   u32* stage;             // STAGE_CAP words (staged slice of sorted positions)
   u64* trace;             // optional per-epoch trace (4 words per epoch) or nullptr
   u32 trace_cap;          // epochs the trace buffer holds
   u64* phase_ticks;       // profiling build: 16 per-phase tick counters (device memory) or nullptr
 };
-constexpr u32 LIST_CAP = 64;
 constexpr u32 SORT_LDS_CAP = MODLE_WAVES_PER_CU > 8 ? 256 : 512;
 constexpr u32 STAGE_CAP = 256;
 

@@ -10,6 +10,11 @@
 #include <stdint.h>
 
 #define MODLE_DEV __device__ __forceinline__
+// a real call even in the default build (large, rarely changing helpers: keeps the kernel small)
+#define MODLE_DEV_CALL __device__ __noinline__
+// pointer into LDS with an explicit address space (needed across a real call, where the
+// compiler cannot infer it)
+#define MODLE_LDS __attribute__((address_space(3)))
 #define MODLE_DEV_MEMBER __device__ __forceinline__
 // Phase functions are inlined into the kernel by default: a wave-uniform value stays in scalar
 // registers across phases and wave-uniform branches compile to scalar branches.  MODLE_OUTLINE
@@ -101,9 +106,19 @@ MODLE_DEV void sync_mem() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
 }
+// Same for data exchanged through LDS only.  LDS operations of one wave execute in order, so no
+// wait is needed: this is a compiler-level ordering point (it does not wait for outstanding
+// device-memory traffic the way sync_mem does).
+MODLE_DEV void sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 // Lanes run in lockstep on hardware: only a compiler-level scheduling barrier is needed where one
 // lane overwrites data another lane has just read.  (The emulator yields here.)
 MODLE_DEV void lockstep() { __builtin_amdgcn_wave_barrier(); }
+
+// the instruction scheduler may not move anything across this point
+MODLE_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
 // constant-rate (100 MHz) timestamp, for the profiling build
 MODLE_DEV uint64_t clock() { return wall_clock64(); }

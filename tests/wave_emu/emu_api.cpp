@@ -31,19 +31,19 @@ namespace {
 
 struct LdsImage {
   std::vector<u64> ring;
+  std::vector<u64> rng_state;
   std::vector<u64> jump;
-  std::vector<u32> list;
   std::vector<u64> sort_lds;
   std::vector<u32> stage;
   WaveLds view() {
     WaveLds l;
     l.ring = ring.data();
+    l.rng_state = rng_state.data();
     l.jump_table = jump.data();
     l.zig_norm_x = ZIG_NORM_X;
     l.zig_norm_y = ZIG_NORM_Y;
     l.zig_exp_x = ZIG_EXP_X;
     l.zig_exp_y = ZIG_EXP_Y;
-    l.list = list.data();
     l.sort_lds = sort_lds.data();
     l.stage = stage.data();
     l.trace = nullptr;
@@ -53,13 +53,12 @@ struct LdsImage {
   }
   LdsImage()
       : ring(RNG_RING),
+        rng_state(4 * 64),
         jump(modle_host::build_jump_table(RNG_BLOCK)),
-        list(LIST_CAP),
         sort_lds(SORT_LDS_CAP),
         stage(STAGE_CAP) {
     // on the device these scratch regions start with whatever the previous kernel left there
     EMU_MARK_UNINIT(ring.data(), ring.size() * 8);
-    EMU_MARK_UNINIT(list.data(), list.size() * 4);
     EMU_MARK_UNINIT(sort_lds.data(), sort_lds.size() * 8);
     EMU_MARK_UNINIT(stage.data(), stage.size() * 4);
   }
@@ -173,7 +172,6 @@ int emu_simulate_interval(const modle_hip_config* cfg, uint64_t start, uint64_t 
   std::vector<uint64_t> wsmem(layout.total_bytes / 8 + 1, 0xDEADBEEFCAFEF00Dull);
   EMU_MARK_UNINIT(wsmem.data(), wsmem.size() * 8);
   std::fill(lds.ring.begin(), lds.ring.end(), 0xDEADBEEFCAFEF00Dull);
-  std::fill(lds.list.begin(), lds.list.end(), 0xDEADBEEFu);
   std::fill(lds.sort_lds.begin(), lds.sort_lds.end(), 0xDEADBEEFCAFEF00Dull);
   std::fill(lds.stage.begin(), lds.stage.end(), 0xDEADBEEFu);
   int rc = MODLE_HIP_OK;

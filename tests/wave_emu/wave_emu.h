@@ -15,6 +15,8 @@
 #include <string.h>
 
 #define MODLE_DEV static inline __attribute__((always_inline))
+#define MODLE_DEV_CALL static __attribute__((noinline))
+#define MODLE_LDS
 #define MODLE_DEV_MEMBER inline __attribute__((always_inline))
 #define MODLE_DEV_NOINLINE static __attribute__((noinline))
 
@@ -149,9 +151,11 @@ MODLE_DEV T shfl_up(T v, unsigned delta, int line = __builtin_LINE()) {
 }
 
 MODLE_DEV void sync_mem(int line = __builtin_LINE()) { (void)wave_emu::collective(0, 0, line); }
+MODLE_DEV void sync_lds(int line = __builtin_LINE()) { (void)wave_emu::collective(0, 0, line); }
 MODLE_DEV void lockstep(int line = __builtin_LINE()) { (void)wave_emu::collective(0, 0, line); }
 
 MODLE_DEV uint64_t clock() { return 0; }
+MODLE_DEV void sched_fence() {}
 
 MODLE_DEV void atomic_inc_u32(uint32_t* p) { __atomic_fetch_add(p, 1u, __ATOMIC_RELAXED); }
 MODLE_DEV void atomic_add_u64(uint64_t* p, uint64_t v) {
