@@ -138,6 +138,7 @@ MODLE_DEV u32 pow2_ceil(u32 x) {
   return p;
 }
 
+template <bool IN_LDS>
 MODLE_DEV_NOINLINE void bitonic_sort_u64(u64* keys, u32 m_pow2) {
   const u32 lane = wave::lane();
   const u32 half = m_pow2 / 2;
@@ -156,7 +157,7 @@ MODLE_DEV_NOINLINE void bitonic_sort_u64(u64* keys, u32 m_pow2) {
           }
         }
       }
-      wave::sync_mem();
+      if (IN_LDS) wave::sync_lds(); else wave::sync_mem();
     }
   }
 }
@@ -170,6 +171,76 @@ MODLE_DEV bool rank_pair_out_of_order(const Workspace& ws, const u32* where, u32
   const u32 ea = ws.epoch[ida], eb = ws.epoch[idb];
   if (ea != eb) return FWD ? ea < eb : ea > eb;
   return where[ida] > where[idb];
+}
+
+// Merge step of rank_update: kept units (old_pos / old_id, sorted) and the sorted keys of the new
+// units go to their final ranks; returns true when two bound units share a position.  The
+// loads of the next batch are issued before the (scattered) stores of the current one: on
+// this hardware a wait for a load also waits for every store issued before it.
+template <bool FWD>
+MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_pos,
+                          const u32* old_id, const u32* new_id, u32* out_pos, u32* out_id,
+                          u32* where_new) {
+  const u32 lane = wave::lane();
+  bool ties = false;
+  u32 carry_old = UNBOUND;  // position of the kept unit before this batch (UNBOUND: none)
+  u32 nxt_p = lane < n_old ? old_pos[lane] : UNBOUND;
+  u32 nxt_i = lane < n_old ? old_id[lane] : 0;
+  for (u32 base = 0; base < n_old; base += 64) {
+    const u32 a = base + lane;
+    const bool act = a < n_old;
+    const u32 pp = nxt_p;
+    const u32 oid = nxt_i;
+    const u32 an = a + 64;
+    nxt_p = an < n_old ? old_pos[an] : UNBOUND;
+    nxt_i = an < n_old ? old_id[an] : 0;
+    bool tie = false;
+    if (act) {
+      const u64 thr = FWD ? ((static_cast<u64>(pp) + 1) << 32) : (static_cast<u64>(pp) << 32);
+      u32 lo = 0, hi = n_new;
+      while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if (keys[mid] < thr) lo = mid + 1; else hi = mid;
+      }
+      if (pp != UNBOUND) {
+        if (FWD) {
+          tie = lo > 0 && static_cast<u32>(keys[lo - 1] >> 32) == pp;
+        } else {
+          tie = lo < n_new && static_cast<u32>(keys[lo] >> 32) == pp;
+        }
+      }
+      out_pos[a + lo] = pp;
+      out_id[a + lo] = oid;
+      where_new[oid] = a + lo;
+    }
+    const u32 prev_in = wave::shfl_up(pp, 1);
+    const u32 prev = lane > 0 ? prev_in : carry_old;
+    tie = tie || (act && pp != UNBOUND && prev == pp && (base != 0 || lane != 0));
+    ties = wave::any(tie) || ties;
+    carry_old = wave::bcast(pp, 63);
+  }
+  for (u32 base = 0; base < n_new; base += 64) {
+    const u32 bq = base + lane;
+    bool tie = false;
+    if (bq < n_new) {
+      const u64 key = keys[bq];
+      const u32 pp = static_cast<u32>(key >> 32);
+      u32 lo = 0, hi = n_old;
+      while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        const u32 q = old_pos[mid];
+        const bool before = FWD ? (q < pp) : (q <= pp);
+        if (before) lo = mid + 1; else hi = mid;
+      }
+      const u32 nid = new_id[static_cast<u32>(key)];
+      out_pos[bq + lo] = pp;
+      out_id[bq + lo] = nid;
+      where_new[nid] = bq + lo;
+      tie = bq + 1 < n_new && static_cast<u32>(keys[bq + 1] >> 32) == pp;
+    }
+    ties = wave::any(tie) || ties;
+  }
+  return ties;
 }
 
 // all_new: treat every entry as newly bound (full sort; used by the phase-level test entry point)
@@ -195,6 +266,9 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
   //    the kept sequence is non-decreasing by construction.
   u32 n_old = 0, n_new = 0;
   u32 run_max = 0;  // max position of carried-over units in previous batches
+#ifdef MODLE_PHASE_TIMERS
+  const u64 rk_t0 = wave::clock();
+#endif
   for (u32 base = 0; base < n; base += 64) {
     const u32 k = base + lane;
     const bool act = k < n;
@@ -232,113 +306,85 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
     run_max = umax(run_max, incl_last);
   }
   wave::sync_mem();
+#ifdef MODLE_PHASE_TIMERS
+  c.ph[14] += wave::clock() - rk_t0;
+#endif
   if (n_old + n_new != n) {
     c.error = ERR_INTERNAL;  // cannot happen: every active unit is either carried over or new
     return;
   }
-  // when nothing is new the order is unchanged and step 4 works in place
-  u32* out_pos = n_new != 0 ? ws.tmp[0] : pos;
-  u32* out_id = n_new != 0 ? ws.tmp[1] : ids;
+  // 2. sort the new units by (position, previous rank): in LDS, or in device memory when there
+  //    are more of them than the LDS buffer holds (whole-chromosome rebinding only)
   if (n_new != 0) {
-    // 2. sort the new units by (position, previous rank)
-    u64* keys = keys_lds;
     const u32 m2 = pow2_ceil(n_new);
-    if (n_new > SORT_LDS_CAP) {
-      keys = keys_glb;
+    if (n_new <= SORT_LDS_CAP) {
+      for (u32 base = n_new; base < m2; base += 64) {
+        const u32 k = base + lane;
+        if (k < m2) keys_lds[k] = ~u64(0);
+      }
+      wave::sync_lds();
+      if (m2 > 1) bitonic_sort_u64<true>(keys_lds, m2);
+    } else {
       for (u32 base = 0; base < SORT_LDS_CAP; base += 64) keys_glb[base + lane] = keys_lds[base + lane];
-    }
-    for (u32 base = n_new; base < m2; base += 64) {
-      const u32 k = base + lane;
-      if (k < m2) keys[k] = ~u64(0);
-    }
-    wave::sync_mem();
-    if (m2 > 1) bitonic_sort_u64(keys, m2);
-    // 3. merge by cross-ranking (kept units are sorted; equal positions are ordered in step 4)
-    for (u32 base = 0; base < n_old; base += 64) {
-      const u32 a = base + lane;
-      if (a < n_old) {
-        const u32 p = old_pos[a];
-        const u64 thr = FWD ? ((static_cast<u64>(p) + 1) << 32) : (static_cast<u64>(p) << 32);
-        u32 lo = 0, hi = n_new;
-        while (lo < hi) {
-          const u32 mid = (lo + hi) >> 1;
-          if (keys[mid] < thr) lo = mid + 1; else hi = mid;
-        }
-        out_pos[a + lo] = p;
-        out_id[a + lo] = old_id[a];
-      }
-    }
-    for (u32 base = 0; base < n_new; base += 64) {
-      const u32 b = base + lane;
-      if (b < n_new) {
-        const u64 key = keys[b];
-        const u32 p = static_cast<u32>(key >> 32);
-        u32 lo = 0, hi = n_old;
-        while (lo < hi) {
-          const u32 mid = (lo + hi) >> 1;
-          const u32 q = old_pos[mid];
-          const bool before = FWD ? (q < p) : (q <= p);
-          if (before) lo = mid + 1; else hi = mid;
-        }
-        out_pos[b + lo] = p;
-        out_id[b + lo] = new_id[static_cast<u32>(key)];
-      }
-    }
-    wave::sync_mem();
-  }
-  // 4. order equal positions (epoch rule, then previous rank) with a stable odd-even
-  //    transposition; normally nothing moves
-  bool bad = false;
-  u32 carry_p = 0, carry_i = 0;
-  for (u32 base = 0; base < n; base += 64) {
-    const u32 k = base + lane;
-    const bool act = k < n;
-    const u32 P = act ? out_pos[k] : 0;
-    const u32 I = act ? out_id[k] : 0;
-    const u32 pp_in = wave::shfl_up(P, 1), pi_in = wave::shfl_up(I, 1);
-    const u32 Pp = lane > 0 ? pp_in : carry_p;
-    const u32 Ip = lane > 0 ? pi_in : carry_i;
-    bool b = false;
-    if (act && k >= 1) {
-      if (Pp > P) b = true;
-      else if (Pp == P) b = rank_pair_out_of_order<FWD>(ws, where, Pp, Ip, P, I);
-    }
-    bad = wave::any(b) || bad;
-    carry_p = wave::bcast(P, 63);
-    carry_i = wave::bcast(I, 63);
-  }
-  while (bad) {
-    bad = false;
-    for (u32 parity = 0; parity < 2; ++parity) {
-      for (u32 base = 0; base < n; base += 128) {
-        const u32 k = base + 2 * lane + parity;
-        bool sw = false;
-        if (k + 1 < n) {
-          const u32 pa = out_pos[k], pb = out_pos[k + 1];
-          const u32 ia = out_id[k], ib = out_id[k + 1];
-          if (rank_pair_out_of_order<FWD>(ws, where, pa, ia, pb, ib)) {
-            out_pos[k] = pb;
-            out_pos[k + 1] = pa;
-            out_id[k] = ib;
-            out_id[k + 1] = ia;
-            sw = true;
-          }
-        }
-        bad = wave::any(sw) || bad;
+      for (u32 base = n_new; base < m2; base += 64) {
+        const u32 k = base + lane;
+        if (k < m2) keys_glb[k] = ~u64(0);
       }
       wave::sync_mem();
+      bitonic_sort_u64<false>(keys_glb, m2);
     }
   }
-  // 5. publish: inverse permutation, then the new arrays become current
-  for (u32 base = 0; base < n; base += 64) {
-    const u32 k = base + lane;
-    if (k < n) where[out_id[k]] = k;
-  }
-  if (n_new != 0) {
-    swap_ptr(pos, ws.tmp[0]);
-    swap_ptr(ids, ws.tmp[1]);
-  }
+#ifdef MODLE_PHASE_TIMERS
+  c.ph[15] += wave::clock() - rk_t0;
+#endif
+  // 3. merge by cross-ranking (kept units are sorted) straight into the output arrays and the
+  //    new inverse permutation.  Equal positions of bound units are the only thing this does not
+  //    order completely (epoch rule); they are rare, so they are only flagged here.
+  u32* out_pos = ws.tmp[0];
+  u32* out_id = ws.tmp[1];
+  u32* where_new = ws.tmp[7];
+  const bool ties = (n_new <= SORT_LDS_CAP)
+                        ? rank_merge<FWD>(keys_lds, n_new, n_old, old_pos, old_id, new_id, out_pos,
+                                          out_id, where_new)
+                        : rank_merge<FWD>(keys_glb, n_new, n_old, old_pos, old_id, new_id, out_pos,
+                                          out_id, where_new);
   wave::sync_mem();
+  if (ties) {
+    // 4. order equal positions (epoch rule, then previous rank) with a stable odd-even
+    //    transposition, then rebuild the inverse permutation
+    bool bad = true;
+    while (bad) {
+      bad = false;
+      for (u32 parity = 0; parity < 2; ++parity) {
+        for (u32 base = 0; base < n; base += 128) {
+          const u32 k = base + 2 * lane + parity;
+          bool sw = false;
+          if (k + 1 < n) {
+            const u32 pa = out_pos[k], pb = out_pos[k + 1];
+            const u32 ia = out_id[k], ib = out_id[k + 1];
+            if (rank_pair_out_of_order<FWD>(ws, where, pa, ia, pb, ib)) {
+              out_pos[k] = pb;
+              out_pos[k + 1] = pa;
+              out_id[k] = ib;
+              out_id[k + 1] = ia;
+              sw = true;
+            }
+          }
+          bad = wave::any(sw) || bad;
+        }
+        wave::sync_mem();
+      }
+    }
+    for (u32 base = 0; base < n; base += 64) {
+      const u32 k = base + lane;
+      if (k < n) where_new[out_id[k]] = k;
+    }
+    wave::sync_mem();
+  }
+  // 5. the new arrays become current
+  swap_ptr(pos, ws.tmp[0]);
+  swap_ptr(ids, ws.tmp[1]);
+  if (FWD) swap_ptr(ws.f_rank, ws.tmp[7]); else swap_ptr(ws.r_rank, ws.tmp[7]);
 }
 
 // =============================================================================================
@@ -390,13 +436,7 @@ MODLE_DEV_NOINLINE void generate_moves_dir(Cell& c, f64 speed, f64 std) {
     u32 mv = 0;
     while (pending != 0) {
       const u32 ndraw = static_cast<u32>(wave::popc64(pending));
-#ifdef MODLE_PHASE_TIMERS
-      const u64 gm_t0 = wave::clock();
-#endif
       rng_ensure(c.g, ndraw);
-#ifdef MODLE_PHASE_TIMERS
-      c.ph[14] += wave::clock() - gm_t0;
-#endif
       const bool mine = ((pending >> lane) & 1u) != 0;
       const u32 k = static_cast<u32>(wave::popc64(pending & lanemask_lt(lane)));
       u32 bucket;
@@ -414,13 +454,7 @@ MODLE_DEV_NOINLINE void generate_moves_dir(Cell& c, f64 speed, f64 std) {
         const u32 f = static_cast<u32>(wave::ctz64(slow));
         if (mine && lane < f) mv = move_from_normal(unit, speed, std);
         c.g.pos += static_cast<u32>(wave::popc64(pending & lanemask_lt(f)));
-#ifdef MODLE_PHASE_TIMERS
-        const u64 gm_t1 = wave::clock();
-#endif
         const f64 exact = unit_normal_exact(c.g, c.lds);
-#ifdef MODLE_PHASE_TIMERS
-        c.ph[15] += wave::clock() - gm_t1;
-#endif
         if (lane == f) mv = move_from_normal(exact, speed, std);
         pending &= ~((u64(2) << f) - 1);
       }
@@ -708,7 +742,11 @@ MODLE_DEV_NOINLINE BoundaryCounts detect_boundaries(Cell& c) {
 // where the previous batch stopped.  A window of BAR_WIN barriers (position and a flag word:
 // state, blocking direction) is staged in LDS with one coalesced load and all per-unit searches
 // run there; a batch whose units need more than the window falls back to device memory.
-constexpr u32 BAR_WIN = STAGE_CAP / 2;
+// The window lives in the LDS sort buffer (idle during the collision passes): BAR_WIN positions
+// followed by BAR_WIN flag words.  It is re-staged only when a batch starts closer than BAR_NEED
+// barriers to its far edge.
+constexpr u32 BAR_WIN = SORT_LDS_CAP;  // SORT_LDS_CAP u64 keys = 2 * BAR_WIN words
+constexpr u32 BAR_NEED = 128;
 
 // Position of the barrier that stalls the unit of rank k (valid where the collision word says
 // LEF-BAR), written by detect_lef_bar for the passes that correct moves.  Lives in ranking
@@ -718,27 +756,117 @@ MODLE_DEV u32* stalling_barrier_positions(const Workspace& ws) {
   return FWD ? ws.tmp[4] : ws.tmp[3];
 }
 
-struct BarView {  // barriers [s0, s1) are staged; everything else is read from device memory
+// Barriers [s0, s1) are staged.  STAGED_ONLY accessors assume the index is inside the staged
+// range (the caller has checked that the whole batch stays inside); the general ones read
+// everything else from device memory.
+struct BarView {
   const Interval* iv;
   const u8* active;
   const u32* st_pos;
   const u32* st_flag;
   u32 s0, s1;
-  MODLE_DEV_MEMBER u32 pos(u32 b) const { return (b >= s0 && b < s1) ? st_pos[b - s0] : iv->bar_pos[b]; }
+  template <bool STAGED_ONLY>
+  MODLE_DEV_MEMBER u32 pos(u32 b) const {
+    if (STAGED_ONLY) return st_pos[b - s0];
+    return (b >= s0 && b < s1) ? st_pos[b - s0] : iv->bar_pos[b];
+  }
   // bit 0: active, bits 1..2: blocking direction
+  template <bool STAGED_ONLY>
   MODLE_DEV_MEMBER u32 flag(u32 b) const {
+    if (STAGED_ONLY) return st_flag[b - s0];
     return (b >= s0 && b < s1) ? st_flag[b - s0]
                                : (static_cast<u32>(active[b] != 0) | (static_cast<u32>(iv->bar_dir[b]) << 1));
   }
 };
 
 // first barrier index in [lo, hi) whose position is >= key (hi when there is none)
+template <bool STAGED_ONLY>
 MODLE_DEV u32 bar_view_lower_bound(const BarView& v, u32 lo, u32 hi, u64 key) {
   while (lo < hi) {
     const u32 mid = (lo + hi) >> 1;
-    if (v.pos(mid) < key) lo = mid + 1; else hi = mid;
+    if (v.pos<STAGED_ONLY>(mid) < key) lo = mid + 1; else hi = mid;
   }
   return lo;
+}
+
+// Barrier index window [b_lo, b_hi) of one unit: lo_key <= position < hi_key.  With STAGED_ONLY
+// the search stays inside the staged range and reports `edge` when the answer touches an edge
+// beyond which more barriers exist (the batch is then redone with the general accessors).
+template <bool FWD, bool STAGED_ONLY>
+MODLE_DEV void lef_bar_window(const BarView& v, u32 nb, u64 lo_key, u64 hi_key, u32& b_lo,
+                              u32& b_hi, bool& edge) {
+  edge = false;
+  if (!FWD) {
+    b_lo = bar_view_lower_bound<STAGED_ONLY>(v, v.s0, v.s1, lo_key);
+    if (b_lo == v.s1 && v.s1 < nb) {
+      if (STAGED_ONLY) {
+        edge = true;
+        b_hi = b_lo;
+        return;
+      }
+      b_lo = bar_view_lower_bound<false>(v, v.s1, nb, lo_key);
+    }
+    b_hi = b_lo;
+    const u32 lim = STAGED_ONLY ? v.s1 : nb;
+    while (b_hi < lim && v.pos<STAGED_ONLY>(b_hi) < hi_key) ++b_hi;
+    if (STAGED_ONLY && b_hi == v.s1 && v.s1 < nb) edge = true;
+  } else {
+    b_hi = bar_view_lower_bound<STAGED_ONLY>(v, v.s0, v.s1, hi_key);
+    if (b_hi == v.s0 && v.s0 > 0) {
+      if (STAGED_ONLY) {
+        edge = true;
+        b_lo = b_hi;
+        return;
+      }
+      b_hi = bar_view_lower_bound<false>(v, 0, v.s0, hi_key);
+    }
+    b_lo = b_hi;
+    const u32 lim = STAGED_ONLY ? v.s0 : 0;
+    while (b_lo > lim && v.pos<STAGED_ONLY>(b_lo - 1) >= lo_key) --b_lo;
+    if (STAGED_ONLY && b_lo == v.s0 && v.s0 > 0) edge = true;
+  }
+}
+
+// Bernoulli trials of one unit: how many it consumes (count_only) or which barrier stalls it
+template <bool FWD, bool STAGED_ONLY>
+MODLE_DEV u32 lef_bar_count_trials(const BarView& v, const Params& p, u32 b_lo, u32 b_hi) {
+  const u32 major_dir = FWD ? DIR_FWD : DIR_REV;
+  u32 ntr = 0;
+  for (u32 b = b_lo; b < b_hi; ++b) {
+    const u32 fl = v.flag<STAGED_ONLY>(b);
+    const f64 pb = (fl >> 1) == major_dir ? p.pblock_major : p.pblock_minor;
+    ntr += ((fl & 1u) && pb != 1.0 && pb != 0.0) ? 1u : 0u;
+  }
+  return ntr;
+}
+
+template <bool FWD, bool STAGED_ONLY>
+MODLE_DEV u32 lef_bar_pick(const BarView& v, const Params& p, const Rng& g, u32 b_lo, u32 b_hi,
+                           u32 trial_off, bool& hard, u32& bpos) {
+  const u32 major_dir = FWD ? DIR_FWD : DIR_REV;
+  u32 winner = 0xFFFFFFFFu;
+  u32 t = 0;
+  for (u32 q = b_lo; q < b_hi; ++q) {
+    const u32 b = FWD ? (b_hi - 1 - (q - b_lo)) : q;  // reference visiting order
+    const u32 fl = v.flag<STAGED_ONLY>(b);
+    if (!(fl & 1u)) continue;
+    const f64 pb = (fl >> 1) == major_dir ? p.pblock_major : p.pblock_minor;
+    bool hit;
+    if (pb == 1.0) {
+      hit = true;
+    } else if (pb == 0.0) {
+      hit = false;
+    } else {
+      hit = bernoulli_raw(rng_peek(g, g.pos + trial_off + t), pb);
+      ++t;
+    }
+    if (hit) {  // later visits overwrite earlier ones
+      winner = b;
+      hard = (fl >> 1) == major_dir;
+    }
+  }
+  if (winner != 0xFFFFFFFFu) bpos = v.pos<STAGED_ONLY>(winner);
+  return winner;
 }
 
 template <bool FWD>
@@ -753,150 +881,146 @@ MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
   const u32* pos = FWD ? ws.f_pos : ws.r_pos;
   const u32* moves = FWD ? ws.f_move : ws.r_move;
   u32* coll = FWD ? ws.f_coll : ws.r_coll;
-  const u32 major_dir = FWD ? DIR_FWD : DIR_REV;
   const bool trials = !((p.pblock_major == 1.0 || p.pblock_major == 0.0) &&
                         (p.pblock_minor == 1.0 || p.pblock_minor == 0.0));
   u32* barpos = stalling_barrier_positions<FWD>(ws);
-  u32* st_pos = c.lds.stage;
-  u32* st_flag = c.lds.stage + BAR_WIN;
+  u32* st_pos = reinterpret_cast<u32*>(c.lds.sort_lds);
+  u32* st_flag = st_pos + BAR_WIN;
   // first / last rank that takes part
   const u32 j_rev0 = bc.n5 == 0 ? 0 : bc.n5 - 1;
   const u32 j_fwd0 = bc.n3 == 0 ? n - 1 : n - bc.n3;
   u32 carry_pos = 0;  // position of the neighbouring unit processed by the previous batch
   u32 anchor = 0;     // rev: first barrier index the next batch can need; fwd: one past the last
+  BarView v;
+  v.iv = &iv;
+  v.active = ws.bar_active;
+  v.st_pos = st_pos;
+  v.st_flag = st_flag;
+  v.s0 = 0;
+  v.s1 = 0;  // nothing staged yet
+  bool located = false;
   const u32 nbatch = (n + 63) / 64;
-  for (u32 bi = 0; bi < nbatch; ++bi) {
-    // rev: ranks ascending; fwd: ranks descending, lane 0 = highest rank of the batch
-    const i64 kk = FWD ? static_cast<i64>(j_fwd0) - static_cast<i64>(bi) * 64 - lane
-                       : static_cast<i64>(j_rev0) + static_cast<i64>(bi) * 64 + lane;
-    const bool act = kk >= 0 && kk < static_cast<i64>(n);
-    if (!wave::any(act)) break;
-    const u32 k = act ? static_cast<u32>(kk) : 0;
-    const u32 P = act ? pos[k] : 0;
-    const u32 M = act ? moves[k] : 0;
-    const bool bnd = act && P != UNBOUND;
-    // neighbour towards which the barriers are shadowed (rank k-1 for rev, k+1 for fwd)
-    const u32 nbr_in = wave::shfl_up(P, 1);
-    const bool first = (bi == 0 && lane == 0);
-    const u32 nbr = lane > 0 ? nbr_in : carry_pos;
-    // the unit can be stalled by barriers with lo_key <= position < hi_key
-    u64 lo_key = 0, hi_key = 0;
-    if (bnd) {
-      if (!FWD) {
-        // prev <= bpos < P and P - bpos <= M
-        const u32 reach = P - M;  // M <= P - start after clamping
-        lo_key = first ? reach : umax(reach, nbr);
-        hi_key = P;
-      } else {
-        // P < bpos <= next and bpos - P <= M
-        const u64 reach = static_cast<u64>(P) + M;
-        lo_key = static_cast<u64>(P) + 1;
-        hi_key = (first ? reach : umin64(reach, nbr)) + 1;
-      }
-    }
-    // stage the window.  The first batch locates it through the bucket table (from the first
-    // bound unit in visiting order); later batches continue where the previous one stopped.
-    const u64 bm = wave::ballot(bnd);
-    if (bm == 0) {
-      carry_pos = wave::bcast(P, 63);
-      continue;
-    }
-    if (bi == 0) {
-      const u32 l0 = static_cast<u32>(wave::ctz64(bm));
-      const u64 key = FWD ? wave::bcast(hi_key, l0) : wave::bcast(lo_key, l0);
-      anchor = wave::uniform(bar_lower_bound(iv, key));
-    }
-    BarView v;
-    v.iv = &iv;
-    v.active = ws.bar_active;
-    v.st_pos = st_pos;
-    v.st_flag = st_flag;
-    if (!FWD) {
-      v.s0 = anchor;
-      v.s1 = umin(anchor + BAR_WIN, nb);
-    } else {
-      v.s1 = anchor;
-      v.s0 = anchor > BAR_WIN ? anchor - BAR_WIN : 0;
-    }
-    wave::lockstep();
-    for (u32 t = lane; t < BAR_WIN; t += 64) {
-      const u32 b = v.s0 + t;
-      if (b < v.s1) {
-        st_pos[t] = iv.bar_pos[b];
-        st_flag[t] = static_cast<u32>(ws.bar_active[b] != 0) | (static_cast<u32>(iv.bar_dir[b]) << 1);
-      }
-    }
-    wave::sync_lds();
-    // window of barrier indices [b_lo, b_hi) of this unit.  Searches start inside the staged
-    // range and continue in device memory when they run off its edge (BarView handles both).
-    u32 b_lo = 0, b_hi = 0;
-    if (bnd) {
-      if (!FWD) {
-        b_lo = bar_view_lower_bound(v, v.s0, v.s1, lo_key);
-        if (b_lo == v.s1 && v.s1 < nb) b_lo = bar_view_lower_bound(v, v.s1, nb, lo_key);
-        b_hi = b_lo;
-        while (b_hi < nb && v.pos(b_hi) < hi_key) ++b_hi;
-      } else {
-        b_hi = bar_view_lower_bound(v, v.s0, v.s1, hi_key);
-        if (b_hi == v.s0 && v.s0 > 0) b_hi = bar_view_lower_bound(v, 0, v.s0, hi_key);
-        b_lo = b_hi;
-        while (b_lo > 0 && v.pos(b_lo - 1) >= lo_key) --b_lo;
-      }
-    }
-    // number of Bernoulli trials this unit consumes
-    u32 ntr = 0;
-    if (trials) {
-      for (u32 b = b_lo; b < b_hi; ++b) {
-        const u32 fl = v.flag(b);
-        const f64 pb = (fl >> 1) == major_dir ? p.pblock_major : p.pblock_minor;
-        ntr += ((fl & 1u) && pb != 1.0 && pb != 0.0) ? 1u : 0u;
-      }
-    }
-    // exclusive prefix sum of ntr over lanes
-    u32 off = ntr;
+  constexpr u32 UX = 4;  // batches whose loads are in flight together
+  for (u32 bg = 0; bg < nbatch; bg += UX) {
+    u32 Pq[UX], Mq[UX];
 #pragma unroll
-    for (u32 s = 1; s < 64; s <<= 1) {
-      const u32 o = wave::shfl_up(off, s);
-      if (lane >= s) off += o;
+    for (u32 u = 0; u < UX; ++u) {
+      // rev: ranks ascending; fwd: ranks descending, lane 0 = highest rank of the batch
+      const i64 kk = FWD ? static_cast<i64>(j_fwd0) - static_cast<i64>(bg + u) * 64 - lane
+                         : static_cast<i64>(j_rev0) + static_cast<i64>(bg + u) * 64 + lane;
+      const bool act = kk >= 0 && kk < static_cast<i64>(n);
+      Pq[u] = act ? pos[static_cast<u32>(kk)] : 0;
+      Mq[u] = act ? moves[static_cast<u32>(kk)] : 0;
     }
-    const u32 total = wave::bcast(off, 63);
-    off -= ntr;
-    if (total > RNG_BLOCK) {
-      c.error = ERR_TRIAL_OVERFLOW;  // more Bernoulli trials in one batch than the ring holds
-      return;
-    }
-    if (total != 0) rng_ensure(c.g, total);
-    u32 winner = 0xFFFFFFFFu;
-    bool winner_hard = false;
-    u32 t = 0;
-    for (u32 q = b_lo; q < b_hi; ++q) {
-      const u32 b = FWD ? (b_hi - 1 - (q - b_lo)) : q;  // reference visiting order
-      const u32 fl = v.flag(b);
-      if (!(fl & 1u)) continue;
-      const f64 pb = (fl >> 1) == major_dir ? p.pblock_major : p.pblock_minor;
-      bool hit;
-      if (pb == 1.0) {
-        hit = true;
-      } else if (pb == 0.0) {
-        hit = false;
-      } else {
-        hit = bernoulli_raw(rng_peek(c.g, c.g.pos + off + t), pb);
-        ++t;
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 bi = bg + u;
+      const i64 kk = FWD ? static_cast<i64>(j_fwd0) - static_cast<i64>(bi) * 64 - lane
+                         : static_cast<i64>(j_rev0) + static_cast<i64>(bi) * 64 + lane;
+      const bool act = kk >= 0 && kk < static_cast<i64>(n);
+      if (!wave::any(act)) break;
+      const u32 k = act ? static_cast<u32>(kk) : 0;
+      const u32 P = Pq[u];
+      const u32 M = Mq[u];
+      const bool bnd = act && P != UNBOUND;
+      // neighbour towards which the barriers are shadowed (rank k-1 for rev, k+1 for fwd)
+      const u32 nbr_in = wave::shfl_up(P, 1);
+      const bool first = (bi == 0 && lane == 0);
+      const u32 nbr = lane > 0 ? nbr_in : carry_pos;
+      // the unit can be stalled by barriers with lo_key <= position < hi_key
+      u64 lo_key = 0, hi_key = 0;
+      if (bnd) {
+        if (!FWD) {
+          // prev <= bpos < P and P - bpos <= M
+          const u32 reach = P - M;  // M <= P - start after clamping
+          lo_key = first ? reach : umax(reach, nbr);
+          hi_key = P;
+        } else {
+          // P < bpos <= next and bpos - P <= M
+          const u64 reach = static_cast<u64>(P) + M;
+          lo_key = static_cast<u64>(P) + 1;
+          hi_key = (first ? reach : umin64(reach, nbr)) + 1;
+        }
       }
-      if (hit) {  // later visits overwrite earlier ones
-        winner = b;
-        winner_hard = (fl >> 1) == major_dir;
+      const u64 bm = wave::ballot(bnd);
+      carry_pos = wave::bcast(P, 63);
+      if (bm == 0) continue;
+      // the first batch with a bound unit locates the window through the bucket table; later
+      // batches continue where the previous one stopped
+      if (!located) {
+        const u32 l0 = static_cast<u32>(wave::ctz64(bm));
+        const u64 key = FWD ? wave::bcast(hi_key, l0) : wave::bcast(lo_key, l0);
+        anchor = wave::uniform(bar_lower_bound(iv, key));
+        located = true;
       }
+      const bool restage = FWD ? (v.s1 == 0 || (anchor < v.s0 + BAR_NEED && v.s0 > 0) || anchor > v.s1)
+                               : (v.s1 == 0 || (anchor + BAR_NEED > v.s1 && v.s1 < nb) || anchor < v.s0);
+      if (restage) {
+        if (!FWD) {
+          v.s0 = anchor;
+          v.s1 = umin(anchor + BAR_WIN, nb);
+        } else {
+          v.s1 = anchor;
+          v.s0 = anchor > BAR_WIN ? anchor - BAR_WIN : 0;
+        }
+        wave::lockstep();
+        for (u32 t = lane; t < BAR_WIN; t += 64) {
+          const u32 b = v.s0 + t;
+          if (b < v.s1) {
+            st_pos[t] = iv.bar_pos[b];
+            st_flag[t] =
+                static_cast<u32>(ws.bar_active[b] != 0) | (static_cast<u32>(iv.bar_dir[b]) << 1);
+          }
+        }
+        wave::sync_lds();
+      }
+      // windows of barrier indices [b_lo, b_hi): in LDS when every unit of the batch stays inside
+      // the staged range, otherwise through the general accessors
+      u32 b_lo = 0, b_hi = 0;
+      bool edge = false;
+      if (bnd) lef_bar_window<FWD, true>(v, nb, lo_key, hi_key, b_lo, b_hi, edge);
+      const bool staged_only = !wave::any(edge);
+      if (!staged_only) {
+        b_lo = 0;
+        b_hi = 0;
+        if (bnd) lef_bar_window<FWD, false>(v, nb, lo_key, hi_key, b_lo, b_hi, edge);
+      }
+      // number of Bernoulli trials this unit consumes
+      u32 ntr = 0;
+      if (trials) {
+        ntr = staged_only ? lef_bar_count_trials<FWD, true>(v, p, b_lo, b_hi)
+                          : lef_bar_count_trials<FWD, false>(v, p, b_lo, b_hi);
+      }
+      u32 off = 0, total = 0;
+      if (trials) {
+        // exclusive prefix sum of ntr over lanes
+        off = ntr;
+#pragma unroll
+        for (u32 s = 1; s < 64; s <<= 1) {
+          const u32 o = wave::shfl_up(off, s);
+          if (lane >= s) off += o;
+        }
+        total = wave::bcast(off, 63);
+        off -= ntr;
+        if (total > RNG_BLOCK) {
+          c.error = ERR_TRIAL_OVERFLOW;  // more Bernoulli trials in one batch than the ring holds
+          return;
+        }
+        if (total != 0) rng_ensure(c.g, total);
+      }
+      bool hard = false;
+      u32 bpos = 0;
+      const u32 winner = staged_only ? lef_bar_pick<FWD, true>(v, p, c.g, b_lo, b_hi, off, hard, bpos)
+                                     : lef_bar_pick<FWD, false>(v, p, c.g, b_lo, b_hi, off, hard, bpos);
+      if (winner != 0xFFFFFFFFu) {
+        coll[k] = cw_make(winner, EV_COLLISION | EV_LEF_BAR) | (hard ? CW_HARD : 0u);
+        barpos[k] = bpos;
+      }
+      c.g.pos += total;
+      // where the next batch continues: past the last bound unit's window (rev) / below it (fwd)
+      const u32 l_last = static_cast<u32>(63 - wave::clz64(bm));
+      anchor = FWD ? wave::bcast(b_lo, l_last) : wave::bcast(b_hi, l_last);
     }
-    if (winner != 0xFFFFFFFFu) {
-      coll[k] = cw_make(winner, EV_COLLISION | EV_LEF_BAR) | (winner_hard ? CW_HARD : 0u);
-      barpos[k] = v.pos(winner);
-    }
-    c.g.pos += total;
-    carry_pos = wave::bcast(P, 63);
-    // where the next batch continues: past the last bound unit's window (rev) / below it (fwd)
-    const u32 l_last = static_cast<u32>(63 - wave::clz64(bm));
-    anchor = FWD ? wave::bcast(b_lo, l_last) : wave::bcast(b_hi, l_last);
   }
   wave::sync_mem();
 }
@@ -949,22 +1073,53 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
   const bool trials = p.p_bypass != 0.0;
   const f64 p_collide = 1.0 - p.p_bypass;
   const u32 prim = EV_COLLISION | EV_LEF_LEF_PRIMARY;
+  // LDS slices of the fwd-side arrays, ranks [w0, w0 + STAGE_CAP): positions in the staging
+  // buffer, moves / collision words / ids in the (idle) sort buffer
   u32* stage = c.lds.stage;
+  u32* st_move = reinterpret_cast<u32*>(c.lds.sort_lds);
+  u32* st_coll = st_move + STAGE_CAP;
+  u32* st_id = st_coll + STAGE_CAP;
+  static_assert(3 * STAGE_CAP <= 2 * SORT_LDS_CAP, "fwd slices do not fit the sort buffer");
   u32 carry_pos = 0;
   u32 carry_pf = 0;  // fwd units strictly upstream of the last rev unit handled so far
   for (u32 base = bc.n5; base < n; base += 64) {
     const u32 k = base + lane;
     const bool act = k < n;
+    // pf = number of fwd units strictly upstream of R.  pf is monotone in the rank, so slices of
+    // the fwd arrays starting at the previous batch's value are staged in LDS (one round trip
+    // together with this batch's rev-side loads) and everything is looked up there; lanes whose
+    // partner lies beyond the slice use device memory.
+    const u32 w0 = carry_pf > 0 ? carry_pf - 1 : 0;
     const u32 R = act ? ws.r_pos[k] : UNBOUND;
+    const u32 rev_move_k = act ? ws.r_move[k] : 0;
+    const u32 rev_id_k = act ? ws.r_id[k] : 0;
+    const u32 rc_k = act ? ws.r_coll[k] : 0;
+    {
+      // all loads first (one round trip), then the LDS writes
+      constexpr u32 NT = STAGE_CAP / 64;
+      u32 sp[NT], sm[NT], sc[NT], si[NT];
+#pragma unroll
+      for (u32 q = 0; q < NT; ++q) {
+        const u32 t = lane + 64 * q;
+        const bool in = w0 + t < n;
+        sp[q] = in ? ws.f_pos[w0 + t] : UNBOUND;
+        sm[q] = in ? ws.f_move[w0 + t] : 0;
+        sc[q] = in ? ws.f_coll[w0 + t] : 0;
+        si[q] = in ? ws.f_id[w0 + t] : 0;
+      }
+      wave::lockstep();
+#pragma unroll
+      for (u32 q = 0; q < NT; ++q) {
+        const u32 t = lane + 64 * q;
+        stage[t] = sp[q];
+        st_move[t] = sm[q];
+        st_coll[t] = sc[q];
+        st_id[t] = si[q];
+      }
+      wave::sync_lds();
+    }
     const u32 prev_in = wave::shfl_up(R, 1);
     const u32 Rprev = lane > 0 ? prev_in : carry_pos;
-    // pf = number of fwd units strictly upstream of R.  pf is monotone in the rank, so a slice
-    // of the sorted fwd positions starting at the previous batch's value is staged in LDS and
-    // searched there; lanes whose answer lies beyond the slice search device memory.
-    const u32 w0 = carry_pf > 0 ? carry_pf - 1 : 0;
-    wave::lockstep();
-    for (u32 t = lane; t < STAGE_CAP; t += 64) stage[t] = (w0 + t < n) ? ws.f_pos[w0 + t] : UNBOUND;
-    wave::sync_lds();
     u32 pf = 0;
     if (act) {
       u32 lo = 0, hi = STAGE_CAP;
@@ -979,13 +1134,17 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
       }
     }
     bool cand = false;
-    u32 F = 0, rev_move = 0, fwd_move = 0;
+    u32 F = 0, rev_move = 0, fwd_move = 0, fwd_id_s = 0, fc_s = 0;
     if (act && pf >= 1 && pf < i2) {
-      F = ws.f_pos[pf - 1];
+      const u32 kf = pf - 1;
+      const bool staged = kf >= w0 && kf - w0 < STAGE_CAP;
+      F = staged ? stage[kf - w0] : ws.f_pos[kf];
       const bool first_after = (k == bc.n5) || Rprev <= F;
       if (first_after) {
-        rev_move = ws.r_move[k];
-        fwd_move = ws.f_move[pf - 1];
+        rev_move = rev_move_k;
+        fwd_move = staged ? st_move[kf - w0] : ws.f_move[kf];
+        fwd_id_s = staged ? st_id[kf - w0] : ws.f_id[kf];
+        fc_s = staged ? st_coll[kf - w0] : ws.f_coll[kf];
         const u32 delta = R - F;  // > 0 by construction
         cand = static_cast<u64>(delta) < static_cast<u64>(rev_move) + fwd_move;
       }
@@ -1001,10 +1160,10 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
     }
     if (hit) {
       const u32 kf = pf - 1;
-      const u32 rev_id = ws.r_id[k], fwd_id = ws.f_id[kf];
+      const u32 rev_id = rev_id_k, fwd_id = fwd_id_s;
       u32 cpos_rev, cpos_fwd;
       lef_lef_collision_pos(R, F, rev_move, fwd_move, cpos_rev, cpos_fwd);
-      const u32 rc = ws.r_coll[k], fc = ws.f_coll[kf];
+      const u32 rc = rc_k, fc = fc_s;
       const bool rev_occ = cw_occurred(rc), fwd_occ = cw_occurred(fc);
       bool both = false;
       if (!rev_occ && !fwd_occ) {
@@ -1230,7 +1389,7 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
 // fix_secondary_lef_lef_collisions (reference: simulation_detect_collisions.cpp:517-644).
 // Rare (one entry per avoided secondary collision); replayed sequentially, uniformly.  The two
 // units trade places: slots i-1 and i of the rank-ordered arrays are rewritten.
-MODLE_DEV_NOINLINE void fix_secondary_rev(Cell& c, const u32* list, u32 n_list) {
+MODLE_DEV_NOINLINE void fix_secondary_rev_seq(Cell& c, const u32* list, u32 n_list) {
   Workspace& ws = c.ws;
   const u32 start = c.iv->start;
   const u32 sec = EV_LEF_LEF_SECONDARY;
@@ -1262,7 +1421,7 @@ MODLE_DEV_NOINLINE void fix_secondary_rev(Cell& c, const u32* list, u32 n_list) 
   }
 }
 
-MODLE_DEV_NOINLINE void fix_secondary_fwd(Cell& c, const u32* list, u32 n_list) {
+MODLE_DEV_NOINLINE void fix_secondary_fwd_seq(Cell& c, const u32* list, u32 n_list) {
   Workspace& ws = c.ws;
   const u32 last = c.iv->end - 1;
   const u32 sec = EV_LEF_LEF_SECONDARY;
@@ -1291,6 +1450,102 @@ MODLE_DEV_NOINLINE void fix_secondary_fwd(Cell& c, const u32* list, u32 n_list) 
     ws.f_rank[id1] = i + 1;
     wave::sync_mem();
   }
+}
+
+// Entries of the list touch the rank slots {i-1, i} (rev) / {i, i+1} (fwd).  Unless two entries are
+// adjacent ranks the swaps are independent of each other and every lane performs one; a list
+// with adjacent entries (a cascade of avoided collisions) is replayed sequentially.
+MODLE_DEV bool fix_list_has_adjacent_entries(const u32* list, u32 n_list, bool ascending) {
+  const u32 lane = wave::lane();
+  bool adj = false;
+  for (u32 base = 0; base < n_list; base += 64) {
+    const u32 q = base + lane;
+    bool a = false;
+    if (q + 1 < n_list) {
+      const u32 x = list[q], y = list[q + 1];
+      a = ascending ? (y <= x + 1) : (x <= y + 1);
+    }
+    adj = wave::any(a) || adj;
+  }
+  return adj;
+}
+
+MODLE_DEV_NOINLINE void fix_secondary_rev(Cell& c, const u32* list, u32 n_list) {
+  if (fix_list_has_adjacent_entries(list, n_list, true)) {
+    fix_secondary_rev_seq(c, list, n_list);
+    return;
+  }
+  Workspace& ws = c.ws;
+  const u32 lane = wave::lane();
+  const u32 start = c.iv->start;
+  const u32 sec = EV_LEF_LEF_SECONDARY;
+  for (u32 base = 0; base < n_list; base += 64) {
+    const u32 q = base + lane;
+    if (q < n_list) {
+      const u32 i = list[q];
+      if (cw_avoided_as(ws.r_coll[i], sec)) {
+        const u32 id1 = ws.r_id[i - 1], id2 = ws.r_id[i];
+        const u32 p1 = ws.r_pos[i - 1], p2 = ws.r_pos[i];
+        const u32 m1 = ws.r_move[i - 1];
+        const u32 c1 = ws.r_coll[i - 1];
+        const u32 pos1 = p1 - m1;
+        const u32 m2 = p2 > pos1 + 1 ? p2 - (pos1 + 1) : 0;
+        const u32 c2 = cw_make(id1, EV_COLLISION | sec);
+        const u32 np1 = umin(ws.f_pos[ws.f_rank[id1]], p2);
+        const u32 np2 = umin(ws.f_pos[ws.f_rank[id2]], p1);
+        ws.r_id[i - 1] = id2;
+        ws.r_pos[i - 1] = np2;
+        ws.r_coll[i - 1] = c1;
+        ws.r_move[i - 1] = umin(np2 - start, m1);
+        ws.r_id[i] = id1;
+        ws.r_pos[i] = np1;
+        ws.r_coll[i] = c2;
+        ws.r_move[i] = umin(np1 - start, m2);
+        ws.r_rank[id2] = i - 1;
+        ws.r_rank[id1] = i;
+      }
+    }
+  }
+  wave::sync_mem();
+}
+
+MODLE_DEV_NOINLINE void fix_secondary_fwd(Cell& c, const u32* list, u32 n_list) {
+  if (fix_list_has_adjacent_entries(list, n_list, false)) {
+    fix_secondary_fwd_seq(c, list, n_list);
+    return;
+  }
+  Workspace& ws = c.ws;
+  const u32 lane = wave::lane();
+  const u32 last = c.iv->end - 1;
+  const u32 sec = EV_LEF_LEF_SECONDARY;
+  for (u32 base = 0; base < n_list; base += 64) {
+    const u32 q = base + lane;
+    if (q < n_list) {
+      const u32 i = list[q];
+      if (cw_avoided_as(ws.f_coll[i], sec)) {
+        const u32 id1 = ws.f_id[i], id2 = ws.f_id[i + 1];
+        const u32 p1 = ws.f_pos[i], p2 = ws.f_pos[i + 1];
+        const u32 m2 = ws.f_move[i + 1];
+        const u32 c2 = ws.f_coll[i + 1];
+        const u32 pos2 = p2 + m2;
+        const u32 m1 = pos2 > p1 + 1 ? pos2 - (p1 + 1) : 0;
+        const u32 c1 = cw_make(id2, EV_COLLISION | sec);
+        const u32 np1 = umax(ws.r_pos[ws.r_rank[id1]], p2);
+        const u32 np2 = umax(ws.r_pos[ws.r_rank[id2]], p1);
+        ws.f_id[i] = id2;
+        ws.f_pos[i] = np2;
+        ws.f_coll[i] = c1;
+        ws.f_move[i] = umin(last - np2, m1);
+        ws.f_id[i + 1] = id1;
+        ws.f_pos[i + 1] = np1;
+        ws.f_coll[i + 1] = c2;
+        ws.f_move[i + 1] = umin(last - np1, m2);
+        ws.f_rank[id2] = i;
+        ws.f_rank[id1] = i + 1;
+      }
+    }
+  }
+  wave::sync_mem();
 }
 
 // returns false when an internal capacity was exceeded (the cell is then flagged as failed)
@@ -1742,6 +1997,8 @@ MODLE_DEV void activate_lefs(Cell& c, u32 n_old, u32 n_new) {
     if (k < n_new) {
       c.ws.r_id[k] = k;
       c.ws.f_id[k] = k;
+      c.ws.r_rank[k] = k;
+      c.ws.f_rank[k] = k;
     }
   }
   c.n_active = n_new;
