@@ -608,7 +608,7 @@ int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen) {
   {
     static const char* names[16] = {"burnin_stats", "bind", "rank_rev", "rank_fwd", "sample", "gen_moves",
                                     "adjust_moves", "barriers+clear", "boundaries", "lef_bar", "primary",
-                                    "secondary", "fix_secondary", "extrude_release", "(rank: split pass)", "(rank: split+sort)"};
+                                    "secondary", "fix_secondary", "extrude_release", "(merge: kept-unit loop)", "(merge: loop iterations)"};
     u64 ticks[16];
     HIP_TRY(hipMemcpy(ticks, h->d_phase_ticks.p, sizeof(ticks), hipMemcpyDeviceToHost));
     u64 total = 0;

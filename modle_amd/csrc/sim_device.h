@@ -180,12 +180,27 @@ MODLE_DEV bool rank_pair_out_of_order(const Workspace& ws, const u32* where, u32
 template <bool FWD>
 MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_pos,
                           const u32* old_id, const u32* new_id, u32* out_pos, u32* out_id,
-                          u32* where_new) {
+                          u32* where_new, u32* cnt_lds, u64* prof) {
   const u32 lane = wave::lane();
   bool ties = false;
+  // cnt_lds[j] = number of kept units that go before new key j, filled in while the kept units
+  // are placed (they see where the keys fall between them); keys after the last kept unit keep
+  // the initial value.  Only when the keys fit the buffer; otherwise the keys search old_pos.
+  const bool use_cnt = n_new <= STAGE_CAP;
+  if (use_cnt) {
+    wave::lockstep();
+    for (u32 j = lane; j < n_new; j += 64) cnt_lds[j] = n_old;
+    wave::sync_lds();
+  }
+  u32 carry_lo = 0;  // keys below the last kept unit of the previous batch
+#ifdef MODLE_PHASE_TIMERS
+  const u64 mg_t0 = wave::clock();
+#endif
   u32 carry_old = UNBOUND;  // position of the kept unit before this batch (UNBOUND: none)
   u32 nxt_p = lane < n_old ? old_pos[lane] : UNBOUND;
   u32 nxt_i = lane < n_old ? old_id[lane] : 0;
+  wave::await(nxt_p);
+  wave::await(nxt_i);
   for (u32 base = 0; base < n_old; base += 64) {
     const u32 a = base + lane;
     const bool act = a < n_old;
@@ -195,13 +210,26 @@ MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_
     nxt_p = an < n_old ? old_pos[an] : UNBOUND;
     nxt_i = an < n_old ? old_id[an] : 0;
     bool tie = false;
+    u32 lo = 0;
     if (act) {
       const u64 thr = FWD ? ((static_cast<u64>(pp) + 1) << 32) : (static_cast<u64>(pp) << 32);
-      u32 lo = 0, hi = n_new;
+      u32 hi = n_new;
       while (lo < hi) {
         const u32 mid = (lo + hi) >> 1;
         if (keys[mid] < thr) lo = mid + 1; else hi = mid;
       }
+    }
+    if (use_cnt) {
+      // keys [lo of the previous kept unit, lo) lie between that unit and this one
+      const u32 lo_in = wave::shfl_up(lo, 1);
+      const u32 lo_prev = lane > 0 ? lo_in : carry_lo;
+      if (act) {
+        for (u32 j = lo_prev; j < lo; ++j) cnt_lds[j] = a;
+      }
+      const u64 am = wave::ballot(act);
+      carry_lo = wave::bcast(lo, static_cast<u32>(63 - wave::clz64(am)));
+    }
+    if (act) {
       if (pp != UNBOUND) {
         if (FWD) {
           tie = lo > 0 && static_cast<u32>(keys[lo - 1] >> 32) == pp;
@@ -209,6 +237,8 @@ MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_
           tie = lo < n_new && static_cast<u32>(keys[lo] >> 32) == pp;
         }
       }
+      wave::await(nxt_p);
+      wave::await(nxt_i);
       out_pos[a + lo] = pp;
       out_id[a + lo] = oid;
       where_new[oid] = a + lo;
@@ -219,18 +249,28 @@ MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_
     ties = wave::any(tie) || ties;
     carry_old = wave::bcast(pp, 63);
   }
+#ifdef MODLE_PHASE_TIMERS
+  prof[14] += wave::clock() - mg_t0;
+  prof[15] += (n_old + 63) / 64;
+#endif
+  wave::sync_lds();
   for (u32 base = 0; base < n_new; base += 64) {
     const u32 bq = base + lane;
     bool tie = false;
     if (bq < n_new) {
       const u64 key = keys[bq];
       const u32 pp = static_cast<u32>(key >> 32);
-      u32 lo = 0, hi = n_old;
-      while (lo < hi) {
-        const u32 mid = (lo + hi) >> 1;
-        const u32 q = old_pos[mid];
-        const bool before = FWD ? (q < pp) : (q <= pp);
-        if (before) lo = mid + 1; else hi = mid;
+      u32 lo = 0;
+      if (use_cnt) {
+        lo = cnt_lds[bq];
+      } else {
+        u32 hi = n_old;
+        while (lo < hi) {
+          const u32 mid = (lo + hi) >> 1;
+          const u32 q = old_pos[mid];
+          const bool before = FWD ? (q < pp) : (q <= pp);
+          if (before) lo = mid + 1; else hi = mid;
+        }
       }
       const u32 nid = new_id[static_cast<u32>(key)];
       out_pos[bq + lo] = pp;
@@ -266,15 +306,25 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
   //    the kept sequence is non-decreasing by construction.
   u32 n_old = 0, n_new = 0;
   u32 run_max = 0;  // max position of carried-over units in previous batches
-#ifdef MODLE_PHASE_TIMERS
-  const u64 rk_t0 = wave::clock();
-#endif
+
+  // software pipeline: the next batch is requested before this one is processed and awaited
+  // before this one's stores are issued (wave::await)
+  u32 nxt_P = lane < n ? pos[lane] : 0;
+  u32 nxt_I = lane < n ? ids[lane] : 0;
+  u32 nxt_M = lane < n ? marks[lane] : 0;
+  wave::await(nxt_P);
+  wave::await(nxt_I);
+  wave::await(nxt_M);
   for (u32 base = 0; base < n; base += 64) {
     const u32 k = base + lane;
     const bool act = k < n;
-    const u32 P = act ? pos[k] : 0;
-    const u32 id = act ? ids[k] : 0;
-    const bool fresh = act && (all_new || marks[k] == NEW_MARK);
+    const u32 P = nxt_P;
+    const u32 id = nxt_I;
+    const bool fresh = act && (all_new || nxt_M == NEW_MARK);
+    const u32 kn = k + 64;
+    nxt_P = kn < n ? pos[kn] : 0;
+    nxt_I = kn < n ? ids[kn] : 0;
+    nxt_M = kn < n ? marks[kn] : 0;
     const bool carried = act && !fresh;
     u32 pm = carried ? P : 0;
 #pragma unroll
@@ -290,6 +340,9 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
     const bool is_old = carried && !displaced;
     const u64 mn = wave::ballot(is_new);
     const u64 mo = wave::ballot(is_old);
+    wave::await(nxt_P);
+    wave::await(nxt_I);
+    wave::await(nxt_M);
     if (is_new) {
       const u32 j = n_new + static_cast<u32>(wave::popc64(mn & lanemask_lt(lane)));
       new_id[j] = id;
@@ -306,9 +359,6 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
     run_max = umax(run_max, incl_last);
   }
   wave::sync_mem();
-#ifdef MODLE_PHASE_TIMERS
-  c.ph[14] += wave::clock() - rk_t0;
-#endif
   if (n_old + n_new != n) {
     c.error = ERR_INTERNAL;  // cannot happen: every active unit is either carried over or new
     return;
@@ -334,20 +384,22 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
       bitonic_sort_u64<false>(keys_glb, m2);
     }
   }
-#ifdef MODLE_PHASE_TIMERS
-  c.ph[15] += wave::clock() - rk_t0;
-#endif
   // 3. merge by cross-ranking (kept units are sorted) straight into the output arrays and the
   //    new inverse permutation.  Equal positions of bound units are the only thing this does not
   //    order completely (epoch rule); they are rare, so they are only flagged here.
   u32* out_pos = ws.tmp[0];
   u32* out_id = ws.tmp[1];
   u32* where_new = ws.tmp[7];
+#ifdef MODLE_PHASE_TIMERS
+  u64* rank_prof = c.ph;
+#else
+  u64* rank_prof = nullptr;
+#endif
   const bool ties = (n_new <= SORT_LDS_CAP)
                         ? rank_merge<FWD>(keys_lds, n_new, n_old, old_pos, old_id, new_id, out_pos,
-                                          out_id, where_new)
+                                          out_id, where_new, c.lds.stage, rank_prof)
                         : rank_merge<FWD>(keys_glb, n_new, n_old, old_pos, old_id, new_id, out_pos,
-                                          out_id, where_new);
+                                          out_id, where_new, c.lds.stage, rank_prof);
   wave::sync_mem();
   if (ties) {
     // 4. order equal positions (epoch rule, then previous rank) with a stable odd-even
@@ -793,11 +845,18 @@ MODLE_DEV u32 bar_view_lower_bound(const BarView& v, u32 lo, u32 hi, u64 key) {
 // the search stays inside the staged range and reports `edge` when the answer touches an edge
 // beyond which more barriers exist (the batch is then redone with the general accessors).
 template <bool FWD, bool STAGED_ONLY>
-MODLE_DEV void lef_bar_window(const BarView& v, u32 nb, u64 lo_key, u64 hi_key, u32& b_lo,
-                              u32& b_hi, bool& edge) {
+MODLE_DEV void lef_bar_window(const BarView& v, u32 nb, u32 anchor, u64 lo_key, u64 hi_key,
+                              u32& b_lo, u32& b_hi, bool& edge) {
   edge = false;
   if (!FWD) {
-    b_lo = bar_view_lower_bound<STAGED_ONLY>(v, v.s0, v.s1, lo_key);
+    if (STAGED_ONLY) {
+      // the answer is almost always within a few dozen barriers of the batch's anchor
+      const u32 near = umin(anchor + BAR_NEED, v.s1);
+      b_lo = bar_view_lower_bound<true>(v, anchor, near, lo_key);
+      if (b_lo == near && near < v.s1) b_lo = bar_view_lower_bound<true>(v, near, v.s1, lo_key);
+    } else {
+      b_lo = bar_view_lower_bound<false>(v, v.s0, v.s1, lo_key);
+    }
     if (b_lo == v.s1 && v.s1 < nb) {
       if (STAGED_ONLY) {
         edge = true;
@@ -811,7 +870,13 @@ MODLE_DEV void lef_bar_window(const BarView& v, u32 nb, u64 lo_key, u64 hi_key, 
     while (b_hi < lim && v.pos<STAGED_ONLY>(b_hi) < hi_key) ++b_hi;
     if (STAGED_ONLY && b_hi == v.s1 && v.s1 < nb) edge = true;
   } else {
-    b_hi = bar_view_lower_bound<STAGED_ONLY>(v, v.s0, v.s1, hi_key);
+    if (STAGED_ONLY) {
+      const u32 near = anchor > v.s0 + BAR_NEED ? anchor - BAR_NEED : v.s0;
+      b_hi = bar_view_lower_bound<true>(v, near, anchor, hi_key);
+      if (b_hi == near && near > v.s0) b_hi = bar_view_lower_bound<true>(v, v.s0, near, hi_key);
+    } else {
+      b_hi = bar_view_lower_bound<false>(v, v.s0, v.s1, hi_key);
+    }
     if (b_hi == v.s0 && v.s0 > 0) {
       if (STAGED_ONLY) {
         edge = true;
@@ -978,12 +1043,12 @@ MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
       // the staged range, otherwise through the general accessors
       u32 b_lo = 0, b_hi = 0;
       bool edge = false;
-      if (bnd) lef_bar_window<FWD, true>(v, nb, lo_key, hi_key, b_lo, b_hi, edge);
+      if (bnd) lef_bar_window<FWD, true>(v, nb, anchor, lo_key, hi_key, b_lo, b_hi, edge);
       const bool staged_only = !wave::any(edge);
       if (!staged_only) {
         b_lo = 0;
         b_hi = 0;
-        if (bnd) lef_bar_window<FWD, false>(v, nb, lo_key, hi_key, b_lo, b_hi, edge);
+        if (bnd) lef_bar_window<FWD, false>(v, nb, anchor, lo_key, hi_key, b_lo, b_hi, edge);
       }
       // number of Bernoulli trials this unit consumes
       u32 ntr = 0;
