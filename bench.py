@@ -27,6 +27,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def measured_traffic(workload_key):
+    """HBM bytes per launch of the simulation kernel, from the PMC passes committed under
+    profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same workload,
+    see profiles/README.md).  bench.py cannot collect hardware counters itself; None when no
+    committed measurement matches the workload."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return None
+    entry = table.get(workload_key)
+    return entry["bytes_per_launch"] if entry else None
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -239,7 +254,8 @@ def main():
                        "cell_epochs_per_gpu_step": epochs, "seed": 0,
                        "parallelism": f"cells sharded over {world} GPU(s), RCCL sum-reduce"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(f"{args.workload}:{cells_per_gpu}"),
                          "kernel": "modle_simulate_cells",
                          "kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": step_bytes},

@@ -180,7 +180,7 @@ MODLE_DEV bool rank_pair_out_of_order(const Workspace& ws, const u32* where, u32
 template <bool FWD>
 MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_pos,
                           const u32* old_id, const u32* new_id, u32* out_pos, u32* out_id,
-                          u32* where_new, u32* cnt_lds, u64* prof) {
+                          u32* where_new, u32* cnt_lds) {
   const u32 lane = wave::lane();
   bool ties = false;
   // cnt_lds[j] = number of kept units that go before new key j, filled in while the kept units
@@ -193,9 +193,7 @@ MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_
     wave::sync_lds();
   }
   u32 carry_lo = 0;  // keys below the last kept unit of the previous batch
-#ifdef MODLE_PHASE_TIMERS
-  const u64 mg_t0 = wave::clock();
-#endif
+
   u32 carry_old = UNBOUND;  // position of the kept unit before this batch (UNBOUND: none)
   u32 nxt_p = lane < n_old ? old_pos[lane] : UNBOUND;
   u32 nxt_i = lane < n_old ? old_id[lane] : 0;
@@ -249,10 +247,6 @@ MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_
     ties = wave::any(tie) || ties;
     carry_old = wave::bcast(pp, 63);
   }
-#ifdef MODLE_PHASE_TIMERS
-  prof[14] += wave::clock() - mg_t0;
-  prof[15] += (n_old + 63) / 64;
-#endif
   wave::sync_lds();
   for (u32 base = 0; base < n_new; base += 64) {
     const u32 bq = base + lane;
@@ -326,12 +320,7 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
     nxt_I = kn < n ? ids[kn] : 0;
     nxt_M = kn < n ? marks[kn] : 0;
     const bool carried = act && !fresh;
-    u32 pm = carried ? P : 0;
-#pragma unroll
-    for (u32 s = 1; s < 64; s <<= 1) {
-      const u32 o = wave::shfl_up(pm, s);
-      if (lane >= s) pm = umax(pm, o);
-    }
+    const u32 pm = wave_prefix_max_u32(carried ? P : 0);
     const u32 incl_last = wave::bcast(pm, 63);
     const u32 pm_prev = wave::shfl_up(pm, 1);
     const u32 excl = umax(run_max, lane > 0 ? pm_prev : 0);
@@ -390,16 +379,11 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
   u32* out_pos = ws.tmp[0];
   u32* out_id = ws.tmp[1];
   u32* where_new = ws.tmp[7];
-#ifdef MODLE_PHASE_TIMERS
-  u64* rank_prof = c.ph;
-#else
-  u64* rank_prof = nullptr;
-#endif
   const bool ties = (n_new <= SORT_LDS_CAP)
                         ? rank_merge<FWD>(keys_lds, n_new, n_old, old_pos, old_id, new_id, out_pos,
-                                          out_id, where_new, c.lds.stage, rank_prof)
+                                          out_id, where_new, c.lds.stage)
                         : rank_merge<FWD>(keys_glb, n_new, n_old, old_pos, old_id, new_id, out_pos,
-                                          out_id, where_new, c.lds.stage, rank_prof);
+                                          out_id, where_new, c.lds.stage);
   wave::sync_mem();
   if (ties) {
     // 4. order equal positions (epoch rule, then previous rank) with a stable odd-even
@@ -538,40 +522,34 @@ MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp)
   i64 carry_d = 0;
   bool carry_ok = false, carry_cross = false;
   i64 viol_rank = -1;
+  // lanes hold the ranks of a batch in DESCENDING order (lane 0 = highest rank), so that the
+  // suffix scan over ranks is a prefix scan over lanes
   for (u32 bi = nbatch; bi-- > 0;) {
-    const u32 k = bi * 64 + lane;
+    const u32 k = bi * 64 + (63 - lane);
     const bool act = k < n;
     const u32 P = act ? ws.r_pos[k] : UNBOUND;
     const u32 M = act ? mv_in[k] : 0;
     const bool bnd = act && P != UNBOUND;
     const bool okself = do_adjust && bnd && static_cast<u64>(P) > start + M;
     const i64 d = okself ? static_cast<i64>(P - M) - static_cast<i64>(k) : 0;
-    const bool ok_next_in = wave::shfl_down(okself, 1);
-    const bool ok_next = lane < 63 ? ok_next_in : carry_ok;
+    const bool ok_next_in = wave::shfl_up(okself, 1);
+    const bool ok_next = lane > 0 ? ok_next_in : carry_ok;
     const bool link = okself && ok_next;
-    i64 val = d;
-    bool cont = link;
-#pragma unroll
-    for (u32 s = 1; s < 64; s <<= 1) {
-      const i64 ov = wave::shfl_down(val, s);
-      const bool oc = wave::shfl_down(cont, s);
-      if (lane + s < 64 && cont) {
-        val = imin64(val, ov);
-        cont = oc;
-      }
-    }
-    if (cont) val = imin64(val, carry_d);
+    const SegScan sc = wave_prefix_segscan<false>(SegScan{d, link});
+    i64 val = sc.val;
+    if (sc.cont) val = imin64(val, carry_d);
     u32 Mnew = M;
     if (okself) Mnew = P - static_cast<u32>(val + static_cast<i64>(k));
     const bool cross = okself && static_cast<u64>(P) <= start + Mnew;
     if (act) mv_out[k] = (bnd && do_clamp) ? umin(Mnew, P - static_cast<u32>(start)) : Mnew;
-    const bool cross_next_in = wave::shfl_down(cross, 1);
-    const bool cross_next = lane < 63 ? cross_next_in : carry_cross;
+    const bool cross_next_in = wave::shfl_up(cross, 1);
+    const bool cross_next = lane > 0 ? cross_next_in : carry_cross;
     const u64 vm = wave::ballot(link && cross_next);
-    if (vm != 0 && viol_rank < 0) viol_rank = bi * 64 + (63 - wave::clz64(vm)) + 1;
-    carry_d = wave::bcast(val, 0);
-    carry_ok = wave::bcast(okself, 0);
-    carry_cross = wave::bcast(cross, 0);
+    // highest rank k whose link to k+1 the scan got wrong (lowest lane); the replay starts at k+1
+    if (vm != 0 && viol_rank < 0) viol_rank = bi * 64 + (63 - wave::ctz64(vm)) + 1;
+    carry_d = wave::bcast(val, 63);
+    carry_ok = wave::bcast(okself, 63);
+    carry_cross = wave::bcast(cross, 63);
   }
   wave::sync_mem();
   if (viol_rank >= 0) {
@@ -616,18 +594,9 @@ MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp)
     const bool ok_prev_in = wave::shfl_up(okself, 1);
     const bool ok_prev = lane > 0 ? ok_prev_in : carry_ok;
     const bool link = okself && ok_prev;  // link between k-1 and k
-    i64 val = d;
-    bool cont = link;
-#pragma unroll
-    for (u32 s = 1; s < 64; s <<= 1) {
-      const i64 ov = wave::shfl_up(val, s);
-      const bool oc = wave::shfl_up(cont, s);
-      if (lane >= s && cont) {
-        val = imax64(val, ov);
-        cont = oc;
-      }
-    }
-    if (cont) val = imax64(val, carry_d);
+    const SegScan sc = wave_prefix_segscan<true>(SegScan{d, link});
+    i64 val = sc.val;
+    if (sc.cont) val = imax64(val, carry_d);
     u32 Mnew = M;
     if (okself) Mnew = static_cast<u32>(val + static_cast<i64>(k) - static_cast<i64>(P));
     const bool cross = okself && static_cast<u64>(P) + Mnew > last;
@@ -1059,12 +1028,7 @@ MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
       u32 off = 0, total = 0;
       if (trials) {
         // exclusive prefix sum of ntr over lanes
-        off = ntr;
-#pragma unroll
-        for (u32 s = 1; s < 64; s <<= 1) {
-          const u32 o = wave::shfl_up(off, s);
-          if (lane >= s) off += o;
-        }
+        off = wave_prefix_sum_u32(ntr);
         total = wave::bcast(off, 63);
         off -= ntr;
         if (total > RNG_BLOCK) {

@@ -37,6 +37,61 @@ MODLE_DEV u64 umin64(u64 a, u64 b) { return a < b ? a : b; }
 MODLE_DEV i64 imin64(i64 a, i64 b) { return a < b ? a : b; }
 MODLE_DEV i64 imax64(i64 a, i64 b) { return a > b ? a : b; }
 
+// ---------------------------------------------------------------------------------------------
+// 64-lane inclusive prefix scans on DPP lane moves (wave::scan_move)
+// ---------------------------------------------------------------------------------------------
+#define MODLE_SCAN_STEPS(APPLY)                                                               \
+  APPLY(wave::SCAN_SHR1) APPLY(wave::SCAN_SHR2) APPLY(wave::SCAN_SHR4) APPLY(wave::SCAN_SHR8) \
+  APPLY(wave::SCAN_BCAST15) APPLY(wave::SCAN_BCAST31)
+
+MODLE_DEV u32 wave_prefix_max_u32(u32 v) {
+#define MODLE_STEP(S) v = umax(v, wave::scan_move<S>(v, 0u));
+  MODLE_SCAN_STEPS(MODLE_STEP)
+#undef MODLE_STEP
+  return v;
+}
+MODLE_DEV u32 wave_prefix_sum_u32(u32 v) {
+#define MODLE_STEP(S) v += wave::scan_move<S>(v, 0u);
+  MODLE_SCAN_STEPS(MODLE_STEP)
+#undef MODLE_STEP
+  return v;
+}
+
+// Segmented scan element: `cont` = the chain through this lane continues into the lanes before
+// it.  combine(a, b), b covering the lanes before a's:  a.cont ? (pick(a.val, b.val), b.cont) : a.
+// MAX = true picks the larger value, false the smaller one.
+struct SegScan {
+  i64 val;
+  bool cont;
+};
+template <bool MAX>
+MODLE_DEV SegScan wave_prefix_segscan(SegScan x) {
+  u32 lo = static_cast<u32>(static_cast<u64>(x.val)), hi = static_cast<u32>(static_cast<u64>(x.val) >> 32);
+  u32 ct = x.cont ? 1u : 0u;
+  // neutral element: the other value never wins, and the chain stays open
+  const u64 neutral = MAX ? 0x8000000000000000ull : 0x7FFFFFFFFFFFFFFFull;
+  const u32 nlo = static_cast<u32>(neutral), nhi = static_cast<u32>(neutral >> 32);
+#define MODLE_STEP(S)                                                                     \
+  {                                                                                       \
+    const u32 blo = wave::scan_move<S>(lo, nlo), bhi = wave::scan_move<S>(hi, nhi);        \
+    const u32 bct = wave::scan_move<S>(ct, 1u);                                           \
+    const i64 a = static_cast<i64>((static_cast<u64>(hi) << 32) | lo);                    \
+    const i64 b = static_cast<i64>((static_cast<u64>(bhi) << 32) | blo);                  \
+    const i64 r = MAX ? imax64(a, b) : imin64(a, b);                                      \
+    if (ct != 0) {                                                                        \
+      lo = static_cast<u32>(static_cast<u64>(r));                                         \
+      hi = static_cast<u32>(static_cast<u64>(r) >> 32);                                   \
+      ct = bct;                                                                           \
+    }                                                                                     \
+  }
+  MODLE_SCAN_STEPS(MODLE_STEP)
+#undef MODLE_STEP
+  SegScan out;
+  out.val = static_cast<i64>((static_cast<u64>(hi) << 32) | lo);
+  out.cont = ct != 0;
+  return out;
+}
+
 constexpr f64 TWO64 = 18446744073709551616.0;
 constexpr f64 TWO_M64 = 5.42101086242752217e-20;
 constexpr f64 TWO_M56 = 1.387778780781445675529539585113525390625e-17;

@@ -101,6 +101,23 @@ MODLE_DEV T shfl_up(T v, unsigned delta) {
   return __shfl_up(v, delta, 64);
 }
 
+// One step of a 64-lane inclusive prefix scan made of DPP lane moves (no LDS round trip).  Lane
+// l receives the value of the lane the step names, or `identity` when the step gives it none:
+//   SCAN_SHR1/2/4/8  lane l - n of the same row of 16 lanes
+//   SCAN_BCAST15     last lane of the previous row, rows 1 and 3 only
+//   SCAN_BCAST31     lane 31, rows 2 and 3 only
+// Applying  v = op(v, scan_move<S>(v, identity))  for the six steps in this order leaves in
+// every lane the combination of lanes 0..l (op associative, identity neutral on the right).
+enum ScanStep { SCAN_SHR1, SCAN_SHR2, SCAN_SHR4, SCAN_SHR8, SCAN_BCAST15, SCAN_BCAST31 };
+template <int STEP>
+MODLE_DEV uint32_t scan_move(uint32_t v, uint32_t identity) {
+  constexpr int ctrl = STEP == SCAN_SHR1 ? 0x111 : STEP == SCAN_SHR2 ? 0x112 : STEP == SCAN_SHR4 ? 0x114
+                     : STEP == SCAN_SHR8 ? 0x118 : STEP == SCAN_BCAST15 ? 0x142 : 0x143;
+  constexpr int row_mask = STEP == SCAN_BCAST15 ? 0xA : STEP == SCAN_BCAST31 ? 0xC : 0xF;
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(identity), static_cast<int>(v),
+                                                           ctrl, row_mask, 0xF, false));
+}
+
 // Orders this wave's earlier global/LDS stores before later loads issued by any lane of the wave.
 MODLE_DEV void sync_mem() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");

@@ -22,3 +22,31 @@ def test_emulated_device_code_matches_oracle(oracle, name, ncells):
         case["stp_inactive"], tasks, case["nrows"], case["ncols"], track_occupancy=track)
     assert_same_results(ores, eres, name)
     assert_same_outputs((oc, om, oo), (ec, em, eo), name)
+
+
+@pytest.mark.parametrize("schedule", [1, 7])
+def test_result_does_not_depend_on_the_lane_schedule(oracle, schedule):
+    """On hardware all lanes execute an instruction together; the emulator runs them one after the
+    other between two collectives.  A kernel that is correct on hardware cannot depend on which
+    lane runs first: descending and randomly permuted lane orders must give the same cell."""
+    from phase_backend import emu_lib
+
+    name = "chr8mb_loop_only"
+    case = build_case(name)
+    cfg, chrom = case["cfg"], case["chrom"]
+    tasks = api.slice_tasks(case["tasks"], 0, 1)
+    track = bool(cfg.track_1d_lef_position)
+    oc, om, oo, ores = oracle.simulate_interval(
+        cfg, chrom["start"], chrom["end"], chrom["bar_pos"], chrom["bar_dir"],
+        case["stp_active"], case["stp_inactive"], tasks, nthreads=1, track_occupancy=track)
+    lib = emu_lib()
+    lib.emu_set_lane_schedule(schedule)
+    try:
+        ec, em, eo, eres = emu_sim.simulate_interval(
+            cfg, chrom["start"], chrom["end"], chrom["bar_pos"], chrom["bar_dir"],
+            case["stp_active"], case["stp_inactive"], tasks, case["nrows"], case["ncols"],
+            track_occupancy=track)
+    finally:
+        lib.emu_set_lane_schedule(0)
+    assert_same_results(ores, eres, name)
+    assert_same_outputs((oc, om, oo), (ec, em, eo), name)

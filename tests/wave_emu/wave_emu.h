@@ -150,6 +150,24 @@ MODLE_DEV T shfl_up(T v, unsigned delta, int line = __builtin_LINE()) {
   return shfl(v, src, line);
 }
 
+enum ScanStep { SCAN_SHR1, SCAN_SHR2, SCAN_SHR4, SCAN_SHR8, SCAN_BCAST15, SCAN_BCAST31 };
+template <int STEP>
+MODLE_DEV uint32_t scan_move(uint32_t v, uint32_t identity, int line = __builtin_LINE()) {
+  const wave_emu::Slot* s = wave_emu::collective(v, 0, line * 8 + STEP);
+  const int l = static_cast<int>(lane());
+  const int row = l / 16, in_row = l % 16;
+  int src = -1;
+  if (STEP <= SCAN_SHR8) {
+    const int n = 1 << STEP;
+    if (in_row >= n) src = l - n;
+  } else if (STEP == SCAN_BCAST15) {
+    if (row == 1 || row == 3) src = row * 16 - 1;
+  } else {
+    if (row >= 2) src = 31;
+  }
+  return src >= 0 ? static_cast<uint32_t>(s[src].v[0]) : identity;
+}
+
 MODLE_DEV void sync_mem(int line = __builtin_LINE()) { (void)wave_emu::collective(0, 0, line); }
 MODLE_DEV void sync_lds(int line = __builtin_LINE()) { (void)wave_emu::collective(0, 0, line); }
 MODLE_DEV void lockstep(int line = __builtin_LINE()) { (void)wave_emu::collective(0, 0, line); }
