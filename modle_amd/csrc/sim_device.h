@@ -195,18 +195,23 @@ MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_
   u32 carry_lo = 0;  // keys below the last kept unit of the previous batch
 
   u32 carry_old = UNBOUND;  // position of the kept unit before this batch (UNBOUND: none)
-  u32 nxt_p = lane < n_old ? old_pos[lane] : UNBOUND;
-  u32 nxt_i = lane < n_old ? old_id[lane] : 0;
-  wave::await(nxt_p);
-  wave::await(nxt_i);
-  for (u32 base = 0; base < n_old; base += 64) {
+  constexpr u32 UX = 4;  // batches whose loads are in flight together
+  for (u32 group = 0; group < n_old; group += 64 * UX) {
+    u32 Pq[UX], Iq[UX];
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 aq = group + 64 * u + lane;
+      Pq[u] = aq < n_old ? old_pos[aq] : UNBOUND;
+      Iq[u] = aq < n_old ? old_id[aq] : 0;
+    }
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+    const u32 base = group + 64 * u;
+    if (base >= n_old) break;
     const u32 a = base + lane;
     const bool act = a < n_old;
-    const u32 pp = nxt_p;
-    const u32 oid = nxt_i;
-    const u32 an = a + 64;
-    nxt_p = an < n_old ? old_pos[an] : UNBOUND;
-    nxt_i = an < n_old ? old_id[an] : 0;
+    const u32 pp = Pq[u];
+    const u32 oid = Iq[u];
     bool tie = false;
     u32 lo = 0;
     if (act) {
@@ -235,8 +240,6 @@ MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_
           tie = lo < n_new && static_cast<u32>(keys[lo] >> 32) == pp;
         }
       }
-      wave::await(nxt_p);
-      wave::await(nxt_i);
       out_pos[a + lo] = pp;
       out_id[a + lo] = oid;
       where_new[oid] = a + lo;
@@ -246,6 +249,7 @@ MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_
     tie = tie || (act && pp != UNBOUND && prev == pp && (base != 0 || lane != 0));
     ties = wave::any(tie) || ties;
     carry_old = wave::bcast(pp, 63);
+    }
   }
   wave::sync_lds();
   for (u32 base = 0; base < n_new; base += 64) {
@@ -301,24 +305,25 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
   u32 n_old = 0, n_new = 0;
   u32 run_max = 0;  // max position of carried-over units in previous batches
 
-  // software pipeline: the next batch is requested before this one is processed and awaited
-  // before this one's stores are issued (wave::await)
-  u32 nxt_P = lane < n ? pos[lane] : 0;
-  u32 nxt_I = lane < n ? ids[lane] : 0;
-  u32 nxt_M = lane < n ? marks[lane] : 0;
-  wave::await(nxt_P);
-  wave::await(nxt_I);
-  wave::await(nxt_M);
-  for (u32 base = 0; base < n; base += 64) {
+  constexpr u32 UX = 4;  // batches whose loads are in flight together
+  for (u32 group = 0; group < n; group += 64 * UX) {
+    u32 Pq[UX], Iq[UX], Kq[UX];
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 kq = group + 64 * u + lane;
+      Pq[u] = kq < n ? pos[kq] : 0;
+      Iq[u] = kq < n ? ids[kq] : 0;
+      Kq[u] = kq < n ? marks[kq] : 0;
+    }
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+    const u32 base = group + 64 * u;
+    if (base >= n) break;
     const u32 k = base + lane;
     const bool act = k < n;
-    const u32 P = nxt_P;
-    const u32 id = nxt_I;
-    const bool fresh = act && (all_new || nxt_M == NEW_MARK);
-    const u32 kn = k + 64;
-    nxt_P = kn < n ? pos[kn] : 0;
-    nxt_I = kn < n ? ids[kn] : 0;
-    nxt_M = kn < n ? marks[kn] : 0;
+    const u32 P = Pq[u];
+    const u32 id = Iq[u];
+    const bool fresh = act && (all_new || Kq[u] == NEW_MARK);
     const bool carried = act && !fresh;
     const u32 pm = wave_prefix_max_u32(carried ? P : 0);
     const u32 incl_last = wave::bcast(pm, 63);
@@ -329,9 +334,6 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
     const bool is_old = carried && !displaced;
     const u64 mn = wave::ballot(is_new);
     const u64 mo = wave::ballot(is_old);
-    wave::await(nxt_P);
-    wave::await(nxt_I);
-    wave::await(nxt_M);
     if (is_new) {
       const u32 j = n_new + static_cast<u32>(wave::popc64(mn & lanemask_lt(lane)));
       new_id[j] = id;
@@ -346,6 +348,7 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
     n_new += static_cast<u32>(wave::popc64(mn));
     n_old += static_cast<u32>(wave::popc64(mo));
     run_max = umax(run_max, incl_last);
+    }
   }
   wave::sync_mem();
   if (n_old + n_new != n) {
@@ -524,11 +527,24 @@ MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp)
   i64 viol_rank = -1;
   // lanes hold the ranks of a batch in DESCENDING order (lane 0 = highest rank), so that the
   // suffix scan over ranks is a prefix scan over lanes
-  for (u32 bi = nbatch; bi-- > 0;) {
+  constexpr u32 UX = 4;  // batches whose loads are in flight together
+  for (u32 bg = 0; bg < nbatch; bg += UX) {
+    u32 Pq[UX], Mq[UX];
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const bool in = bg + u < nbatch;
+      const u32 kq = (nbatch - 1 - (bg + u)) * 64 + (63 - lane);
+      Pq[u] = in && kq < n ? ws.r_pos[kq] : UNBOUND;
+      Mq[u] = in && kq < n ? mv_in[kq] : 0;
+    }
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+    if (bg + u >= nbatch) break;
+    const u32 bi = nbatch - 1 - (bg + u);
     const u32 k = bi * 64 + (63 - lane);
     const bool act = k < n;
-    const u32 P = act ? ws.r_pos[k] : UNBOUND;
-    const u32 M = act ? mv_in[k] : 0;
+    const u32 P = Pq[u];
+    const u32 M = Mq[u];
     const bool bnd = act && P != UNBOUND;
     const bool okself = do_adjust && bnd && static_cast<u64>(P) > start + M;
     const i64 d = okself ? static_cast<i64>(P - M) - static_cast<i64>(k) : 0;
@@ -550,6 +566,7 @@ MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp)
     carry_d = wave::bcast(val, 63);
     carry_ok = wave::bcast(okself, 63);
     carry_cross = wave::bcast(cross, 63);
+    }
   }
   wave::sync_mem();
   if (viol_rank >= 0) {
@@ -583,11 +600,23 @@ MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp)
   i64 carry_d = 0;
   bool carry_ok = false, carry_cross = false;
   i64 viol_rank = -1;
-  for (u32 bi = 0; bi < nbatch; ++bi) {
+  constexpr u32 UX = 4;  // batches whose loads are in flight together
+  for (u32 bg = 0; bg < nbatch; bg += UX) {
+    u32 Pq[UX], Mq[UX];
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 kq = (bg + u) * 64 + lane;
+      Pq[u] = kq < n ? ws.f_pos[kq] : UNBOUND;
+      Mq[u] = kq < n ? mv_in[kq] : 0;
+    }
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+    const u32 bi = bg + u;
+    if (bi >= nbatch) break;
     const u32 k = bi * 64 + lane;
     const bool act = k < n;
-    const u32 P = act ? ws.f_pos[k] : UNBOUND;
-    const u32 M = act ? mv_in[k] : 0;
+    const u32 P = Pq[u];
+    const u32 M = Mq[u];
     const bool bnd = act && P != UNBOUND;
     const bool okself = do_adjust && bnd && static_cast<u64>(P) + M <= last;
     const i64 d = okself ? static_cast<i64>(static_cast<u64>(P) + M) - static_cast<i64>(k) : 0;
@@ -609,6 +638,7 @@ MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp)
     carry_d = wave::bcast(val, 63);
     carry_ok = wave::bcast(okself, 63);
     carry_cross = wave::bcast(cross, 63);
+    }
   }
   wave::sync_mem();
   if (viol_rank >= 0) {

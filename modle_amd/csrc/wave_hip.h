@@ -134,12 +134,6 @@ MODLE_DEV void sync_lds() {
 // lane overwrites data another lane has just read.  (The emulator yields here.)
 MODLE_DEV void lockstep() { __builtin_amdgcn_wave_barrier(); }
 
-// Makes the caller wait here for a value prefetched from device memory.  Used right before the
-// stores of a loop iteration: a wait for a load also waits for every store issued before it
-// (one in-order counter), so the prefetch of the next iteration is awaited first and the
-// stores are never waited for.
-MODLE_DEV void await(uint32_t v) { asm volatile("" ::"v"(v)); }
-
 // the instruction scheduler may not move anything across this point
 MODLE_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 

@@ -174,7 +174,6 @@ MODLE_DEV void lockstep(int line = __builtin_LINE()) { (void)wave_emu::collectiv
 
 MODLE_DEV uint64_t clock() { return 0; }
 MODLE_DEV void sched_fence() {}
-MODLE_DEV void await(uint32_t) {}
 
 MODLE_DEV void atomic_inc_u32(uint32_t* p) { __atomic_fetch_add(p, 1u, __ATOMIC_RELAXED); }
 MODLE_DEV void atomic_add_u64(uint64_t* p, uint64_t v) {
