@@ -85,9 +85,22 @@ MODLE_DEV_NOINLINE void phase_bind(Cell& c, u32 epoch_now) {
   const u32 lane = wave::lane();
   const u64 range = static_cast<u64>(iv.end) - 1 - iv.start;
   const u64 bucket = range != 0 ? uniform_int_bucket(range) : 1;
-  for (u32 base = 0; base < n; base += 64) {
+  constexpr u32 UX = 4;  // batches whose loads are in flight together
+  for (u32 group = 0; group < n; group += 64 * UX) {
+    u32 Eq[UX], Rq[UX], Fq[UX];
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 iq = group + 64 * u + lane;
+      Eq[u] = iq < n ? ws.epoch[iq] : 0;
+      Rq[u] = iq < n ? ws.r_rank[iq] : 0;
+      Fq[u] = iq < n ? ws.f_rank[iq] : 0;
+    }
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+    const u32 base = group + 64 * u;
+    if (base >= n) break;
     const u32 i = base + lane;
-    const bool unb = i < n && ws.epoch[i] == UNBOUND;
+    const bool unb = i < n && Eq[u] == UNBOUND;
     const u64 mask = wave::ballot(unb);
     if (mask == 0) continue;
     u32 posv = iv.start;
@@ -112,11 +125,12 @@ MODLE_DEV_NOINLINE void phase_bind(Cell& c, u32 epoch_now) {
     }
     if (unb) {
       ws.epoch[i] = epoch_now;
-      const u32 kr = ws.r_rank[i], kf = ws.f_rank[i];
+      const u32 kr = Rq[u], kf = Fq[u];
       ws.r_pos[kr] = posv;
       ws.r_move[kr] = NEW_MARK;
       ws.f_pos[kf] = posv;
       ws.f_move[kf] = NEW_MARK;
+    }
     }
   }
   wave::sync_mem();
@@ -696,20 +710,35 @@ MODLE_DEV_NOINLINE void barriers_next_state(Cell& c) {
   const Interval& iv = *c.iv;
   const u32 nb = wave::uniform(iv.n_barriers);
   const u32 lane = wave::lane();
-  for (u32 base = 0; base < nb; base += 64) {
-    const u32 i = base + lane;
-    const u32 cnt = umin(64u, nb - base);
-    rng_ensure(c.g, cnt);
-    if (i < nb) {
-      const f64 u = canonical_raw(rng_peek(c.g, c.g.pos + lane));
-      const u8 st = c.ws.bar_active[i];
-      if (!st && u > iv.bar_stp_inactive[i]) {
-        c.ws.bar_active[i] = 1;
-      } else if (st && u > iv.bar_stp_active[i]) {
-        c.ws.bar_active[i] = 0;
-      }
+  constexpr u32 UX = 4;  // batches whose loads are in flight together
+  for (u32 group = 0; group < nb; group += 64 * UX) {
+    u8 Sq[UX];
+    f64 Iq[UX], Aq[UX];
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 iq = group + 64 * u + lane;
+      Sq[u] = iq < nb ? c.ws.bar_active[iq] : u8(0);
+      Iq[u] = iq < nb ? iv.bar_stp_inactive[iq] : 0.0;
+      Aq[u] = iq < nb ? iv.bar_stp_active[iq] : 0.0;
     }
-    c.g.pos += cnt;
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 base = group + 64 * u;
+      if (base >= nb) break;
+      const u32 i = base + lane;
+      const u32 cnt = umin(64u, nb - base);
+      rng_ensure(c.g, cnt);
+      if (i < nb) {
+        const f64 r = canonical_raw(rng_peek(c.g, c.g.pos + lane));
+        const u8 st = Sq[u];
+        if (!st && r > Iq[u]) {
+          c.ws.bar_active[i] = 1;
+        } else if (st && r > Aq[u]) {
+          c.ws.bar_active[i] = 0;
+        }
+      }
+      c.g.pos += cnt;
+    }
   }
   wave::sync_mem();
 }
@@ -1673,13 +1702,26 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
     }
   }
   wave::sync_mem();
-  for (u32 base = 0; base < n; base += 64) {
+  for (u32 group = 0; group < n; group += 64 * UX) {
+    u32 Eq[UX], Hq[UX], Rq[UX], Fq[UX];
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 iq = group + 64 * u + lane;
+      Eq[u] = iq < n ? ws.epoch[iq] : UNBOUND;
+      Hq[u] = iq < n ? ws.stall[iq] : 0;
+      Rq[u] = iq < n ? ws.r_rank[iq] : 0;
+      Fq[u] = iq < n ? ws.f_rank[iq] : 0;
+    }
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+    const u32 base = group + 64 * u;
+    if (base >= n) break;
     const u32 i = base + lane;
     const bool act = i < n;
-    const u32 ep = act ? ws.epoch[i] : UNBOUND;
-    const u32 hard = act ? ws.stall[i] : 0;
-    const u32 kr = act ? ws.r_rank[i] : 0;
-    const u32 kf = act ? ws.f_rank[i] : 0;
+    const u32 ep = Eq[u];
+    const u32 hard = Hq[u];
+    const u32 kr = Rq[u];
+    const u32 kf = Fq[u];
     const bool bnd = ep != UNBOUND;
     f64 prob = 0.0;
     if (act) {
@@ -1699,6 +1741,7 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
       ws.epoch[i] = UNBOUND;
       ws.r_pos[kr] = UNBOUND;
       ws.f_pos[kf] = UNBOUND;
+    }
     }
   }
   wave::sync_mem();
@@ -1939,17 +1982,36 @@ MODLE_DEV_NOINLINE void compute_loop_size_stats(Cell& c) {
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
   const u32 cap = c.p->hist_len;
-  u32* loop_size = ws.tmp[0];
+  // pass A, rank order (contiguous reads, four batches in flight): every unit drops its position
+  // at its LEF's slot of two id-ordered scratch arrays; the sum of all loop sizes is the sum of
+  // the fwd positions minus the sum of the rev positions (released LEFs have both units at
+  // UNBOUND and cancel: loop size 0, like the reference)
+  u32* by_id_fwd = ws.tmp[0];
+  u32* by_id_rev = ws.tmp[1];
+  constexpr u32 UX = 4;
   u64 part = 0;
-  for (u32 base = 0; base < n; base += 64) {
-    const u32 i = base + lane;
-    if (i < n) {
-      // released LEFs have both units at UNBOUND: loop size 0, like the reference
-      const u32 ls = ws.f_pos[ws.f_rank[i]] - ws.r_pos[ws.r_rank[i]];
-      loop_size[i] = ls;
-      part += ls;
+  for (u32 group = 0; group < n; group += 64 * UX) {
+    u32 fP[UX], fI[UX], rP[UX], rI[UX];
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 k = group + 64 * u + lane;
+      const bool act = k < n;
+      fP[u] = act ? ws.f_pos[k] : 0;
+      fI[u] = act ? ws.f_id[k] : 0;
+      rP[u] = act ? ws.r_pos[k] : 0;
+      rI[u] = act ? ws.r_id[k] : 0;
+    }
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 k = group + 64 * u + lane;
+      if (k < n) {
+        by_id_fwd[fI[u]] = fP[u];
+        by_id_rev[rI[u]] = rP[u];
+        part += static_cast<u64>(fP[u]) - static_cast<u64>(rP[u]);
+      }
     }
   }
+  wave::sync_mem();
 #pragma unroll
   for (u32 s = 1; s < 64; s <<= 1) {
     const u64 o = wave::shfl_down(part, s);
@@ -1957,18 +2019,31 @@ MODLE_DEV_NOINLINE void compute_loop_size_stats(Cell& c) {
   }
   const u64 total = wave::bcast(part, 0);
   const f64 avg = static_cast<f64>(total) / static_cast<f64>(n);
-  // strictly sequential accumulation: every lane computes its term, the terms of a batch are
-  // then folded in lane order through broadcasts (no memory round trip)
+  // pass B, LEF-id order: strictly sequential accumulation like std::accumulate: every lane
+  // computes its term, the terms of a batch are folded in lane order through broadcasts
   f64 ssd = 0.0;
-  for (u32 base = 0; base < n; base += 64) {
-    const u32 i = base + lane;
-    f64 term = 0.0;
-    if (i < n) {
-      const f64 d = static_cast<f64>(static_cast<u64>(loop_size[i])) - avg;
-      term = d * d;
+  for (u32 group = 0; group < n; group += 64 * UX) {
+    u32 lf[UX], lr[UX];
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 i = group + 64 * u + lane;
+      lf[u] = i < n ? by_id_fwd[i] : 0;
+      lr[u] = i < n ? by_id_rev[i] : 0;
     }
-    const u32 cnt = umin(64u, n - base);
-    for (u32 l = 0; l < cnt; ++l) ssd = ssd + wave::bcast(term, l);
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 base = group + 64 * u;
+      if (base >= n) break;
+      const u32 i = base + lane;
+      f64 term = 0.0;
+      if (i < n) {
+        const u32 ls = lf[u] - lr[u];
+        const f64 d = static_cast<f64>(static_cast<u64>(ls)) - avg;
+        term = d * d;
+      }
+      const u32 cnt = umin(64u, n - base);
+      for (u32 l = 0; l < cnt; ++l) ssd = ssd + wave::bcast(term, l);
+    }
   }
   const f64 std = wave::f_sqrt(ssd / static_cast<f64>(n));
   // push_back with pop_front at capacity (two deque<double>)
