@@ -25,6 +25,25 @@ CASES = {
     # burn-in skipped: every LEF is bound in epoch 0 (full-sort path of the ranking)
     "chr6mb_skip_burnin": dict(size=6_000_000, barriers=True,
                                cfg=dict(num_cells=128, skip_burnin=1)),
+    # edge cases ------------------------------------------------------------------------------
+    # 60 kb: compute_num_lefs rounds to a single LEF (ranking, scans and windows of width 1).
+    # Burn-in is skipped: the loop-size history of a single LEF does not settle, and with the
+    # default max_burnin_epochs (none) the reference's burn-in would not end either.
+    "tiny_single_lef": dict(size=60_000, barriers=True,
+                            cfg=dict(num_cells=8, simulate_chromosomes_wo_barriers=1,
+                                     skip_burnin=1)),
+    # more cells than target contacts: most cells get num_target_contacts = 0 and stop at the
+    # first stop-condition check after init_states (scheduler_simulate.cpp:129-141, 234)
+    "zero_target_cells": dict(size=400_000, barriers=True,
+                              cfg=dict(num_cells=4096, target_contact_density=0.05)),
+    # stop on a number of epochs instead of a contact density, TAD contacts only.  (With burn-in
+    # the unsigned `epoch - num_burnin_epochs` of the reference's stop condition underflows as
+    # soon as the first epoch needs two burn-in rounds, simulation.cpp:930 + 866-894, and the
+    # cell ends after one epoch; that behaviour is reproduced, but it makes a poor test.)
+    "epochs_stop_tad_only": dict(size=3_000_000, barriers=True,
+                                 cfg=dict(num_cells=16, target_contact_density=-1.0,
+                                          target_simulation_epochs=40, skip_burnin=1,
+                                          contact_sampling_strategy=3)),
 }
 
 
