@@ -133,7 +133,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # under torch.distributed.run the RCCL path runs even with one rank (same code as N > 1)
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if use_dist:
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=dev)
@@ -182,7 +184,7 @@ def main():
                 t[1].zero_()
         sim.launch(stream.cuda_stream)
         sim.wait()
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
 
             for t in tensors:
@@ -193,7 +195,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
 
             dist.barrier()
@@ -211,7 +213,7 @@ def main():
         first = False
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
 
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -264,7 +266,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, genome, unit, args.cpu_sample_cells)
         print(json.dumps(out), flush=True)
     sim.close()
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
 
         dist.destroy_process_group()

@@ -8,9 +8,9 @@
 // Conventions
 //   * "uniform" values are identical in all 64 lanes; every collective (ballot / shuffle / sync)
 //     is issued from wave-uniform control flow.
-//   * Per-cell state lives in the wave's Workspace (device memory), indexed by LEF id with two
-//     rank arrays giving the 5'->3' order of rev / fwd units, like the reference's State buffers
-//     (reference: src/libmodle/cpu/include/modle/simulation.hpp:86-94) but with 32-bit fields.
+//   * Per-cell state lives in the wave's Workspace (device memory): extrusion units in rank order,
+//     rev and fwd separately, plus id-ordered binding epochs and the inverse permutations
+//     (layout in sim_types.h / sim_device.h); 32-bit fields throughout.
 //   * The cell's single xoshiro256++ stream is produced in blocks of RNG_BLOCK raw outputs by
 //     all 64 lanes (lane l owns RNG_CHUNK consecutive outputs of every block and hops to its
 //     chunk of the next block with a GF(2) jump table) and consumed strictly in the reference's
