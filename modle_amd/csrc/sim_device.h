@@ -584,19 +584,26 @@ MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp)
   }
   wave::sync_mem();
   if (viol_rank >= 0) {
-    // sequential replay (reference loop) from the first rank whose decision the scan got wrong
+    // sequential replay (reference loop) from the first rank whose decision the scan got wrong.
+    // The reference adjusts all moves first and clamps afterwards, so the replay carries the
+    // UNCLAMPED updated move of the unit it has just left (mv_out holds clamped values); the
+    // unit it starts from is the one whose updated move crosses the 5'-end.
+    bool first = true;
+    u32 M2u = 0;
     for (u32 i = static_cast<u32>(viol_rank); i > 0; --i) {
       u32 M1 = mv_in[i - 1];
       const u64 P1 = ws.r_pos[i - 1], P2 = ws.r_pos[i];
-      if (P1 != UNBOUND && P2 != UNBOUND) {
-        const u32 M2 = mv_out[i];
-        if (!(P1 <= start + M1 || P2 <= start + M2)) {
-          const u64 pos1 = P1 - M1, pos2 = P2 - M2;
+      const bool both = P1 != UNBOUND && P2 != UNBOUND;
+      if (both) {
+        const bool cross2 = first || P2 <= start + M2u;
+        if (!(P1 <= start + M1 || cross2)) {
+          const u64 pos1 = P1 - M1, pos2 = P2 - M2u;
           if (pos2 <= pos1) M1 += static_cast<u32>(pos1 - pos2) + 1;
         }
-        if (do_clamp) M1 = umin(M1, static_cast<u32>(P1 - start));
       }
-      mv_out[i - 1] = M1;
+      M2u = M1;
+      first = false;
+      mv_out[i - 1] = (P1 != UNBOUND && do_clamp) ? umin(M1, static_cast<u32>(P1 - start)) : M1;
     }
     wave::sync_mem();
   }
@@ -656,18 +663,24 @@ MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp)
   }
   wave::sync_mem();
   if (viol_rank >= 0) {
+    // see adjust_moves_rev: the replay works on unclamped moves; unit viol_rank is the one whose
+    // updated move crosses the 3'-end
+    bool first = true;
+    u32 M1u = 0;
     for (u32 i = static_cast<u32>(viol_rank) + 1; i < n; ++i) {
       u32 M2 = mv_in[i];
       const u64 P1 = ws.f_pos[i - 1], P2 = ws.f_pos[i];
-      if (P1 != UNBOUND && P2 != UNBOUND) {
-        const u32 M1 = mv_out[i - 1];
-        if (!(P1 + M1 > last || P2 + M2 > last)) {
-          const u64 pos1 = P1 + M1, pos2 = P2 + M2;
+      const bool both = P1 != UNBOUND && P2 != UNBOUND;
+      if (both) {
+        const bool cross1 = first || P1 + M1u > last;
+        if (!(cross1 || P2 + M2 > last)) {
+          const u64 pos1 = P1 + M1u, pos2 = P2 + M2;
           if (pos1 >= pos2) M2 += static_cast<u32>(pos1 - pos2) + 1;
         }
-        if (do_clamp) M2 = umin(M2, static_cast<u32>(last - P2));
       }
-      mv_out[i] = M2;
+      M1u = M2;
+      first = false;
+      mv_out[i] = (P2 != UNBOUND && do_clamp) ? umin(M2, static_cast<u32>(last - P2)) : M2;
     }
     wave::sync_mem();
   }
@@ -1158,8 +1171,12 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
   if (bc.n5 == n || bc.n3 == n) return;
   const u32 lane = wave::lane();
   const u32 i2 = bc.n3 == 0 ? n : n - (bc.n3 - 1);
-  const bool trials = p.p_bypass != 0.0;
+  // run_lef_lef_collision_trial (simulation_impl.hpp:93-96): no draw when the bypass probability
+  // is 0 (always collide) -- and none when it is 1: bernoulli_distribution(0) returns false
+  // without touching the engine
   const f64 p_collide = 1.0 - p.p_bypass;
+  const bool never_collide = p.p_bypass != 0.0 && p_collide == 0.0;
+  const bool trials = p.p_bypass != 0.0 && !never_collide;
   const u32 prim = EV_COLLISION | EV_LEF_LEF_PRIMARY;
   // LDS slices of the fwd-side arrays, ranks [w0, w0 + STAGE_CAP): positions in the staging
   // buffer, moves / collision words / ids in the (idle) sort buffer
@@ -1238,7 +1255,7 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
       }
     }
     const u64 cm = wave::ballot(cand);
-    bool hit = cand;
+    bool hit = cand && !never_collide;
     if (trials && cm != 0) {
       const u32 cnt = static_cast<u32>(wave::popc64(cm));
       rng_ensure(c.g, cnt);
@@ -1356,8 +1373,12 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
   const u32* barpos = stalling_barrier_positions<FWD>(ws);
   u32* moves = FWD ? ws.f_move : ws.r_move;
   u32* coll = FWD ? ws.f_coll : ws.r_coll;
-  const bool trials = p.p_bypass != 0.0;
+  // run_lef_lef_collision_trial (simulation_impl.hpp:93-96): no draw when the bypass probability
+  // is 0 (always collide) -- and none when it is 1: bernoulli_distribution(0) returns false
+  // without touching the engine
   const f64 p_collide = 1.0 - p.p_bypass;
+  const bool never_collide = p.p_bypass != 0.0 && p_collide == 0.0;
+  const bool trials = p.p_bypass != 0.0 && !never_collide;
   u32 n_list = 0;
   // rev: followers i = max(1, n5) .. n-1 ascending, blocker = rank i-1
   // fwd: followers i-1 for i = (n - min(n3, n3-1) - 1) .. 1 descending, blocker = rank i
@@ -1436,7 +1457,7 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
                              : (static_cast<u64>(P) - M <= static_cast<u64>(bP) - bM);
         const bool draws = mine && cw_occurred(bC) && geo;
         const u64 dm = wave::ballot(draws);
-        bool collide = draws;
+        bool collide = draws && !never_collide;
         if (trials && dm != 0) {
           const u32 cnt = static_cast<u32>(wave::popc64(dm));
           rng_ensure(c.g, cnt);
@@ -2287,6 +2308,17 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
       status = c.error;
       break;
     }
+#ifdef MODLE_TRACE
+    if (wave::lane() == 0 && getenv("MO_TRACE_EPOCH") &&
+        static_cast<u64>(atoll(getenv("MO_TRACE_EPOCH"))) == epoch) {
+      for (u32 i = 0; i < c.n_active; ++i) {
+        const u32 kr = c.ws.r_rank[i], kf = c.ws.f_rank[i];
+        fprintf(stderr, "D %u %u %u %u %u %u:%u %u:%u\n", i, c.ws.r_pos[kr], c.ws.f_pos[kf],
+                c.ws.r_move[kr], c.ws.f_move[kf], cw_event(c.ws.r_coll[kr]),
+                cw_index(c.ws.r_coll[kr]), cw_event(c.ws.f_coll[kf]), cw_index(c.ws.f_coll[kf]));
+      }
+    }
+#endif
     PHASE(c, 13, phase_extrude_and_release(c, burnin_completed));
     trace_stage(c, epoch, 4);
 #ifdef MODLE_TRACE

@@ -1,0 +1,25 @@
+"""The same differential test as tests/test_gpu_fuzz_parity.py with the device code running under
+the CPU lane emulator (one cell per set-up: the emulator is slow)."""
+import pytest
+
+import emu_sim
+from fuzz_cases import random_case
+from modle_amd import api
+from parity_cases import assert_same_outputs, assert_same_results
+
+
+@pytest.mark.parametrize("seed", [100, 101, 105, 108, 1148])
+def test_emulated_device_code_matches_oracle_on_random_setups(oracle, seed):
+    case = random_case(seed)
+    cfg, chrom = case["cfg"], case["chrom"]
+    tasks = api.slice_tasks(case["tasks"], 0, 1)
+    track = bool(cfg.track_1d_lef_position)
+    oc, om, oo, ores = oracle.simulate_interval(
+        cfg, chrom["start"], chrom["end"], chrom["bar_pos"], chrom["bar_dir"],
+        case["stp_active"], case["stp_inactive"], tasks, nthreads=1, track_occupancy=track)
+    ec, em, eo, eres = emu_sim.simulate_interval(
+        cfg, chrom["start"], chrom["end"], chrom["bar_pos"], chrom["bar_dir"], case["stp_active"],
+        case["stp_inactive"], tasks, case["nrows"], case["ncols"], track_occupancy=track)
+    what = f"seed {seed}: {case['kw']}, size {case['size']}"
+    assert_same_results(ores, eres, what)
+    assert_same_outputs((oc, om, oo), (ec, em, eo), what)
