@@ -1,7 +1,19 @@
-"""Seeded random simulation set-ups for the differential tests (GPU / emulator vs oracle)."""
+"""Seeded random simulation set-ups for the differential tests (GPU / emulator vs oracle).
+
+`random_case(seed)` is the generator the committed regression seeds refer to; `random_case_v2`
+widens the space (intervals that do not start at 0, barrier density, extrusion speeds and
+their spread, LEF processivity, sampling interval, noise parameters)."""
 import numpy as np
 
 from modle_amd import api, synthetic
+
+
+def _finish(cfg, chrom, kw, size):
+    stp_active, stp_inactive = api.barrier_stps(cfg, chrom["bar_occupancy"])
+    tasks = api.make_tasks(cfg, chrom["name"], chrom["size"], chrom["start"], chrom["end"])
+    nrows, ncols = api.matrix_shape(cfg, chrom["end"] - chrom["start"])
+    return dict(cfg=cfg, chrom=chrom, stp_active=stp_active, stp_inactive=stp_inactive,
+                tasks=tasks, nrows=nrows, ncols=ncols, kw=kw, size=size)
 
 
 def random_case(seed):
@@ -30,8 +42,52 @@ def random_case(seed):
     with_barriers = bool(rng.random() < 0.85)
     cfg = api.make_config(**cfg_kw)
     chrom = synthetic.synthetic_chromosome(f"chrF{seed}", size, seed=seed, with_barriers=with_barriers)
-    stp_active, stp_inactive = api.barrier_stps(cfg, chrom["bar_occupancy"])
-    tasks = api.make_tasks(cfg, chrom["name"], chrom["size"], chrom["start"], chrom["end"])
-    nrows, ncols = api.matrix_shape(cfg, chrom["end"] - chrom["start"])
-    return dict(cfg=cfg, chrom=chrom, stp_active=stp_active, stp_inactive=stp_inactive,
-                tasks=tasks, nrows=nrows, ncols=ncols, kw=cfg_kw, size=size)
+    return _finish(cfg, chrom, cfg_kw, size)
+
+
+def random_case_v2(seed):
+    rng = np.random.default_rng(seed ^ 0x5EED)
+    chrom_size = int(rng.integers(400_000, 12_000_000))
+    # simulated interval: the whole chromosome, or a window that starts / ends inside it
+    start, end = 0, chrom_size
+    if rng.random() < 0.5:
+        start = int(rng.integers(0, chrom_size // 2))
+        end = int(rng.integers(start + chrom_size // 4, chrom_size + 1))
+    cfg_kw = dict(
+        num_cells=int(rng.integers(4, 24)),
+        seed=int(rng.integers(0, 2**31)),
+        number_of_lefs_per_mbp=float(rng.choice([5.0, 20.0, 33.3, 64.0])),
+        probability_of_extrusion_unit_bypass=float(rng.choice([0.0, 0.05, 0.1, 0.3])),
+        lef_bar_major_collision_pblock=float(rng.choice([1.0, 0.95, 0.7])),
+        lef_bar_minor_collision_pblock=float(rng.choice([0.0, 0.1, 0.3])),
+        soft_stall_lef_stability_multiplier=float(rng.choice([1.0, 2.0])),
+        hard_stall_lef_stability_multiplier=float(rng.choice([5.0, 2.0])),
+        contact_sampling_strategy=int(rng.choice([7, 6, 5, 4, 3, 2])),
+        tad_to_loop_contact_ratio=float(rng.choice([5.0, 0.0, 2.0])),
+        track_1d_lef_position=int(rng.integers(0, 2)),
+        target_contact_density=float(rng.choice([0.5, 0.1])),
+        diagonal_width=int(rng.choice([3_000_000, 1_000_000])),
+        bin_size=int(rng.choice([5000, 10000])),
+        skip_burnin=int(rng.random() < 0.25),
+        simulate_chromosomes_wo_barriers=1,
+        max_burnin_epochs=1200,
+        avg_lef_processivity=int(rng.choice([300_000, 100_000, 800_000])),
+        contact_sampling_interval=int(rng.choice([50_000, 20_000, 150_000])),
+        genextreme_sigma=float(rng.choice([12_500.0, 4_000.0])),
+        genextreme_xi=float(rng.choice([0.001, 0.0, 0.2])),
+    )
+    speed = rng.choice(["default", "slow_fwd", "no_spread"])
+    if speed == "slow_fwd":
+        cfg_kw.update(rev_extrusion_speed=int(cfg_kw["bin_size"] // 2), rev_extrusion_speed_set=1,
+                      fwd_extrusion_speed=int(cfg_kw["bin_size"] // 5), fwd_extrusion_speed_set=1)
+    elif speed == "no_spread":
+        cfg_kw.update(rev_extrusion_speed_std=0.0, fwd_extrusion_speed_std=0.0)
+    cfg = api.make_config(**cfg_kw)
+    spacing = int(rng.choice([79_564, 25_000, 300_000]))
+    full = synthetic.synthetic_chromosome(f"chrG{seed}", chrom_size, seed=seed,
+                                          with_barriers=bool(rng.random() < 0.9), spacing=spacing)
+    inside = (full["bar_pos"] >= start) & (full["bar_pos"] < end)
+    chrom = dict(name=full["name"], size=chrom_size, start=start, end=end,
+                 bar_pos=full["bar_pos"][inside], bar_dir=full["bar_dir"][inside],
+                 bar_occupancy=full["bar_occupancy"][inside])
+    return _finish(cfg, chrom, dict(cfg_kw, start=start, end=end, spacing=spacing), end - start)

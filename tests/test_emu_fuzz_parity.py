@@ -3,14 +3,22 @@ the CPU lane emulator (one cell per set-up: the emulator is slow)."""
 import pytest
 
 import emu_sim
-from fuzz_cases import random_case
+from fuzz_cases import random_case, random_case_v2
 from modle_amd import api
 from parity_cases import assert_same_outputs, assert_same_results
 
 
 @pytest.mark.parametrize("seed", [100, 101, 105, 108, 1148])
 def test_emulated_device_code_matches_oracle_on_random_setups(oracle, seed):
-    case = random_case(seed)
+    _compare(oracle, random_case(seed), f"seed {seed}")
+
+
+@pytest.mark.parametrize("seed", [4, 5, 6, 8])
+def test_emulated_device_code_matches_oracle_on_random_setups_v2(oracle, seed):
+    _compare(oracle, random_case_v2(seed), f"v2 seed {seed}")
+
+
+def _compare(oracle, case, label):
     cfg, chrom = case["cfg"], case["chrom"]
     tasks = api.slice_tasks(case["tasks"], 0, 1)
     track = bool(cfg.track_1d_lef_position)
@@ -20,6 +28,6 @@ def test_emulated_device_code_matches_oracle_on_random_setups(oracle, seed):
     ec, em, eo, eres = emu_sim.simulate_interval(
         cfg, chrom["start"], chrom["end"], chrom["bar_pos"], chrom["bar_dir"], case["stp_active"],
         case["stp_inactive"], tasks, case["nrows"], case["ncols"], track_occupancy=track)
-    what = f"seed {seed}: {case['kw']}, size {case['size']}"
+    what = f"{label}: {case['kw']}, size {case['size']}"
     assert_same_results(ores, eres, what)
     assert_same_outputs((oc, om, oo), (ec, em, eo), what)

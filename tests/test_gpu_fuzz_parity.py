@@ -3,7 +3,7 @@ probabilities, stall multipliers, sampling strategies, resolutions): every outpu
 per-cell counter of the HIP path must equal the oracle's."""
 import pytest
 
-from fuzz_cases import random_case
+from fuzz_cases import random_case, random_case_v2
 from parity_cases import assert_same_outputs, assert_same_results
 
 pytestmark = pytest.mark.gpu
@@ -11,9 +11,18 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("seed", list(range(100, 116)) + [1121, 1148, 1178, 5482, 5645, 6024])
 def test_gpu_matches_oracle_on_random_setups(oracle, seed):
+    _compare(oracle, random_case(seed), f"seed {seed}")
+
+
+@pytest.mark.parametrize("seed", list(range(1, 13)))
+def test_gpu_matches_oracle_on_random_setups_v2(oracle, seed):
+    """wider generator: windows that do not start at 0, barrier density, speeds, noise, ..."""
+    _compare(oracle, random_case_v2(seed), f"v2 seed {seed}")
+
+
+def _compare(oracle, case, label):
     from modle_amd import api
 
-    case = random_case(seed)
     cfg, chrom = case["cfg"], case["chrom"]
     tasks = api.slice_tasks(case["tasks"], 0, min(12, len(case["tasks"])))
     track = bool(cfg.track_1d_lef_position)
@@ -27,6 +36,6 @@ def test_gpu_matches_oracle_on_random_setups(oracle, seed):
             case["stp_inactive"], tasks)
     finally:
         sim.close()
-    what = f"seed {seed}: {case['kw']}, size {case['size']}"
+    what = f"{label}: {case['kw']}, size {case['size']}"
     assert_same_results(ores, gres, what)
     assert_same_outputs((oc, om, oo), (gc, gm, go if track else None), what)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Differential fuzz campaign on the GPU: python tools/fuzz_campaign.py FIRST_SEED N_SEEDS
+"""Differential fuzz campaign on the GPU: python tools/fuzz_campaign.py FIRST_SEED N_SEEDS [v2]
 (random set-ups of tests/fuzz_cases.py, HIP path vs oracle, all outputs and per-cell counters)."""
 import os
 import sys
@@ -11,16 +11,17 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 
-from fuzz_cases import random_case  # noqa: E402
+from fuzz_cases import random_case, random_case_v2  # noqa: E402
 from modle_amd import api  # noqa: E402
 from oracle import binding as oracle  # noqa: E402
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
+gen = random_case_v2 if len(sys.argv) > 3 and sys.argv[3] == "v2" else random_case
 bad = 0
 skipped = 0
 t0 = time.time()
 for seed in range(first, first + count):
-    case = random_case(seed)
+    case = gen(seed)
     cfg, chrom = case["cfg"], case["chrom"]
     tasks = api.slice_tasks(case["tasks"], 0, min(8, len(case["tasks"])))
     # keep the oracle's share of the run short: skip set-ups whose cells need many epochs
