@@ -91,3 +91,32 @@ def test_chr1_scale_properties():
         assert r.burnin_epochs >= cfg.burnin_target_epochs_for_lef_activation
         assert r.epochs > r.burnin_epochs
         assert r.sim_epochs <= r.epochs
+
+
+@pytest.mark.parametrize("skip_burnin,ncells,extra", [
+    (0, 8, {}), (1, 6, {}),
+    # BASELINE config 4 shape: 64 LEFs/Mb (15 933 LEFs on chr1), minor-collision trials, soft stalls
+    (0, 3, dict(number_of_lefs_per_mbp=64.0, lef_bar_minor_collision_pblock=0.3,
+                soft_stall_lef_stability_multiplier=2.0, num_cells=4096))])
+def test_chr1_scale_matches_oracle(oracle, skip_burnin, ncells, extra):
+    """BASELINE config 1 shape (chr1: 4979 LEFs, 3129 barriers) against the oracle, cell by cell.
+    With burn-in skipped every LEF binds in epoch 0: the ranking sorts 4979 new keys in device
+    memory instead of LDS, and barrier windows / staged slices are re-staged many times."""
+    from modle_amd import api, synthetic
+    from parity_cases import assert_same_outputs, assert_same_results
+
+    chrom = synthetic.grch38_like(seed=42, chroms={"chr1"})[0]
+    cfg = api.make_config(**dict(dict(num_cells=512, seed=0, skip_burnin=skip_burnin), **extra))
+    tasks = api.slice_tasks(api.make_tasks(cfg, chrom["name"], chrom["size"], chrom["start"],
+                                           chrom["end"]), 0, ncells)
+    stp_a, stp_i = api.barrier_stps(cfg, chrom["bar_occupancy"])
+    oc, om, oo, ores = oracle.simulate_interval(cfg, chrom["start"], chrom["end"], chrom["bar_pos"],
+                                                chrom["bar_dir"], stp_a, stp_i, tasks, nthreads=8)
+    sim = api.Simulator(cfg, 0)
+    try:
+        gc, gm, go, gres = sim.simulate_interval(chrom["start"], chrom["end"], chrom["bar_pos"],
+                                                 chrom["bar_dir"], stp_a, stp_i, tasks)
+    finally:
+        sim.close()
+    assert_same_results(ores, gres, "chr1")
+    assert_same_outputs((oc, om, oo), (gc, gm, go), "chr1")
