@@ -2062,8 +2062,10 @@ MODLE_DEV_NOINLINE void compute_loop_size_stats(Cell& c) {
         const f64 d = static_cast<f64>(static_cast<u64>(ls)) - avg;
         term = d * d;
       }
-      const u32 cnt = umin(64u, n - base);
-      for (u32 l = 0; l < cnt; ++l) ssd = ssd + wave::bcast(term, l);
+      // lanes past the end hold +0.0, which leaves the (non-negative) running sum unchanged, so
+      // all 64 terms are folded with constant lane indices (no loop control in the chain)
+#pragma unroll
+      for (u32 l = 0; l < 64; ++l) ssd = ssd + wave::bcast(term, l);
     }
   }
   const f64 std = wave::f_sqrt(ssd / static_cast<f64>(n));
