@@ -449,6 +449,86 @@ MODLE_DEV u32 move_from_normal(f64 unit, f64 speed, f64 std) {
   return static_cast<u32>(static_cast<u64>(wave::f_round(v > 0.0 ? v : 0.0)));
 }
 
+// Queue of drawn moves (LDS, c.lds.stage): entry e lives at slot e % MOVQ_CAP, its move in the
+// first half of the buffer and the low word of the stream position right after its draw in the
+// second half.
+constexpr u32 MOVQ_CAP = STAGE_CAP / 2;
+
+// One step of the draw stream of generate_moves: lane l evaluates the normal-distribution attempt
+// that would start at stream position pos + l (Boost's ziggurat, sim_rng.h: unit_normal_exact).
+// An attempt takes one raw output (the strip's rectangle, ~98.8 %) or two (wedge test: accepted
+// or rejected); which positions really start an attempt follows from the chain "an attempt that
+// takes two outputs hides the position after it".  Accepted attempts are appended to the queue in
+// stream order; the rare attempts whose length is data dependent beyond that (tail of the
+// distribution, a uniform_01 retry) are replayed by the sequential routine.  Returns the new
+// queue tail; uniform.
+MODLE_DEV u32 draw_moves_step(Cell& c, f64 speed, f64 std, u32 tail) {
+  const u32 lane = wave::lane();
+  Rng& g = c.g;
+  u32* q_move = c.lds.stage;
+  u32* q_end = c.lds.stage + MOVQ_CAP;
+  rng_ensure(g, 65);
+  u32 bucket;
+  const f64 u = int_float_pair8(rng_peek(g, g.pos + lane), bucket);
+  const u32 layer = bucket >> 1;
+  const f64 xi = c.lds.zig_norm_x[layer], xi1 = c.lds.zig_norm_x[layer + 1];
+  const f64 x = u * xi;
+  const bool fast = x < xi1;
+  bool accept = fast, irregular = false;
+  if (!fast) {
+    if (layer == 0) {
+      irregular = true;  // tail of the distribution
+    } else {
+      const f64 y01 = static_cast<f64>(rng_peek(g, g.pos + lane + 1)) * TWO_M64;
+      if (!(y01 < 1.0)) {
+        irregular = true;  // uniform_01 draws again
+      } else {
+        const f64 yi = c.lds.zig_norm_y[layer], yi1 = c.lds.zig_norm_y[layer + 1];
+        const f64 y = yi + y01 * (yi1 - yi);
+        const f64 chord = (xi - xi1) * y01 - (xi - x);
+        const f64 tangent = y - (yi + (xi - x) * yi * xi);
+        const f64 y_above_ubound = (xi >= 1) ? chord : tangent;
+        const f64 y_above_lbound = (xi >= 1) ? tangent : chord;
+        accept = y_above_ubound < 0 && (y_above_lbound < 0 || y < wave::f_exp(-(x * x / 2)));
+      }
+    }
+  }
+  const u32 mv = move_from_normal((bucket & 1u) ? x : -x, speed, std);
+  // positions that start a two-output attempt: every other position of a run of slow positions
+  u64 two = wave::ballot(!fast);
+  u64 dbl = 0;
+  while (two != 0) {
+    const u32 b = static_cast<u32>(wave::ctz64(two));
+    dbl |= u64(1) << b;
+    two &= ~(u64(3) << b);
+  }
+  const u64 starts = ~(dbl << 1);
+  const u64 irr = wave::ballot(irregular) & starts;
+  const u32 stop = irr != 0 ? static_cast<u32>(wave::ctz64(irr)) : 64u;  // first irregular attempt
+  const u64 below = stop < 64 ? lanemask_lt(stop) : ~u64(0);
+  const u64 acc = wave::ballot(accept) & starts & below;
+  wave::lockstep();  // queue slots read by the consumer of the previous step may be overwritten
+  if ((acc >> lane) & 1u) {
+    const u32 e = tail + static_cast<u32>(wave::popc64(acc & lanemask_lt(lane)));
+    q_move[e % MOVQ_CAP] = mv;
+    q_end[e % MOVQ_CAP] = static_cast<u32>(g.pos) + lane + 1 + static_cast<u32>((dbl >> lane) & 1u);
+  }
+  tail += static_cast<u32>(wave::popc64(acc));
+  if (stop == 64) {
+    g.pos += 64 + static_cast<u32>(dbl >> 63);
+  } else {
+    g.pos += stop;
+    const f64 exact = unit_normal_exact(g, c.lds);
+    if (lane == 0) {
+      q_move[tail % MOVQ_CAP] = move_from_normal(exact, speed, std);
+      q_end[tail % MOVQ_CAP] = static_cast<u32>(g.pos);
+    }
+    ++tail;
+  }
+  wave::sync_lds();
+  return tail;
+}
+
 template <bool FWD>
 MODLE_DEV_NOINLINE void generate_moves_dir(Cell& c, f64 speed, f64 std) {
   Workspace& ws = c.ws;
@@ -464,6 +544,12 @@ MODLE_DEV_NOINLINE void generate_moves_dir(Cell& c, f64 speed, f64 std) {
     }
     return;
   }
+  // Bound LEFs take the draws in id order.  The draws are produced 64 stream positions at a time
+  // into a queue, independently of how the LEFs fall into batches; what the last step produced
+  // beyond the draw of the last bound LEF is handed back by rewinding the stream position.
+  const u32* q_move = c.lds.stage;
+  const u32* q_end = c.lds.stage + MOVQ_CAP;
+  u32 head = 0, tail = 0;  // entries consumed / produced
   constexpr u32 UX = 4;  // batches whose loads are in flight together
   for (u32 group = 0; group < n; group += 64 * UX) {
     u32 Eq[UX], Sq[UX];
@@ -481,39 +567,20 @@ MODLE_DEV_NOINLINE void generate_moves_dir(Cell& c, f64 speed, f64 std) {
     const bool act = i < n;
     const bool bnd = act && Eq[u] != UNBOUND;
     const u32 slot = Sq[u];
-    // bound LEFs of the batch still waiting for their draw, in id order.  Every pass gives each
-    // of them the raw output it would get if all draws before it took the fast path; the first
-    // one that needs the slow path is replayed exactly and the ones after it are re-evaluated
-    // at their shifted stream positions (registers only: nothing is re-read from memory).
-    u64 pending = wave::ballot(bnd);
+    const u64 bm = wave::ballot(bnd);
+    const u32 need = static_cast<u32>(wave::popc64(bm));
+    while (tail - head < need) tail = draw_moves_step(c, speed, std, tail);
     u32 mv = 0;
-    while (pending != 0) {
-      const u32 ndraw = static_cast<u32>(wave::popc64(pending));
-      rng_ensure(c.g, ndraw);
-      const bool mine = ((pending >> lane) & 1u) != 0;
-      const u32 k = static_cast<u32>(wave::popc64(pending & lanemask_lt(lane)));
-      u32 bucket;
-      const f64 u = int_float_pair8(rng_peek(c.g, c.g.pos + k), bucket);
-      const u32 layer = bucket >> 1;
-      const f64 x = u * c.lds.zig_norm_x[layer];
-      const bool fast = x < c.lds.zig_norm_x[layer + 1];
-      const f64 unit = (bucket & 1u) ? x : -x;
-      const u64 slow = wave::ballot(mine && !fast);
-      if (slow == 0) {
-        if (mine) mv = move_from_normal(unit, speed, std);
-        c.g.pos += ndraw;
-        pending = 0;
-      } else {
-        const u32 f = static_cast<u32>(wave::ctz64(slow));
-        if (mine && lane < f) mv = move_from_normal(unit, speed, std);
-        c.g.pos += static_cast<u32>(wave::popc64(pending & lanemask_lt(f)));
-        const f64 exact = unit_normal_exact(c.g, c.lds);
-        if (lane == f) mv = move_from_normal(exact, speed, std);
-        pending &= ~((u64(2) << f) - 1);
-      }
-    }
+    if (bnd) mv = q_move[(head + static_cast<u32>(wave::popc64(bm & lanemask_lt(lane)))) % MOVQ_CAP];
+    head += need;
     if (act) moves[slot] = mv;
     }
+  }
+  if (head != 0) {
+    // the stream ends right after the draw of the last bound LEF: hand back what the last step
+    // evaluated beyond it (queued draws, and rejected attempts that no draw followed)
+    const u32 end_low = wave::uniform(q_end[(head - 1) % MOVQ_CAP]);
+    c.g.pos -= static_cast<u32>(static_cast<u32>(c.g.pos) - end_low);
   }
 }
 
