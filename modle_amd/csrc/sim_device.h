@@ -1042,6 +1042,259 @@ MODLE_DEV u32 lef_bar_pick(const BarView& v, const Params& p, const Rng& g, u32 
   return winner;
 }
 
+// ---------------------------------------------------------------------------------------------
+// detect_lef_bar_collisions when both blocking probabilities are 0 or 1 (the reference default:
+// major 1, minor 0): no Bernoulli trial is drawn and a barrier stalls a unit iff it is active
+// and the probability that applies to its direction is 1.  Of the barriers in a unit's window the
+// reference keeps the one it visits last: the highest such barrier for a rev unit, the lowest
+// for a fwd unit.  The stalling barriers are therefore compacted (position, index | hard << 31)
+// into the LDS window, in ascending order, and a unit needs one search there and one test.
+//
+// The compacted window holds every stalling barrier with index in [s0, s1); it serves any unit
+// window [lo, hi) with lo >= lo_cover and hi <= hi_cover.  Unit windows are disjoint and ordered
+// like the ranks, so every batch continues the search where the previous one stopped; a batch
+// whose windows do not fit is looked up in device memory.
+// ---------------------------------------------------------------------------------------------
+constexpr u32 HITBAR_HARD = 0x80000000u;
+constexpr u32 HITBAR_NEAR = 127;  // entries next to the anchor that the fixed-step search covers
+
+template <bool FWD>
+MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
+  Workspace& ws = c.ws;
+  const Interval& iv = *c.iv;
+  const Params& p = *c.p;
+  const u32 n = wave::uniform(c.n_active);
+  const u32 nb = wave::uniform(iv.n_barriers);
+  const bool major_hits = p.pblock_major == 1.0, minor_hits = p.pblock_minor == 1.0;
+  if (!major_hits && !minor_hits) return;  // no barrier ever stalls a unit
+  const u32 major_dir = FWD ? DIR_FWD : DIR_REV;
+  const u32 lane = wave::lane();
+  const u32* pos = FWD ? ws.f_pos : ws.r_pos;
+  const u32* moves = FWD ? ws.f_move : ws.r_move;
+  u32* coll = FWD ? ws.f_coll : ws.r_coll;
+  u32* barpos = stalling_barrier_positions<FWD>(ws);
+  u32* cp = reinterpret_cast<u32*>(c.lds.sort_lds);  // positions of the compacted barriers
+  u32* ci = cp + BAR_WIN;                              // their indices (| HITBAR_HARD)
+  const u32 j_rev0 = bc.n5 == 0 ? 0 : bc.n5 - 1;
+  const u32 j_fwd0 = bc.n3 == 0 ? n - 1 : n - bc.n3;
+  u32 carry_pos = 0;
+  u32 c0 = 0, cnt = 0;              // compacted entries: cp[c0 .. c0 + cnt)
+  u64 lo_cover = 1, hi_cover = 0;   // nothing staged yet
+  u32 anchor = 0;                   // rev: entries below it lie before the batch; fwd: entries at
+                                    // or above it lie beyond the batch (relative to c0)
+  const u32 nbatch = (n + 63) / 64;
+  constexpr u32 UX = 4;  // batches whose loads are in flight together
+  for (u32 bg = 0; bg < nbatch; bg += UX) {
+    u32 Pq[UX], Mq[UX];
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const i64 kk = FWD ? static_cast<i64>(j_fwd0) - static_cast<i64>(bg + u) * 64 - lane
+                         : static_cast<i64>(j_rev0) + static_cast<i64>(bg + u) * 64 + lane;
+      const bool act = kk >= 0 && kk < static_cast<i64>(n);
+      Pq[u] = act ? pos[static_cast<u32>(kk)] : 0;
+      Mq[u] = act ? moves[static_cast<u32>(kk)] : 0;
+    }
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 bi = bg + u;
+      const i64 kk = FWD ? static_cast<i64>(j_fwd0) - static_cast<i64>(bi) * 64 - lane
+                         : static_cast<i64>(j_rev0) + static_cast<i64>(bi) * 64 + lane;
+      const bool act = kk >= 0 && kk < static_cast<i64>(n);
+      if (!wave::any(act)) break;
+      const u32 k = act ? static_cast<u32>(kk) : 0;
+      const u32 P = Pq[u];
+      const u32 M = Mq[u];
+      const bool bnd = act && P != UNBOUND;
+      const u32 nbr_in = wave::shfl_up(P, 1);
+      const bool first = (bi == 0 && lane == 0);
+      const u32 nbr = lane > 0 ? nbr_in : carry_pos;
+      u64 lo_key = 0, hi_key = 0;  // see detect_lef_bar
+      if (bnd) {
+        if (!FWD) {
+          const u32 reach = P - M;
+          lo_key = first ? reach : umax(reach, nbr);
+          hi_key = P;
+        } else {
+          const u64 reach = static_cast<u64>(P) + M;
+          lo_key = static_cast<u64>(P) + 1;
+          hi_key = (first ? reach : umin64(reach, nbr)) + 1;
+        }
+      }
+      const u64 bm = wave::ballot(bnd);
+      carry_pos = wave::bcast(P, 63);
+      if (bm == 0) continue;
+      const u32 l_first = static_cast<u32>(wave::ctz64(bm));
+      const u32 l_last = static_cast<u32>(63 - wave::clz64(bm));
+      // keys the batch spans (lanes hold ascending positions for rev, descending for fwd)
+      const u64 need_lo = wave::bcast(lo_key, FWD ? l_last : l_first);
+      const u64 need_hi = wave::bcast(hi_key, FWD ? l_first : l_last);
+      if (need_lo < lo_cover || need_hi > hi_cover) {
+        // stage the stalling barriers from where this batch starts
+        wave::lockstep();
+        constexpr u32 G = 4;  // chunks of 64 barriers whose loads are in flight together
+        if (!FWD) {
+          const u32 s0 = wave::uniform(bar_lower_bound(iv, need_lo));
+          lo_cover = need_lo;
+          c0 = 0;
+          cnt = 0;
+          u32 b = s0;
+          bool full = false;
+          while (b < nb && !full) {
+            u32 Bp[G], Bf[G];
+#pragma unroll
+            for (u32 q = 0; q < G; ++q) {
+              const u32 idx = b + 64 * q + lane;
+              const bool in = idx < nb;
+              Bp[q] = in ? iv.bar_pos[idx] : 0;
+              Bf[q] = in ? (static_cast<u32>(ws.bar_active[idx] != 0) | (static_cast<u32>(iv.bar_dir[idx]) << 1)) : 0;
+            }
+#pragma unroll
+            for (u32 q = 0; q < G; ++q) {
+              if (full || b >= nb) break;
+              if (cnt + 64 > BAR_WIN) {
+                full = true;
+                break;
+              }
+              const u32 idx = b + lane;
+              const bool is_major = (Bf[q] >> 1) == major_dir;
+              const bool hit = idx < nb && (Bf[q] & 1u) && (is_major ? major_hits : minor_hits);
+              const u64 hm = wave::ballot(hit);
+              if (hit) {
+                const u32 slot = cnt + static_cast<u32>(wave::popc64(hm & lanemask_lt(lane)));
+                cp[slot] = Bp[q];
+                ci[slot] = idx | (is_major ? HITBAR_HARD : 0u);
+              }
+              cnt += static_cast<u32>(wave::popc64(hm));
+              b += 64;
+            }
+          }
+          const u32 s1 = umin(b, nb);
+          hi_cover = s1 < nb ? static_cast<u64>(wave::uniform(iv.bar_pos[s1])) : ~u64(0);
+          anchor = 0;
+        } else {
+          const u32 s1 = wave::uniform(bar_lower_bound(iv, need_hi));
+          hi_cover = need_hi;
+          u32 top = BAR_WIN;
+          u32 e = s1;
+          bool full = false;
+          while (e > 0 && !full) {
+            u32 Bp[G], Bf[G];
+#pragma unroll
+            for (u32 q = 0; q < G; ++q) {
+              const i64 idx = static_cast<i64>(e) - 64 * (q + 1) + lane;
+              const bool in = idx >= 0;
+              Bp[q] = in ? iv.bar_pos[idx] : 0;
+              Bf[q] = in ? (static_cast<u32>(ws.bar_active[idx] != 0) | (static_cast<u32>(iv.bar_dir[idx]) << 1)) : 0;
+            }
+#pragma unroll
+            for (u32 q = 0; q < G; ++q) {
+              if (full || e == 0) break;
+              if (top < 64) {
+                full = true;
+                break;
+              }
+              const i64 idx = static_cast<i64>(e) - 64 + lane;
+              const bool is_major = (Bf[q] >> 1) == major_dir;
+              const bool hit = idx >= 0 && (Bf[q] & 1u) && (is_major ? major_hits : minor_hits);
+              const u64 hm = wave::ballot(hit);
+              top -= static_cast<u32>(wave::popc64(hm));
+              if (hit) {
+                const u32 slot = top + static_cast<u32>(wave::popc64(hm & lanemask_lt(lane)));
+                cp[slot] = Bp[q];
+                ci[slot] = static_cast<u32>(idx) | (is_major ? HITBAR_HARD : 0u);
+              }
+              e = e > 64 ? e - 64 : 0;
+            }
+          }
+          const u32 s0 = e;
+          lo_cover = s0 > 0 ? static_cast<u64>(wave::uniform(iv.bar_pos[s0 - 1])) + 1 : 0;
+          c0 = top;
+          cnt = BAR_WIN - top;
+          anchor = cnt;
+        }
+        wave::sync_lds();
+      }
+      u32 winner = 0xFFFFFFFFu, bpos = 0;
+      bool hard = false;
+      if (need_lo >= lo_cover && need_hi <= hi_cover) {
+        u32 q = anchor;
+        if (!FWD) {
+          // q = number of entries before the unit: the last of them is the candidate
+          if (bnd) {
+#pragma unroll
+            for (u32 sft = 64; sft >= 1; sft >>= 1) {
+              if (q + sft <= cnt && cp[c0 + q + sft - 1] < hi_key) q += sft;
+            }
+            if (q == anchor + HITBAR_NEAR && q < cnt) {
+              u32 hi = cnt;
+              while (q < hi) {
+                const u32 mid = (q + hi) >> 1;
+                if (cp[c0 + mid] < hi_key) q = mid + 1; else hi = mid;
+              }
+            }
+            if (q > 0) {
+              const u32 bp = cp[c0 + q - 1];
+              if (bp >= lo_key) {
+                const u32 w = ci[c0 + q - 1];
+                winner = w & ~HITBAR_HARD;
+                hard = (w & HITBAR_HARD) != 0;
+                bpos = bp;
+              }
+            }
+          }
+        } else {
+          // q = number of entries at or before the unit: entry q is the candidate
+          if (bnd) {
+#pragma unroll
+            for (u32 sft = 64; sft >= 1; sft >>= 1) {
+              if (q >= sft && cp[c0 + q - sft] >= lo_key) q -= sft;
+            }
+            if (q + HITBAR_NEAR == anchor && q > 0) {
+              u32 lo = 0;
+              while (lo < q) {
+                const u32 mid = (lo + q) >> 1;
+                if (cp[c0 + mid] < lo_key) lo = mid + 1; else q = mid;
+              }
+            }
+            if (q < cnt) {
+              const u32 bp = cp[c0 + q];
+              if (bp < hi_key) {
+                const u32 w = ci[c0 + q];
+                winner = w & ~HITBAR_HARD;
+                hard = (w & HITBAR_HARD) != 0;
+                bpos = bp;
+              }
+            }
+          }
+        }
+        anchor = wave::bcast(q, l_last);
+      } else {
+        // the batch spans more stalling barriers than the window holds (few, far apart units):
+        // per-unit searches in device memory
+        BarView v;
+        v.iv = &iv;
+        v.active = ws.bar_active;
+        v.st_pos = cp;
+        v.st_flag = ci;
+        v.s0 = FWD ? nb : 0;  // empty staged range at the end the search starts from
+        v.s1 = v.s0;
+        u32 b_lo = 0, b_hi = 0;
+        bool edge = false;
+        if (bnd) lef_bar_window<FWD, false>(v, nb, 0, lo_key, hi_key, b_lo, b_hi, edge);
+        winner = lef_bar_pick<FWD, false>(v, p, c.g, b_lo, b_hi, 0, hard, bpos);
+        // the staged entries stay valid, but the next batch must not trust the anchor
+        lo_cover = 1;
+        hi_cover = 0;
+      }
+      if (winner != 0xFFFFFFFFu) {
+        coll[k] = cw_make(winner, EV_COLLISION | EV_LEF_BAR) | (hard ? CW_HARD : 0u);
+        barpos[k] = bpos;
+      }
+    }
+  }
+  wave::sync_mem();
+}
+
 template <bool FWD>
 MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
   Workspace& ws = c.ws;
@@ -1056,6 +1309,10 @@ MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
   u32* coll = FWD ? ws.f_coll : ws.r_coll;
   const bool trials = !((p.pblock_major == 1.0 || p.pblock_major == 0.0) &&
                         (p.pblock_minor == 1.0 || p.pblock_minor == 0.0));
+  if (!trials) {
+    detect_lef_bar_det<FWD>(c, bc);
+    return;
+  }
   u32* barpos = stalling_barrier_positions<FWD>(ws);
   u32* st_pos = reinterpret_cast<u32*>(c.lds.sort_lds);
   u32* st_flag = st_pos + BAR_WIN;
@@ -1230,6 +1487,31 @@ MODLE_DEV u32 stalling_barrier_pos(const Interval& iv, u32 word) {
 // one pair and the pair's corrected moves depend only on the two units (original moves, or
 // "distance to the stalling barrier - 1" for a unit that stays stalled by a barrier, which is
 // what correct_moves_for_lef_bar_collisions stores for it).
+// what one batch of detect_primary reads from device memory: the rev units of 64 ranks and a
+// slice of STAGE_CAP fwd units
+struct PrimaryBatch {
+  u32 R, rev_move, rev_id, rc;
+  u32 sp[STAGE_CAP / 64], sm[STAGE_CAP / 64], sc[STAGE_CAP / 64], si[STAGE_CAP / 64];
+};
+MODLE_DEV void primary_load_batch(const Workspace& ws, u32 n, u32 base, u32 w0, u32 lane,
+                                  PrimaryBatch& b) {
+  const u32 k = base + lane;
+  const bool act = k < n;
+  b.R = act ? ws.r_pos[k] : UNBOUND;
+  b.rev_move = act ? ws.r_move[k] : 0;
+  b.rev_id = act ? ws.r_id[k] : 0;
+  b.rc = act ? ws.r_coll[k] : 0;
+#pragma unroll
+  for (u32 q = 0; q < STAGE_CAP / 64; ++q) {
+    const u32 t = lane + 64 * q;
+    const bool in = w0 + t < n;
+    b.sp[q] = in ? ws.f_pos[w0 + t] : UNBOUND;
+    b.sm[q] = in ? ws.f_move[w0 + t] : 0;
+    b.sc[q] = in ? ws.f_coll[w0 + t] : 0;
+    b.si[q] = in ? ws.f_id[w0 + t] : 0;
+  }
+}
+
 MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_correct) {
   Workspace& ws = c.ws;
   const Params& p = *c.p;
@@ -1254,42 +1536,35 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
   static_assert(3 * STAGE_CAP <= 2 * SORT_LDS_CAP, "fwd slices do not fit the sort buffer");
   u32 carry_pos = 0;
   u32 carry_pf = 0;  // fwd units strictly upstream of the last rev unit handled so far
+  // pf = number of fwd units strictly upstream of R.  pf is monotone in the rank, so slices of
+  // the fwd arrays starting at the previous batch's value are staged in LDS (one round trip
+  // together with the batch's rev-side loads) and everything is looked up there; lanes whose
+  // partner lies beyond the slice use device memory.  The loads of the next batch are issued as
+  // soon as this batch knows where its last unit falls among the fwd units, before the rest of
+  // its work.  What they can miss are this batch's updates of the fwd unit at the start of the
+  // next slice (its move and collision word), and no unit of the next batch can pair with that
+  // unit: it lies upstream of this batch's last rev unit, which is then the "first rev unit
+  // downstream of it".
+  PrimaryBatch cur;
+  primary_load_batch(ws, n, bc.n5, 0, lane, cur);
   for (u32 base = bc.n5; base < n; base += 64) {
     const u32 k = base + lane;
     const bool act = k < n;
-    // pf = number of fwd units strictly upstream of R.  pf is monotone in the rank, so slices of
-    // the fwd arrays starting at the previous batch's value are staged in LDS (one round trip
-    // together with this batch's rev-side loads) and everything is looked up there; lanes whose
-    // partner lies beyond the slice use device memory.
     const u32 w0 = carry_pf > 0 ? carry_pf - 1 : 0;
-    const u32 R = act ? ws.r_pos[k] : UNBOUND;
-    const u32 rev_move_k = act ? ws.r_move[k] : 0;
-    const u32 rev_id_k = act ? ws.r_id[k] : 0;
-    const u32 rc_k = act ? ws.r_coll[k] : 0;
-    {
-      // all loads first (one round trip), then the LDS writes
-      constexpr u32 NT = STAGE_CAP / 64;
-      u32 sp[NT], sm[NT], sc[NT], si[NT];
+    const u32 R = cur.R;
+    const u32 rev_move_k = cur.rev_move;
+    const u32 rev_id_k = cur.rev_id;
+    const u32 rc_k = cur.rc;
+    wave::lockstep();
 #pragma unroll
-      for (u32 q = 0; q < NT; ++q) {
-        const u32 t = lane + 64 * q;
-        const bool in = w0 + t < n;
-        sp[q] = in ? ws.f_pos[w0 + t] : UNBOUND;
-        sm[q] = in ? ws.f_move[w0 + t] : 0;
-        sc[q] = in ? ws.f_coll[w0 + t] : 0;
-        si[q] = in ? ws.f_id[w0 + t] : 0;
-      }
-      wave::lockstep();
-#pragma unroll
-      for (u32 q = 0; q < NT; ++q) {
-        const u32 t = lane + 64 * q;
-        stage[t] = sp[q];
-        st_move[t] = sm[q];
-        st_coll[t] = sc[q];
-        st_id[t] = si[q];
-      }
-      wave::sync_lds();
+    for (u32 q = 0; q < STAGE_CAP / 64; ++q) {
+      const u32 t = lane + 64 * q;
+      stage[t] = cur.sp[q];
+      st_move[t] = cur.sm[q];
+      st_coll[t] = cur.sc[q];
+      st_id[t] = cur.si[q];
     }
+    wave::sync_lds();
     const u32 prev_in = wave::shfl_up(R, 1);
     const u32 Rprev = lane > 0 ? prev_in : carry_pos;
     u32 pf = 0;
@@ -1305,6 +1580,10 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
         pf = umin(w0 + lo, n);
       }
     }
+    // last active lane's pf (inactive lanes hold 0)
+    const u64 am = wave::ballot(act);
+    const u32 next_pf = wave::bcast(pf, static_cast<u32>(63 - wave::clz64(am)));
+    if (base + 64 < n) primary_load_batch(ws, n, base + 64, next_pf > 0 ? next_pf - 1 : 0, lane, cur);
     bool cand = false;
     u32 F = 0, rev_move = 0, fwd_move = 0, fwd_id_s = 0, fc_s = 0;
     if (act && pf >= 1 && pf < i2) {
@@ -1371,9 +1650,7 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
       }
     }
     carry_pos = wave::bcast(R, 63);
-    // last active lane's pf (inactive lanes hold 0)
-    const u64 am = wave::ballot(act);
-    carry_pf = wave::bcast(pf, static_cast<u32>(63 - wave::clz64(am)));
+    carry_pf = next_pf;
   }
   wave::sync_mem();
 }

@@ -45,7 +45,8 @@ def random_case(seed):
     return _finish(cfg, chrom, cfg_kw, size)
 
 
-def random_case_v2(seed):
+def random_case_v2(seed, pblock_pairs=None, spacings=(79_564, 25_000, 300_000),
+                   lef_densities=(5.0, 20.0, 33.3, 64.0)):
     rng = np.random.default_rng(seed ^ 0x5EED)
     chrom_size = int(rng.integers(400_000, 12_000_000))
     # simulated interval: the whole chromosome, or a window that starts / ends inside it
@@ -56,7 +57,7 @@ def random_case_v2(seed):
     cfg_kw = dict(
         num_cells=int(rng.integers(4, 24)),
         seed=int(rng.integers(0, 2**31)),
-        number_of_lefs_per_mbp=float(rng.choice([5.0, 20.0, 33.3, 64.0])),
+        number_of_lefs_per_mbp=float(rng.choice(list(lef_densities))),
         probability_of_extrusion_unit_bypass=float(rng.choice([0.0, 0.05, 0.1, 0.3])),
         lef_bar_major_collision_pblock=float(rng.choice([1.0, 0.95, 0.7])),
         lef_bar_minor_collision_pblock=float(rng.choice([0.0, 0.1, 0.3])),
@@ -82,8 +83,12 @@ def random_case_v2(seed):
                       fwd_extrusion_speed=int(cfg_kw["bin_size"] // 5), fwd_extrusion_speed_set=1)
     elif speed == "no_spread":
         cfg_kw.update(rev_extrusion_speed_std=0.0, fwd_extrusion_speed_std=0.0)
+    if pblock_pairs is not None:
+        major, minor = pblock_pairs[int(rng.integers(0, len(pblock_pairs)))]
+        cfg_kw.update(lef_bar_major_collision_pblock=float(major),
+                      lef_bar_minor_collision_pblock=float(minor))
     cfg = api.make_config(**cfg_kw)
-    spacing = int(rng.choice([79_564, 25_000, 300_000]))
+    spacing = int(rng.choice(list(spacings)))
     full = synthetic.synthetic_chromosome(f"chrG{seed}", chrom_size, seed=seed,
                                           with_barriers=bool(rng.random() < 0.9), spacing=spacing)
     inside = (full["bar_pos"] >= start) & (full["bar_pos"] < end)
@@ -91,3 +96,11 @@ def random_case_v2(seed):
                  bar_pos=full["bar_pos"][inside], bar_dir=full["bar_dir"][inside],
                  bar_occupancy=full["bar_occupancy"][inside])
     return _finish(cfg, chrom, dict(cfg_kw, start=start, end=end, spacing=spacing), end - start)
+
+
+def random_case_v3(seed):
+    """blocking probabilities in {0, 1} only (no Bernoulli trial at the barriers: the device code
+    takes its compacted-barrier path), barriers from dense to sparse, LEFs from very few to many"""
+    return random_case_v2(seed ^ 0x7EA7, pblock_pairs=[(1, 0), (1, 0), (1, 1), (0, 1), (0, 0)],
+                          spacings=(79_564, 8_000, 2_500, 300_000),
+                          lef_densities=(1.0, 5.0, 20.0, 64.0))

@@ -3,7 +3,7 @@ the CPU lane emulator (one cell per set-up: the emulator is slow)."""
 import pytest
 
 import emu_sim
-from fuzz_cases import random_case, random_case_v2
+from fuzz_cases import random_case, random_case_v2, random_case_v3
 from modle_amd import api
 from parity_cases import assert_same_outputs, assert_same_results
 
@@ -16,6 +16,11 @@ def test_emulated_device_code_matches_oracle_on_random_setups(oracle, seed):
 @pytest.mark.parametrize("seed", [4, 5, 6, 8])
 def test_emulated_device_code_matches_oracle_on_random_setups_v2(oracle, seed):
     _compare(oracle, random_case_v2(seed), f"v2 seed {seed}")
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_emulated_device_code_matches_oracle_on_random_setups_v3(oracle, seed):
+    _compare(oracle, random_case_v3(seed), f"v3 seed {seed}")
 
 
 def _compare(oracle, case, label):

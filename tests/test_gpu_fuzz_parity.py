@@ -3,7 +3,7 @@ probabilities, stall multipliers, sampling strategies, resolutions): every outpu
 per-cell counter of the HIP path must equal the oracle's."""
 import pytest
 
-from fuzz_cases import random_case, random_case_v2
+from fuzz_cases import random_case, random_case_v2, random_case_v3
 from parity_cases import assert_same_outputs, assert_same_results
 
 pytestmark = pytest.mark.gpu
@@ -18,6 +18,12 @@ def test_gpu_matches_oracle_on_random_setups(oracle, seed):
 def test_gpu_matches_oracle_on_random_setups_v2(oracle, seed):
     """wider generator: windows that do not start at 0, barrier density, speeds, noise, ..."""
     _compare(oracle, random_case_v2(seed), f"v2 seed {seed}")
+
+
+@pytest.mark.parametrize("seed", list(range(1, 17)))
+def test_gpu_matches_oracle_on_random_setups_v3(oracle, seed):
+    """blocking probabilities in {0, 1}: the compacted-barrier path of LEF-BAR detection"""
+    _compare(oracle, random_case_v3(seed), f"v3 seed {seed}")
 
 
 def _compare(oracle, case, label):
