@@ -85,16 +85,27 @@ MODLE_DEV_NOINLINE void phase_bind(Cell& c, u32 epoch_now) {
   const u32 lane = wave::lane();
   const u64 range = static_cast<u64>(iv.end) - 1 - iv.start;
   const u64 bucket = range != 0 ? uniform_int_bucket(range) : 1;
-  constexpr u32 UX = 4;  // batches whose loads are in flight together
-  for (u32 group = 0; group < n; group += 64 * UX) {
-    u32 Eq[UX], Rq[UX], Fq[UX];
+  constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
+  struct LefRegs {
+    u32 E[UX], R[UX], F[UX];
+  };
+  const auto load_lefs = [&](u32 group, LefRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 iq = group + 64 * u + lane;
-      Eq[u] = iq < n ? ws.epoch[iq] : 0;
-      Rq[u] = iq < n ? ws.r_rank[iq] : 0;
-      Fq[u] = iq < n ? ws.f_rank[iq] : 0;
+      r.E[u] = iq < n ? ws.epoch[iq] : 0;
+      r.R[u] = iq < n ? ws.r_rank[iq] : 0;
+      r.F[u] = iq < n ? ws.f_rank[iq] : 0;
     }
+  };
+  LefRegs cur;
+  load_lefs(0, cur);
+  for (u32 group = 0; group < n; group += 64 * UX) {
+    const LefRegs g = cur;
+    if (group + 64 * UX < n) load_lefs(group + 64 * UX, cur);
+    const u32* Eq = g.E;
+    const u32* Rq = g.R;
+    const u32* Fq = g.F;
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
     const u32 base = group + 64 * u;
@@ -209,15 +220,25 @@ MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_
   u32 carry_lo = 0;  // keys below the last kept unit of the previous batch
 
   u32 carry_old = UNBOUND;  // position of the kept unit before this batch (UNBOUND: none)
-  constexpr u32 UX = 4;  // batches whose loads are in flight together
-  for (u32 group = 0; group < n_old; group += 64 * UX) {
-    u32 Pq[UX], Iq[UX];
+  constexpr u32 UX = 4;  // batches per group
+  struct KeptRegs {
+    u32 P[UX], I[UX];
+  };
+  const auto load_kept = [&](u32 group, KeptRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 aq = group + 64 * u + lane;
-      Pq[u] = aq < n_old ? old_pos[aq] : UNBOUND;
-      Iq[u] = aq < n_old ? old_id[aq] : 0;
+      r.P[u] = aq < n_old ? old_pos[aq] : UNBOUND;
+      r.I[u] = aq < n_old ? old_id[aq] : 0;
     }
+  };
+  KeptRegs cur;
+  load_kept(0, cur);
+  for (u32 group = 0; group < n_old; group += 64 * UX) {
+    const KeptRegs g = cur;
+    if (group + 64 * UX < n_old) load_kept(group + 64 * UX, cur);
+    const u32* Pq = g.P;
+    const u32* Iq = g.I;
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
     const u32 base = group + 64 * u;
@@ -319,16 +340,27 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
   u32 n_old = 0, n_new = 0;
   u32 run_max = 0;  // max position of carried-over units in previous batches
 
-  constexpr u32 UX = 4;  // batches whose loads are in flight together
-  for (u32 group = 0; group < n; group += 64 * UX) {
-    u32 Pq[UX], Iq[UX], Kq[UX];
+  constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
+  struct UnitRegs {
+    u32 P[UX], I[UX], K[UX];
+  };
+  const auto load_units = [&](u32 group, UnitRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 kq = group + 64 * u + lane;
-      Pq[u] = kq < n ? pos[kq] : 0;
-      Iq[u] = kq < n ? ids[kq] : 0;
-      Kq[u] = kq < n ? marks[kq] : 0;
+      r.P[u] = kq < n ? pos[kq] : 0;
+      r.I[u] = kq < n ? ids[kq] : 0;
+      r.K[u] = kq < n ? marks[kq] : 0;
     }
+  };
+  UnitRegs cur;
+  load_units(0, cur);
+  for (u32 group = 0; group < n; group += 64 * UX) {
+    const UnitRegs g = cur;
+    if (group + 64 * UX < n) load_units(group + 64 * UX, cur);
+    const u32* Pq = g.P;
+    const u32* Iq = g.I;
+    const u32* Kq = g.K;
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
     const u32 base = group + 64 * u;
@@ -550,23 +582,31 @@ MODLE_DEV_NOINLINE void generate_moves_dir(Cell& c, f64 speed, f64 std) {
   const u32* q_move = c.lds.stage;
   const u32* q_end = c.lds.stage + MOVQ_CAP;
   u32 head = 0, tail = 0;  // entries consumed / produced
-  constexpr u32 UX = 4;  // batches whose loads are in flight together
-  for (u32 group = 0; group < n; group += 64 * UX) {
-    u32 Eq[UX], Sq[UX];
+  constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
+  struct LefRegs {
+    u32 E[UX], S[UX];
+  };
+  const auto load_lefs = [&](u32 group, LefRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 i = group + 64 * u + lane;
-      Eq[u] = i < n ? ws.epoch[i] : UNBOUND;
-      Sq[u] = i < n ? rank[i] : 0;
+      r.E[u] = i < n ? ws.epoch[i] : UNBOUND;
+      r.S[u] = i < n ? rank[i] : 0;
     }
+  };
+  LefRegs cur;
+  load_lefs(0, cur);
+  for (u32 group = 0; group < n; group += 64 * UX) {
+    const LefRegs g = cur;
+    if (group + 64 * UX < n) load_lefs(group + 64 * UX, cur);
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
     const u32 base = group + 64 * u;
     if (base >= n) break;
     const u32 i = base + lane;
     const bool act = i < n;
-    const bool bnd = act && Eq[u] != UNBOUND;
-    const u32 slot = Sq[u];
+    const bool bnd = act && g.E[u] != UNBOUND;
+    const u32 slot = g.S[u];
     const u64 bm = wave::ballot(bnd);
     const u32 need = static_cast<u32>(wave::popc64(bm));
     while (tail - head < need) tail = draw_moves_step(c, speed, std, tail);
@@ -608,16 +648,26 @@ MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp)
   i64 viol_rank = -1;
   // lanes hold the ranks of a batch in DESCENDING order (lane 0 = highest rank), so that the
   // suffix scan over ranks is a prefix scan over lanes
-  constexpr u32 UX = 4;  // batches whose loads are in flight together
-  for (u32 bg = 0; bg < nbatch; bg += UX) {
-    u32 Pq[UX], Mq[UX];
+  constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
+  struct UnitRegs {
+    u32 P[UX], M[UX];
+  };
+  const auto load_units = [&](u32 bg, UnitRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const bool in = bg + u < nbatch;
       const u32 kq = (nbatch - 1 - (bg + u)) * 64 + (63 - lane);
-      Pq[u] = in && kq < n ? ws.r_pos[kq] : UNBOUND;
-      Mq[u] = in && kq < n ? mv_in[kq] : 0;
+      r.P[u] = in && kq < n ? ws.r_pos[kq] : UNBOUND;
+      r.M[u] = in && kq < n ? mv_in[kq] : 0;
     }
+  };
+  UnitRegs cur;
+  load_units(0, cur);
+  for (u32 bg = 0; bg < nbatch; bg += UX) {
+    const UnitRegs g = cur;
+    if (bg + UX < nbatch) load_units(bg + UX, cur);
+    const u32* Pq = g.P;
+    const u32* Mq = g.M;
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
     if (bg + u >= nbatch) break;
@@ -688,15 +738,25 @@ MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp)
   i64 carry_d = 0;
   bool carry_ok = false, carry_cross = false;
   i64 viol_rank = -1;
-  constexpr u32 UX = 4;  // batches whose loads are in flight together
-  for (u32 bg = 0; bg < nbatch; bg += UX) {
-    u32 Pq[UX], Mq[UX];
+  constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
+  struct UnitRegs {
+    u32 P[UX], M[UX];
+  };
+  const auto load_units = [&](u32 bg, UnitRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 kq = (bg + u) * 64 + lane;
-      Pq[u] = kq < n ? ws.f_pos[kq] : UNBOUND;
-      Mq[u] = kq < n ? mv_in[kq] : 0;
+      r.P[u] = kq < n ? ws.f_pos[kq] : UNBOUND;
+      r.M[u] = kq < n ? mv_in[kq] : 0;
     }
+  };
+  UnitRegs cur;
+  load_units(0, cur);
+  for (u32 bg = 0; bg < nbatch; bg += UX) {
+    const UnitRegs g = cur;
+    if (bg + UX < nbatch) load_units(bg + UX, cur);
+    const u32* Pq = g.P;
+    const u32* Mq = g.M;
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
     const u32 bi = bg + u;
@@ -790,17 +850,28 @@ MODLE_DEV_NOINLINE void barriers_next_state(Cell& c) {
   const Interval& iv = *c.iv;
   const u32 nb = wave::uniform(iv.n_barriers);
   const u32 lane = wave::lane();
-  constexpr u32 UX = 4;  // batches whose loads are in flight together
-  for (u32 group = 0; group < nb; group += 64 * UX) {
-    u8 Sq[UX];
-    f64 Iq[UX], Aq[UX];
+  constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
+  struct BarRegs {
+    u8 S[UX];
+    f64 I[UX], A[UX];
+  };
+  const auto load_bars = [&](u32 group, BarRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 iq = group + 64 * u + lane;
-      Sq[u] = iq < nb ? c.ws.bar_active[iq] : u8(0);
-      Iq[u] = iq < nb ? iv.bar_stp_inactive[iq] : 0.0;
-      Aq[u] = iq < nb ? iv.bar_stp_active[iq] : 0.0;
+      r.S[u] = iq < nb ? c.ws.bar_active[iq] : u8(0);
+      r.I[u] = iq < nb ? iv.bar_stp_inactive[iq] : 0.0;
+      r.A[u] = iq < nb ? iv.bar_stp_active[iq] : 0.0;
     }
+  };
+  BarRegs cur;
+  load_bars(0, cur);
+  for (u32 group = 0; group < nb; group += 64 * UX) {
+    const BarRegs g = cur;
+    if (group + 64 * UX < nb) load_bars(group + 64 * UX, cur);
+    const u8* Sq = g.S;
+    const f64* Iq = g.I;
+    const f64* Aq = g.A;
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 base = group + 64 * u;
@@ -1732,9 +1803,11 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
   // ranks from f_first on (in visiting order) can be followers
   u32 carry_pos = 0, carry_move = 0, carry_coll = 0, carry_id = 0;
   const u32 nbatch = (n + 63) / 64;
-  constexpr u32 UX = 4;  // batches whose loads are in flight together
-  for (u32 bg = 0; bg < nbatch; bg += UX) {
-    u32 Pq[UX], Iq[UX], Mq[UX], Cq[UX], Bq[UX];
+  constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
+  struct UnitRegs {
+    u32 P[UX], I[UX], M[UX], C[UX], B[UX];
+  };
+  const auto load_units = [&](u32 bg, UnitRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 bi = bg + u;
@@ -1742,12 +1815,23 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
                          : static_cast<i64>(bi) * 64 + lane;
       const bool act = kk >= 0 && kk < static_cast<i64>(n);
       const u32 k = act ? static_cast<u32>(kk) : 0;
-      Pq[u] = act ? pos[k] : 0;
-      Iq[u] = act ? ids[k] : 0;
-      Mq[u] = act ? moves[k] : 0;
-      Cq[u] = act ? coll[k] : 0;
-      Bq[u] = act ? barpos[k] : 0;
+      r.P[u] = act ? pos[k] : 0;
+      r.I[u] = act ? ids[k] : 0;
+      r.M[u] = act ? moves[k] : 0;
+      r.C[u] = act ? coll[k] : 0;
+      r.B[u] = act ? barpos[k] : 0;
     }
+  };
+  UnitRegs cur;
+  load_units(0, cur);
+  for (u32 bg = 0; bg < nbatch; bg += UX) {
+    const UnitRegs g = cur;
+    if (bg + UX < nbatch) load_units(bg + UX, cur);
+    const u32* Pq = g.P;
+    const u32* Iq = g.I;
+    const u32* Mq = g.M;
+    const u32* Cq = g.C;
+    const u32* Bq = g.B;
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 bi = bg + u;
@@ -2035,64 +2119,82 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
   // independent); units stalled by a barrier that blocks their own direction ("hard" stalls)
   // are reported to their LEF through stall[id].  The collision words are consumed here, so
   // they are cleared on the way (the next epoch starts with clean arrays).
-  constexpr u32 UX = 4;  // batches whose loads are in flight together
-  for (u32 base = 0; base < n; base += 64 * UX) {
+  // The loads of the next group of batches are issued before the stores of the current one: a
+  // wait for a load also waits for every store issued before it.
+  constexpr u32 UX = 4;  // batches per group
+  struct UnitRegs {
     u32 rP[UX], rM[UX], rc[UX], fP[UX], fM[UX], fc[UX], rI[UX], fI[UX];
+  };
+  const auto load_units = [&](u32 base, UnitRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 k = base + 64 * u + lane;
       const bool act = k < n;
-      rP[u] = act ? ws.r_pos[k] : UNBOUND;
-      rM[u] = act ? ws.r_move[k] : 0;
-      rc[u] = act ? ws.r_coll[k] : 0;
-      rI[u] = act ? ws.r_id[k] : 0;
-      fP[u] = act ? ws.f_pos[k] : UNBOUND;
-      fM[u] = act ? ws.f_move[k] : 0;
-      fc[u] = act ? ws.f_coll[k] : 0;
-      fI[u] = act ? ws.f_id[k] : 0;
+      r.rP[u] = act ? ws.r_pos[k] : UNBOUND;
+      r.rM[u] = act ? ws.r_move[k] : 0;
+      r.rc[u] = act ? ws.r_coll[k] : 0;
+      r.rI[u] = act ? ws.r_id[k] : 0;
+      r.fP[u] = act ? ws.f_pos[k] : UNBOUND;
+      r.fM[u] = act ? ws.f_move[k] : 0;
+      r.fc[u] = act ? ws.f_coll[k] : 0;
+      r.fI[u] = act ? ws.f_id[k] : 0;
     }
+  };
+  UnitRegs cur;
+  load_units(0, cur);
+  for (u32 base = 0; base < n; base += 64 * UX) {
+    const UnitRegs g = cur;
+    if (base + 64 * UX < n) load_units(base + 64 * UX, cur);
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 k = base + 64 * u + lane;
       if (k < n) {
-        if (rP[u] != UNBOUND) ws.r_pos[k] = rP[u] - rM[u];
-        if (fP[u] != UNBOUND) ws.f_pos[k] = fP[u] + fM[u];
-        if (rc[u] != 0) ws.r_coll[k] = 0;
-        if (fc[u] != 0) ws.f_coll[k] = 0;
-        if (rP[u] != UNBOUND && cw_occurred_as(rc[u], EV_LEF_BAR) && (rc[u] & CW_HARD))
-          wave::atomic_inc_u32(&ws.stall[rI[u]]);
-        if (fP[u] != UNBOUND && cw_occurred_as(fc[u], EV_LEF_BAR) && (fc[u] & CW_HARD))
-          wave::atomic_inc_u32(&ws.stall[fI[u]]);
+        if (g.rP[u] != UNBOUND) ws.r_pos[k] = g.rP[u] - g.rM[u];
+        if (g.fP[u] != UNBOUND) ws.f_pos[k] = g.fP[u] + g.fM[u];
+        if (g.rc[u] != 0) ws.r_coll[k] = 0;
+        if (g.fc[u] != 0) ws.f_coll[k] = 0;
+        if (g.rP[u] != UNBOUND && cw_occurred_as(g.rc[u], EV_LEF_BAR) && (g.rc[u] & CW_HARD))
+          wave::atomic_inc_u32(&ws.stall[g.rI[u]]);
+        if (g.fP[u] != UNBOUND && cw_occurred_as(g.fc[u], EV_LEF_BAR) && (g.fc[u] & CW_HARD))
+          wave::atomic_inc_u32(&ws.stall[g.fI[u]]);
       }
     }
   }
   wave::sync_mem();
-  for (u32 group = 0; group < n; group += 64 * UX) {
-    u32 Eq[UX], Hq[UX], Rq[UX], Fq[UX];
+  const f64 affinity_soft = 1.0 / p.soft_stall_mult, affinity_hard = 1.0 / p.hard_stall_mult;
+  struct LefRegs {
+    u32 E[UX], H[UX], R[UX], F[UX];
+  };
+  const auto load_lefs = [&](u32 group, LefRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 iq = group + 64 * u + lane;
-      Eq[u] = iq < n ? ws.epoch[iq] : UNBOUND;
-      Hq[u] = iq < n ? ws.stall[iq] : 0;
-      Rq[u] = iq < n ? ws.r_rank[iq] : 0;
-      Fq[u] = iq < n ? ws.f_rank[iq] : 0;
+      r.E[u] = iq < n ? ws.epoch[iq] : UNBOUND;
+      r.H[u] = iq < n ? ws.stall[iq] : 0;
+      r.R[u] = iq < n ? ws.r_rank[iq] : 0;
+      r.F[u] = iq < n ? ws.f_rank[iq] : 0;
     }
+  };
+  LefRegs lcur;
+  load_lefs(0, lcur);
+  for (u32 group = 0; group < n; group += 64 * UX) {
+    const LefRegs g = lcur;
+    if (group + 64 * UX < n) load_lefs(group + 64 * UX, lcur);
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
     const u32 base = group + 64 * u;
     if (base >= n) break;
     const u32 i = base + lane;
     const bool act = i < n;
-    const u32 ep = Eq[u];
-    const u32 hard = Hq[u];
-    const u32 kr = Rq[u];
-    const u32 kf = Fq[u];
+    const u32 ep = g.E[u];
+    const u32 hard = g.H[u];
+    const u32 kr = g.R[u];
+    const u32 kf = g.F[u];
     const bool bnd = ep != UNBOUND;
     f64 prob = 0.0;
     if (act) {
       if (hard != 0) ws.stall[i] = 0;
-      const f64 affinity =
-          hard == 0 ? 1.0 : (hard == 1 ? 1.0 / p.soft_stall_mult : 1.0 / p.hard_stall_mult);
+      const f64 affinity = hard == 0 ? 1.0 : (hard == 1 ? affinity_soft : affinity_hard);
       prob = affinity * base_p;
     }
     const bool draws = bnd && prob != 0.0;
