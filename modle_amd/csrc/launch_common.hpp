@@ -87,6 +87,7 @@ struct WorkspaceLayout {
   size_t u64_words;   // sort keys
   size_t f64_words;   // burn-in history
   size_t u8_bytes;    // barrier states
+  size_t hit_words;   // 4 lists of stalling barriers (u32)
   size_t total_bytes;
 };
 
@@ -98,7 +99,8 @@ inline WorkspaceLayout workspace_layout(uint32_t max_lefs, uint32_t max_barriers
   w.u64_words = pow2_ceil(max_lefs < 64 ? 64 : max_lefs);
   w.f64_words = 2 * static_cast<size_t>(hist_len);
   w.u8_bytes = (static_cast<size_t>(max_barriers) + 63) & ~size_t(63);
-  w.total_bytes = w.u64_words * 8 + w.f64_words * 8 + w.u32_words * 4 + w.u8_bytes;
+  w.hit_words = 4 * ((static_cast<size_t>(max_barriers) + 63) & ~size_t(63));
+  w.total_bytes = w.u64_words * 8 + w.f64_words * 8 + w.u32_words * 4 + w.u8_bytes + w.hit_words * 4;
   w.total_bytes = (w.total_bytes + 255) & ~size_t(255);
   return w;
 }
@@ -121,6 +123,13 @@ inline modle_dev::Workspace carve_workspace(void* base, uint32_t max_lefs, uint3
   for (uint32_t k = 0; k < modle_dev::NUM_TMP; ++k) ws.tmp[k] = q + (12 + static_cast<size_t>(k)) * Lp;
   p += w.u32_words * 4;
   ws.bar_active = reinterpret_cast<uint8_t*>(p);
+  p += w.u8_bytes;
+  uint32_t* hq = reinterpret_cast<uint32_t*>(p);
+  const size_t Bp = w.hit_words / 4;
+  ws.hit_pos[0] = hq;
+  ws.hit_pos[1] = hq + Bp;
+  ws.hit_idx[0] = hq + 2 * Bp;
+  ws.hit_idx[1] = hq + 3 * Bp;
   ws.capacity_lefs = max_lefs;
   ws.capacity_barriers = max_barriers;
   return ws;

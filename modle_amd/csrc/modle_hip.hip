@@ -93,6 +93,13 @@ __device__ __forceinline__ Workspace device_carve(char* base, u32 max_lefs, u32 
   for (u32 k = 0; k < NUM_TMP; ++k) ws.tmp[k] = q + (12 + static_cast<u64>(k)) * Lp;
   p += static_cast<u64>(NUM_STATE_ARRAYS) * Lp * 4;
   ws.bar_active = reinterpret_cast<u8*>(p);
+  const u64 Bp = (static_cast<u64>(max_barriers) + 63) & ~u64(63);
+  p += Bp;
+  u32* hq = reinterpret_cast<u32*>(p);
+  ws.hit_pos[0] = hq;
+  ws.hit_pos[1] = hq + Bp;
+  ws.hit_idx[0] = hq + 2 * Bp;
+  ws.hit_idx[1] = hq + 3 * Bp;
   ws.capacity_lefs = max_lefs;
   ws.capacity_barriers = max_barriers;
   return ws;

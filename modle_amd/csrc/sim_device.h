@@ -26,6 +26,7 @@ struct Cell {
   u32 hist_len;   // entries in the burn-in history buffers
   u32 hist_head;  // ring head
   u32 error;      // non-zero when an internal capacity was exceeded (uniform)
+  u32 n_hit[2];   // entries of ws.hit_pos / hit_idx (stalling barriers of this epoch; uniform)
 #ifdef MODLE_PHASE_TIMERS
   u64 ph[16];     // profiling build: time spent per phase (wave::clock ticks)
 #endif
@@ -846,13 +847,62 @@ MODLE_DEV_NOINLINE void barriers_init_states(Cell& c) {
   wave::sync_mem();
 }
 
+// LEF-BAR detection without Bernoulli trials (both blocking probabilities in {0, 1}) works on
+// the barriers that stall a unit, compacted in position order: list 0 as the rev units see
+// them, list 1 as the fwd units do.  A barrier is on a list iff it is active and the blocking
+// probability that applies to it there is 1.
+MODLE_DEV bool stalling_lists_wanted(const Params& p) {
+  return (p.pblock_major == 1.0 || p.pblock_major == 0.0) &&
+         (p.pblock_minor == 1.0 || p.pblock_minor == 0.0);
+}
+constexpr u32 HITBAR_HARD = 0x80000000u;
+
+// appends the barriers of one batch (index i per lane, `on`: active) to the two lists; uniform
+MODLE_DEV void stalling_lists_append(Cell& c, u32 i, bool in, bool on, u32 bpos, u32 bdir) {
+  const Params& p = *c.p;
+  const u32 lane = wave::lane();
+#pragma unroll
+  for (u32 d = 0; d < 2; ++d) {
+    const bool is_major = bdir == (d == 0 ? DIR_REV : DIR_FWD);
+    const bool hit = in && on && ((is_major ? p.pblock_major : p.pblock_minor) == 1.0);
+    const u64 hm = wave::ballot(hit);
+    if (hit) {
+      const u32 slot = c.n_hit[d] + static_cast<u32>(wave::popc64(hm & lanemask_lt(lane)));
+      c.ws.hit_pos[d][slot] = bpos;
+      c.ws.hit_idx[d][slot] = i | (is_major ? HITBAR_HARD : 0u);
+    }
+    c.n_hit[d] += static_cast<u32>(wave::popc64(hm));
+  }
+}
+
+// stand-alone construction of the lists from the current barrier states (phase-level test entry
+// point; the epoch loop builds them while it updates the states)
+MODLE_DEV_NOINLINE void compact_stalling_barriers(Cell& c) {
+  const Interval& iv = *c.iv;
+  const u32 nb = wave::uniform(iv.n_barriers);
+  const u32 lane = wave::lane();
+  c.n_hit[0] = 0;
+  c.n_hit[1] = 0;
+  for (u32 base = 0; base < nb; base += 64) {
+    const u32 i = base + lane;
+    const bool in = i < nb;
+    stalling_lists_append(c, i, in, in && c.ws.bar_active[i] != 0, in ? iv.bar_pos[i] : 0,
+                          in ? iv.bar_dir[i] : 0);
+  }
+  wave::sync_mem();
+}
+
 MODLE_DEV_NOINLINE void barriers_next_state(Cell& c) {
   const Interval& iv = *c.iv;
   const u32 nb = wave::uniform(iv.n_barriers);
   const u32 lane = wave::lane();
+  const bool lists = stalling_lists_wanted(*c.p);
+  c.n_hit[0] = 0;
+  c.n_hit[1] = 0;
   constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
   struct BarRegs {
-    u8 S[UX];
+    u8 S[UX], D[UX];
+    u32 P[UX];
     f64 I[UX], A[UX];
   };
   const auto load_bars = [&](u32 group, BarRegs& r) {
@@ -862,6 +912,8 @@ MODLE_DEV_NOINLINE void barriers_next_state(Cell& c) {
       r.S[u] = iq < nb ? c.ws.bar_active[iq] : u8(0);
       r.I[u] = iq < nb ? iv.bar_stp_inactive[iq] : 0.0;
       r.A[u] = iq < nb ? iv.bar_stp_active[iq] : 0.0;
+      r.D[u] = lists && iq < nb ? iv.bar_dir[iq] : u8(0);
+      r.P[u] = lists && iq < nb ? iv.bar_pos[iq] : 0;
     }
   };
   BarRegs cur;
@@ -879,16 +931,19 @@ MODLE_DEV_NOINLINE void barriers_next_state(Cell& c) {
       const u32 i = base + lane;
       const u32 cnt = umin(64u, nb - base);
       rng_ensure(c.g, cnt);
+      u8 st = Sq[u];
       if (i < nb) {
         const f64 r = canonical_raw(rng_peek(c.g, c.g.pos + lane));
-        const u8 st = Sq[u];
         if (!st && r > Iq[u]) {
+          st = 1;
           c.ws.bar_active[i] = 1;
         } else if (st && r > Aq[u]) {
+          st = 0;
           c.ws.bar_active[i] = 0;
         }
       }
       c.g.pos += cnt;
+      if (lists) stalling_lists_append(c, i, i < nb, st != 0, g.P[u], g.D[u]);
     }
   }
   wave::sync_mem();
@@ -1126,7 +1181,6 @@ MODLE_DEV u32 lef_bar_pick(const BarView& v, const Params& p, const Rng& g, u32 
 // like the ranks, so every batch continues the search where the previous one stopped; a batch
 // whose windows do not fit is looked up in device memory.
 // ---------------------------------------------------------------------------------------------
-constexpr u32 HITBAR_HARD = 0x80000000u;
 constexpr u32 HITBAR_NEAR = 127;  // entries next to the anchor that the fixed-step search covers
 
 template <bool FWD>
@@ -1149,22 +1203,38 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
   const u32 j_rev0 = bc.n5 == 0 ? 0 : bc.n5 - 1;
   const u32 j_fwd0 = bc.n3 == 0 ? n - 1 : n - bc.n3;
   u32 carry_pos = 0;
-  u32 c0 = 0, cnt = 0;              // compacted entries: cp[c0 .. c0 + cnt)
+  const u32 nh = wave::uniform(c.n_hit[FWD ? 1 : 0]);
+  if (nh == 0) return;  // no barrier stalls a unit of this direction in this epoch
+  const u32* hpos = ws.hit_pos[FWD ? 1 : 0];
+  const u32* hidx = ws.hit_idx[FWD ? 1 : 0];
+  constexpr u32 c0 = 0;
+  u32 g0 = 0, g1 = 0, cnt = 0;      // the window holds list entries [g0, g1): cp[0 .. cnt)
+  bool staged = false;
   u64 lo_cover = 1, hi_cover = 0;   // nothing staged yet
   u32 anchor = 0;                   // rev: entries below it lie before the batch; fwd: entries at
                                     // or above it lie beyond the batch (relative to c0)
   const u32 nbatch = (n + 63) / 64;
-  constexpr u32 UX = 4;  // batches whose loads are in flight together
-  for (u32 bg = 0; bg < nbatch; bg += UX) {
-    u32 Pq[UX], Mq[UX];
+  constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
+  struct UnitRegs {
+    u32 P[UX], M[UX];
+  };
+  const auto load_units = [&](u32 bg, UnitRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const i64 kk = FWD ? static_cast<i64>(j_fwd0) - static_cast<i64>(bg + u) * 64 - lane
                          : static_cast<i64>(j_rev0) + static_cast<i64>(bg + u) * 64 + lane;
       const bool act = kk >= 0 && kk < static_cast<i64>(n);
-      Pq[u] = act ? pos[static_cast<u32>(kk)] : 0;
-      Mq[u] = act ? moves[static_cast<u32>(kk)] : 0;
+      r.P[u] = act ? pos[static_cast<u32>(kk)] : 0;
+      r.M[u] = act ? moves[static_cast<u32>(kk)] : 0;
     }
+  };
+  UnitRegs cur;
+  load_units(0, cur);
+  for (u32 bg = 0; bg < nbatch; bg += UX) {
+    const UnitRegs g = cur;
+    if (bg + UX < nbatch) load_units(bg + UX, cur);
+    const u32* Pq = g.P;
+    const u32* Mq = g.M;
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 bi = bg + u;
@@ -1200,90 +1270,65 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
       const u64 need_lo = wave::bcast(lo_key, FWD ? l_last : l_first);
       const u64 need_hi = wave::bcast(hi_key, FWD ? l_first : l_last);
       if (need_lo < lo_cover || need_hi > hi_cover) {
-        // stage the stalling barriers from where this batch starts
-        wave::lockstep();
-        constexpr u32 G = 4;  // chunks of 64 barriers whose loads are in flight together
-        if (!FWD) {
-          const u32 s0 = wave::uniform(bar_lower_bound(iv, need_lo));
-          lo_cover = need_lo;
-          c0 = 0;
-          cnt = 0;
-          u32 b = s0;
-          bool full = false;
-          while (b < nb && !full) {
-            u32 Bp[G], Bf[G];
+        // Move the window along the list to where this batch starts (one coalesced load of
+        // positions and indices).  Entries the window has already passed are dropped by counting;
+        // when the batch lies beyond the whole window, the window keeps moving.
+        u32 moved = 0;
+        for (;;) {
+          if (staged) {
+            // window entries before the batch (rev: below need_lo; fwd: below need_hi)
+            const u64 key = FWD ? need_hi : need_lo;
+            u32 below = 0;
 #pragma unroll
-            for (u32 q = 0; q < G; ++q) {
-              const u32 idx = b + 64 * q + lane;
-              const bool in = idx < nb;
-              Bp[q] = in ? iv.bar_pos[idx] : 0;
-              Bf[q] = in ? (static_cast<u32>(ws.bar_active[idx] != 0) | (static_cast<u32>(iv.bar_dir[idx]) << 1)) : 0;
+            for (u32 t = 0; t < BAR_WIN / 64; ++t) {
+              const u32 e = lane + 64 * t;
+              below += static_cast<u32>(wave::popc64(wave::ballot(e < cnt && cp[e] < key)));
             }
-#pragma unroll
-            for (u32 q = 0; q < G; ++q) {
-              if (full || b >= nb) break;
-              if (cnt + 64 > BAR_WIN) {
-                full = true;
-                break;
-              }
-              const u32 idx = b + lane;
-              const bool is_major = (Bf[q] >> 1) == major_dir;
-              const bool hit = idx < nb && (Bf[q] & 1u) && (is_major ? major_hits : minor_hits);
-              const u64 hm = wave::ballot(hit);
-              if (hit) {
-                const u32 slot = cnt + static_cast<u32>(wave::popc64(hm & lanemask_lt(lane)));
-                cp[slot] = Bp[q];
-                ci[slot] = idx | (is_major ? HITBAR_HARD : 0u);
-              }
-              cnt += static_cast<u32>(wave::popc64(hm));
-              b += 64;
+            if (!FWD) {
+              g0 += below;
+            } else {
+              g1 = g0 + below;
             }
+          } else {
+            if (FWD) g1 = nh; else g0 = 0;
           }
-          const u32 s1 = umin(b, nb);
-          hi_cover = s1 < nb ? static_cast<u64>(wave::uniform(iv.bar_pos[s1])) : ~u64(0);
-          anchor = 0;
-        } else {
-          const u32 s1 = wave::uniform(bar_lower_bound(iv, need_hi));
-          hi_cover = need_hi;
-          u32 top = BAR_WIN;
-          u32 e = s1;
-          bool full = false;
-          while (e > 0 && !full) {
-            u32 Bp[G], Bf[G];
-#pragma unroll
-            for (u32 q = 0; q < G; ++q) {
-              const i64 idx = static_cast<i64>(e) - 64 * (q + 1) + lane;
-              const bool in = idx >= 0;
-              Bp[q] = in ? iv.bar_pos[idx] : 0;
-              Bf[q] = in ? (static_cast<u32>(ws.bar_active[idx] != 0) | (static_cast<u32>(iv.bar_dir[idx]) << 1)) : 0;
-            }
-#pragma unroll
-            for (u32 q = 0; q < G; ++q) {
-              if (full || e == 0) break;
-              if (top < 64) {
-                full = true;
-                break;
-              }
-              const i64 idx = static_cast<i64>(e) - 64 + lane;
-              const bool is_major = (Bf[q] >> 1) == major_dir;
-              const bool hit = idx >= 0 && (Bf[q] & 1u) && (is_major ? major_hits : minor_hits);
-              const u64 hm = wave::ballot(hit);
-              top -= static_cast<u32>(wave::popc64(hm));
-              if (hit) {
-                const u32 slot = top + static_cast<u32>(wave::popc64(hm & lanemask_lt(lane)));
-                cp[slot] = Bp[q];
-                ci[slot] = static_cast<u32>(idx) | (is_major ? HITBAR_HARD : 0u);
-              }
-              e = e > 64 ? e - 64 : 0;
-            }
+          if (!FWD) {
+            g1 = umin(g0 + BAR_WIN, nh);
+          } else {
+            g0 = g1 > BAR_WIN ? g1 - BAR_WIN : 0;
           }
-          const u32 s0 = e;
-          lo_cover = s0 > 0 ? static_cast<u64>(wave::uniform(iv.bar_pos[s0 - 1])) + 1 : 0;
-          c0 = top;
-          cnt = BAR_WIN - top;
-          anchor = cnt;
+          cnt = g1 - g0;
+          wave::lockstep();
+          {
+            u32 Hp[BAR_WIN / 64], Hi[BAR_WIN / 64];
+#pragma unroll
+            for (u32 t = 0; t < BAR_WIN / 64; ++t) {
+              const u32 e = lane + 64 * t;
+              Hp[t] = e < cnt ? hpos[g0 + e] : 0;
+              Hi[t] = e < cnt ? hidx[g0 + e] : 0;
+            }
+            // what the window does not hold: everything before it lies below lo_cover,
+            // everything after it at or above hi_cover
+            const u32 edge_lo = g0 > 0 ? hpos[g0 - 1] : 0;
+            const u32 edge_hi = g1 < nh ? hpos[g1] : 0;
+#pragma unroll
+            for (u32 t = 0; t < BAR_WIN / 64; ++t) {
+              const u32 e = lane + 64 * t;
+              if (e < cnt) {
+                cp[e] = Hp[t];
+                ci[e] = Hi[t];
+              }
+            }
+            lo_cover = g0 > 0 ? static_cast<u64>(wave::uniform(edge_lo)) + 1 : 0;
+            hi_cover = g1 < nh ? static_cast<u64>(wave::uniform(edge_hi)) : ~u64(0);
+          }
+          wave::sync_lds();
+          staged = true;
+          anchor = FWD ? cnt : 0;
+          // done unless the batch starts beyond this window and the list goes on
+          const bool beyond = FWD ? (need_hi <= lo_cover && g0 > 0) : (need_lo >= hi_cover && g1 < nh);
+          if (!beyond || ++moved > 64) break;  // (a batch that is still not covered is looked up in device memory)
         }
-        wave::sync_lds();
       }
       u32 winner = 0xFFFFFFFFu, bpos = 0;
       bool hard = false;
@@ -2634,6 +2679,8 @@ MODLE_DEV void init_cell(Cell& c, const Params& p, const Interval& iv, const Wor
   c.hist_len = 0;
   c.hist_head = 0;
   c.error = 0;
+  c.n_hit[0] = 0;
+  c.n_hit[1] = 0;
 #ifdef MODLE_PHASE_TIMERS
   for (int i = 0; i < 16; ++i) c.ph[i] = 0;
 #endif
@@ -2901,6 +2948,7 @@ MODLE_DEV u32 run_test_phases(const Params& p, const Interval& iv, const Workspa
     if (mask & PH_USE_BOUNDARY_COUNTS) bc = got;
   }
   if (mask & PH_LEF_BAR) {
+    if (stalling_lists_wanted(p)) compact_stalling_barriers(c);
     detect_lef_bar<false>(c, bc);
     detect_lef_bar<true>(c, bc);
   }

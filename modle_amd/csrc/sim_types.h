@@ -124,6 +124,10 @@ struct Workspace {
   u64* sort_keys;                       // pow2ceil(L) words
   f64* hist;                            // 2 * hist_len doubles (burn-in history)
   u8* bar_active;                       // n_barriers bytes
+  // barriers that stall a unit without a Bernoulli trial (blocking probabilities in {0, 1}),
+  // compacted in position order once per epoch: [0] as the rev units see them, [1] the fwd units
+  u32* hit_pos[2];                      // capacity_barriers words each
+  u32* hit_idx[2];                      // barrier index | hard << 31
   u32 capacity_lefs, capacity_barriers;
 };
 constexpr u32 NUM_STATE_ARRAYS = 12 + NUM_TMP;
