@@ -1181,7 +1181,32 @@ MODLE_DEV u32 lef_bar_pick(const BarView& v, const Params& p, const Rng& g, u32 
 // like the ranks, so every batch continues the search where the previous one stopped; a batch
 // whose windows do not fit is looked up in device memory.
 // ---------------------------------------------------------------------------------------------
-constexpr u32 HITBAR_NEAR = 127;  // entries next to the anchor that the fixed-step search covers
+constexpr u32 HITBAR_NEAR = 127;
+
+// Copies `cnt` (<= BAR_WIN) list entries into the LDS window: all loads in flight, then the LDS
+// writes.  A real call: it runs a few times per pass and its registers stay out of the pass's
+// allocation.
+MODLE_DEV_CALL void stage_stalling_window_call(MODLE_LDS u32* cp, MODLE_LDS u32* ci,
+                                               const u32* hpos, const u32* hidx, u32 cnt) {
+  const u32 lane = wave::lane();
+  const u32* gp = wave::as_global(hpos);
+  const u32* gi = wave::as_global(hidx);
+  u32 Hp[BAR_WIN / 64], Hi[BAR_WIN / 64];
+#pragma unroll
+  for (u32 t = 0; t < BAR_WIN / 64; ++t) {
+    const u32 e = lane + 64 * t;
+    Hp[t] = e < cnt ? gp[e] : 0;
+    Hi[t] = e < cnt ? gi[e] : 0;
+  }
+#pragma unroll
+  for (u32 t = 0; t < BAR_WIN / 64; ++t) {
+    const u32 e = lane + 64 * t;
+    if (e < cnt) {
+      cp[e] = Hp[t];
+      ci[e] = Hi[t];
+    }
+  }
+}  // entries next to the anchor that the fixed-step search covers
 
 template <bool FWD>
 MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
@@ -1300,25 +1325,11 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
           cnt = g1 - g0;
           wave::lockstep();
           {
-            u32 Hp[BAR_WIN / 64], Hi[BAR_WIN / 64];
-#pragma unroll
-            for (u32 t = 0; t < BAR_WIN / 64; ++t) {
-              const u32 e = lane + 64 * t;
-              Hp[t] = e < cnt ? hpos[g0 + e] : 0;
-              Hi[t] = e < cnt ? hidx[g0 + e] : 0;
-            }
             // what the window does not hold: everything before it lies below lo_cover,
             // everything after it at or above hi_cover
             const u32 edge_lo = g0 > 0 ? hpos[g0 - 1] : 0;
             const u32 edge_hi = g1 < nh ? hpos[g1] : 0;
-#pragma unroll
-            for (u32 t = 0; t < BAR_WIN / 64; ++t) {
-              const u32 e = lane + 64 * t;
-              if (e < cnt) {
-                cp[e] = Hp[t];
-                ci[e] = Hi[t];
-              }
-            }
+            stage_stalling_window_call((MODLE_LDS u32*)cp, (MODLE_LDS u32*)ci, hpos + g0, hidx + g0, cnt);
             lo_cover = g0 > 0 ? static_cast<u64>(wave::uniform(edge_lo)) + 1 : 0;
             hi_cover = g1 < nh ? static_cast<u64>(wave::uniform(edge_hi)) : ~u64(0);
           }
@@ -1605,9 +1616,13 @@ MODLE_DEV u32 stalling_barrier_pos(const Interval& iv, u32 word) {
 // what correct_moves_for_lef_bar_collisions stores for it).
 // what one batch of detect_primary reads from device memory: the rev units of 64 ranks and a
 // slice of STAGE_CAP fwd units
+// (positions for the whole slice: every lane searches them; moves, collision words and ids for
+// its first PRIMARY_NEAR units only: a rev unit's partner is almost always among them)
+constexpr u32 PRIMARY_NEAR = 128;
 struct PrimaryBatch {
   u32 R, rev_move, rev_id, rc;
-  u32 sp[STAGE_CAP / 64], sm[STAGE_CAP / 64], sc[STAGE_CAP / 64], si[STAGE_CAP / 64];
+  u32 sp[STAGE_CAP / 64];
+  u32 sm[PRIMARY_NEAR / 64], sc[PRIMARY_NEAR / 64], si[PRIMARY_NEAR / 64];
 };
 MODLE_DEV void primary_load_batch(const Workspace& ws, u32 n, u32 base, u32 w0, u32 lane,
                                   PrimaryBatch& b) {
@@ -1620,8 +1635,12 @@ MODLE_DEV void primary_load_batch(const Workspace& ws, u32 n, u32 base, u32 w0, 
 #pragma unroll
   for (u32 q = 0; q < STAGE_CAP / 64; ++q) {
     const u32 t = lane + 64 * q;
+    b.sp[q] = w0 + t < n ? ws.f_pos[w0 + t] : UNBOUND;
+  }
+#pragma unroll
+  for (u32 q = 0; q < PRIMARY_NEAR / 64; ++q) {
+    const u32 t = lane + 64 * q;
     const bool in = w0 + t < n;
-    b.sp[q] = in ? ws.f_pos[w0 + t] : UNBOUND;
     b.sm[q] = in ? ws.f_move[w0 + t] : 0;
     b.sc[q] = in ? ws.f_coll[w0 + t] : 0;
     b.si[q] = in ? ws.f_id[w0 + t] : 0;
@@ -1647,9 +1666,9 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
   // buffer, moves / collision words / ids in the (idle) sort buffer
   u32* stage = c.lds.stage;
   u32* st_move = reinterpret_cast<u32*>(c.lds.sort_lds);
-  u32* st_coll = st_move + STAGE_CAP;
-  u32* st_id = st_coll + STAGE_CAP;
-  static_assert(3 * STAGE_CAP <= 2 * SORT_LDS_CAP, "fwd slices do not fit the sort buffer");
+  u32* st_coll = st_move + PRIMARY_NEAR;
+  u32* st_id = st_coll + PRIMARY_NEAR;
+  static_assert(3 * PRIMARY_NEAR <= 2 * SORT_LDS_CAP, "fwd slices do not fit the sort buffer");
   u32 carry_pos = 0;
   u32 carry_pf = 0;  // fwd units strictly upstream of the last rev unit handled so far
   // pf = number of fwd units strictly upstream of R.  pf is monotone in the rank, so slices of
@@ -1673,9 +1692,10 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
     const u32 rc_k = cur.rc;
     wave::lockstep();
 #pragma unroll
-    for (u32 q = 0; q < STAGE_CAP / 64; ++q) {
+    for (u32 q = 0; q < STAGE_CAP / 64; ++q) stage[lane + 64 * q] = cur.sp[q];
+#pragma unroll
+    for (u32 q = 0; q < PRIMARY_NEAR / 64; ++q) {
       const u32 t = lane + 64 * q;
-      stage[t] = cur.sp[q];
       st_move[t] = cur.sm[q];
       st_coll[t] = cur.sc[q];
       st_id[t] = cur.si[q];
@@ -1705,13 +1725,14 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
     if (act && pf >= 1 && pf < i2) {
       const u32 kf = pf - 1;
       const bool staged = kf >= w0 && kf - w0 < STAGE_CAP;
+      const bool near = kf >= w0 && kf - w0 < PRIMARY_NEAR;
       F = staged ? stage[kf - w0] : ws.f_pos[kf];
       const bool first_after = (k == bc.n5) || Rprev <= F;
       if (first_after) {
         rev_move = rev_move_k;
-        fwd_move = staged ? st_move[kf - w0] : ws.f_move[kf];
-        fwd_id_s = staged ? st_id[kf - w0] : ws.f_id[kf];
-        fc_s = staged ? st_coll[kf - w0] : ws.f_coll[kf];
+        fwd_move = near ? st_move[kf - w0] : ws.f_move[kf];
+        fwd_id_s = near ? st_id[kf - w0] : ws.f_id[kf];
+        fc_s = near ? st_coll[kf - w0] : ws.f_coll[kf];
         const u32 delta = R - F;  // > 0 by construction
         cand = static_cast<u64>(delta) < static_cast<u64>(rev_move) + fwd_move;
       }
@@ -2500,26 +2521,34 @@ MODLE_DEV_NOINLINE void compute_loop_size_stats(Cell& c) {
   // UNBOUND and cancel: loop size 0, like the reference)
   u32* by_id_fwd = ws.tmp[0];
   u32* by_id_rev = ws.tmp[1];
-  constexpr u32 UX = 4;
+  constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
   u64 part = 0;
-  for (u32 group = 0; group < n; group += 64 * UX) {
+  struct UnitRegs {
     u32 fP[UX], fI[UX], rP[UX], rI[UX];
+  };
+  const auto load_units = [&](u32 group, UnitRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 k = group + 64 * u + lane;
       const bool act = k < n;
-      fP[u] = act ? ws.f_pos[k] : 0;
-      fI[u] = act ? ws.f_id[k] : 0;
-      rP[u] = act ? ws.r_pos[k] : 0;
-      rI[u] = act ? ws.r_id[k] : 0;
+      r.fP[u] = act ? ws.f_pos[k] : 0;
+      r.fI[u] = act ? ws.f_id[k] : 0;
+      r.rP[u] = act ? ws.r_pos[k] : 0;
+      r.rI[u] = act ? ws.r_id[k] : 0;
     }
+  };
+  UnitRegs cur;
+  load_units(0, cur);
+  for (u32 group = 0; group < n; group += 64 * UX) {
+    const UnitRegs g = cur;
+    if (group + 64 * UX < n) load_units(group + 64 * UX, cur);
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 k = group + 64 * u + lane;
       if (k < n) {
-        by_id_fwd[fI[u]] = fP[u];
-        by_id_rev[rI[u]] = rP[u];
-        part += static_cast<u64>(fP[u]) - static_cast<u64>(rP[u]);
+        by_id_fwd[g.fI[u]] = g.fP[u];
+        by_id_rev[g.rI[u]] = g.rP[u];
+        part += static_cast<u64>(g.fP[u]) - static_cast<u64>(g.rP[u]);
       }
     }
   }
