@@ -27,8 +27,6 @@ struct Cell {
   u32 hist_head;  // ring head
   u32 error;      // non-zero when an internal capacity was exceeded (uniform)
   u32 n_hit[2];   // entries of ws.hit_pos / hit_idx (stalling barriers of this epoch; uniform)
-  u32 n_bind;     // LEFs bound by this epoch's phase_bind: ids in ws.tmp[8], positions in ws.tmp[9]
-  u32 n_fix[2];   // avoided secondary collisions of the previous epoch (rev, fwd): ws.tmp[5] / [6]
 #ifdef MODLE_PHASE_TIMERS
   u64 ph[16];     // profiling build: time spent per phase (wave::clock ticks)
 #endif
@@ -88,7 +86,6 @@ MODLE_DEV_NOINLINE void phase_bind(Cell& c, u32 epoch_now) {
   const u32 lane = wave::lane();
   const u64 range = static_cast<u64>(iv.end) - 1 - iv.start;
   const u64 bucket = range != 0 ? uniform_int_bucket(range) : 1;
-  c.n_bind = 0;
   constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
   struct LefRegs {
     u32 E[UX], R[UX], F[UX];
@@ -139,10 +136,6 @@ MODLE_DEV_NOINLINE void phase_bind(Cell& c, u32 epoch_now) {
       }
     }
     if (unb) {
-      // (id, position) of every LEF bound in this epoch, for the ranking that follows
-      const u32 j = c.n_bind + static_cast<u32>(wave::popc64(mask & lanemask_lt(lane)));
-      ws.tmp[8][j] = i;
-      ws.tmp[9][j] = posv;
       ws.epoch[i] = epoch_now;
       const u32 kr = Rq[u], kf = Fq[u];
       ws.r_pos[kr] = posv;
@@ -150,7 +143,6 @@ MODLE_DEV_NOINLINE void phase_bind(Cell& c, u32 epoch_now) {
       ws.f_pos[kf] = posv;
       ws.f_move[kf] = NEW_MARK;
     }
-    c.n_bind += static_cast<u32>(wave::popc64(mask));
     }
   }
   wave::sync_mem();
@@ -325,214 +317,12 @@ MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_
   return ties;
 }
 
-// Orders equal positions (epoch rule, then previous rank) with a stable odd-even transposition
-// and rebuilds the inverse permutation.  Rare: only when two bound units share a position.
-template <bool FWD>
-MODLE_DEV_NOINLINE void rank_repair_ties(const Workspace& ws, u32 n, const u32* where, u32* out_pos,
-                                         u32* out_id, u32* where_new) {
-  const u32 lane = wave::lane();
-  bool bad = true;
-  while (bad) {
-    bad = false;
-    for (u32 parity = 0; parity < 2; ++parity) {
-      for (u32 base = 0; base < n; base += 128) {
-        const u32 k = base + 2 * lane + parity;
-        bool sw = false;
-        if (k + 1 < n) {
-          const u32 pa = out_pos[k], pb = out_pos[k + 1];
-          const u32 ia = out_id[k], ib = out_id[k + 1];
-          if (rank_pair_out_of_order<FWD>(ws, where, pa, ia, pb, ib)) {
-            out_pos[k] = pb;
-            out_pos[k + 1] = pa;
-            out_id[k] = ib;
-            out_id[k + 1] = ia;
-            sw = true;
-          }
-        }
-        bad = wave::any(sw) || bad;
-      }
-      wave::sync_mem();
-    }
-  }
-  for (u32 base = 0; base < n; base += 64) {
-    const u32 k = base + lane;
-    if (k < n) where_new[out_id[k]] = k;
-  }
-  wave::sync_mem();
-}
-
-// ---------------------------------------------------------------------------------------------
-// rank_lefs in one pass over the rank arrays, for the usual epoch: the units that have to be
-// (re)inserted are known before the pass -- the LEFs bound in this epoch (phase_bind lists them)
-// and the units whose rank slots fix_secondary_lef_lef_collisions rewrote in the previous epoch
-// (slots {i-1, i} of every rev entry i of its list, {i, i+1} for fwd; a superset of the units
-// that are really out of order).  Their keys are sorted in LDS and every other unit, still in
-// order, goes straight to  (its index among the kept units) + (keys before it).  Returns false
-// without touching the ranking when the set-up does not fit (too many new units) or a kept unit
-// turns out to be out of order; rank_update then takes the general two-pass route.
-// ---------------------------------------------------------------------------------------------
-template <bool FWD>
-MODLE_DEV_NOINLINE bool rank_update_fast(Cell& c) {
-  Workspace& ws = c.ws;
-  const u32 n = wave::uniform(c.n_active);
-  const u32 lane = wave::lane();
-  const u32 nbind = wave::uniform(c.n_bind);
-  const u32 nfix = wave::uniform(c.n_fix[FWD ? 1 : 0]);
-  if (nbind + 2 * nfix > STAGE_CAP) return false;
-  u32*& pos = FWD ? ws.f_pos : ws.r_pos;
-  u32*& ids = FWD ? ws.f_id : ws.r_id;
-  u32* marks = FWD ? ws.f_move : ws.r_move;
-  u32* where = FWD ? ws.f_rank : ws.r_rank;  // previous ranks until the final swap
-  u32* new_id = ws.tmp[4];
-  const u32* bind_ids = ws.tmp[8];
-  const u32* bind_pos = ws.tmp[9];
-  const u32* fix_list = FWD ? ws.tmp[6] : ws.tmp[5];
-  u64* keys = c.lds.sort_lds;
-  u32* cnt_lds = c.lds.stage;
-  // 1. keys of the units to insert: (position, serial number)
-  wave::lockstep();
-  for (u32 j = lane; j < nbind; j += 64) {
-    keys[j] = (static_cast<u64>(bind_pos[j]) << 32) | j;
-    new_id[j] = bind_ids[j];
-  }
-  u32 n_new = nbind;
-  for (u32 base = 0; base < 2 * nfix; base += 64) {
-    const u32 t = base + lane;
-    bool own = false;
-    u32 k = 0;
-    if (t < 2 * nfix) {
-      const u32 i = fix_list[t >> 1];
-      k = FWD ? i + (t & 1u) : i - (t & 1u);
-      // a slot can be named twice, or belong to a LEF that was released and bound again
-      if (k < n) own = wave::atomic_exch_u32(&marks[k], NEW_MARK) != NEW_MARK;
-    }
-    const u64 om = wave::ballot(own);
-    if (own) {
-      const u32 j = n_new + static_cast<u32>(wave::popc64(om & lanemask_lt(lane)));
-      keys[j] = (static_cast<u64>(pos[k]) << 32) | j;
-      new_id[j] = ids[k];
-    }
-    n_new += static_cast<u32>(wave::popc64(om));
-  }
-  const u32 n_old = n - n_new;
-  {
-    const u32 m2 = pow2_ceil(n_new);
-    for (u32 j = n_new + lane; j < m2; j += 64) keys[j] = ~u64(0);
-    for (u32 j = lane; j < n_new; j += 64) cnt_lds[j] = n_old;
-    wave::sync_mem();  // marks and new_id are read back below
-    if (m2 > 1) bitonic_sort_u64<true>(keys, m2);
-  }
-  // 2. the pass
-  u32* out_pos = ws.tmp[0];
-  u32* out_id = ws.tmp[1];
-  u32* where_new = ws.tmp[7];
-  bool ties = false, out_of_order = false;
-  u32 seen_old = 0, run_max = 0, carry_lo = 0;
-  constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
-  struct UnitRegs {
-    u32 P[UX], I[UX], K[UX];
-  };
-  const auto load_units = [&](u32 group, UnitRegs& r) {
-#pragma unroll
-    for (u32 u = 0; u < UX; ++u) {
-      const u32 kq = group + 64 * u + lane;
-      r.P[u] = kq < n ? pos[kq] : 0;
-      r.I[u] = kq < n ? ids[kq] : 0;
-      r.K[u] = kq < n ? marks[kq] : NEW_MARK;
-    }
-  };
-  UnitRegs cur;
-  load_units(0, cur);
-  for (u32 group = 0; group < n && !out_of_order; group += 64 * UX) {
-    const UnitRegs g = cur;
-    if (group + 64 * UX < n) load_units(group + 64 * UX, cur);
-#pragma unroll
-    for (u32 u = 0; u < UX; ++u) {
-      const u32 base = group + 64 * u;
-      if (base >= n || out_of_order) break;
-      const u32 pp = g.P[u];
-      const u32 oid = g.I[u];
-      const bool kept = base + lane < n && g.K[u] != NEW_MARK;
-      // kept units must be non-decreasing; excl = position of the kept unit before this one
-      const u32 pm = wave_prefix_max_u32(kept ? pp : 0);
-      const u32 pm_prev = wave::shfl_up(pm, 1);
-      const u32 excl = umax(run_max, lane > 0 ? pm_prev : 0);
-      if (wave::any(kept && pp < excl)) {
-        out_of_order = true;
-        break;
-      }
-      const u64 km = wave::ballot(kept);
-      const u32 before = static_cast<u32>(wave::popc64(km & lanemask_lt(lane)));
-      const u32 a = seen_old + before;
-      u32 lo = 0;
-      if (kept) {
-        const u64 thr = FWD ? ((static_cast<u64>(pp) + 1) << 32) : (static_cast<u64>(pp) << 32);
-        u32 hi = n_new;
-        while (lo < hi) {
-          const u32 mid = (lo + hi) >> 1;
-          if (keys[mid] < thr) lo = mid + 1; else hi = mid;
-        }
-      }
-      // keys [lo of the previous kept unit, lo) lie between that unit and this one
-      const u32 lo_run = wave_prefix_max_u32(kept ? lo : 0);
-      const u32 lo_run_prev = wave::shfl_up(lo_run, 1);
-      const u32 lo_prev = umax(carry_lo, lane > 0 ? lo_run_prev : 0);
-      bool tie = false;
-      if (kept) {
-        for (u32 j = lo_prev; j < lo; ++j) cnt_lds[j] = a;
-        if (pp != UNBOUND) {
-          if (FWD) {
-            tie = lo > 0 && static_cast<u32>(keys[lo - 1] >> 32) == pp;
-          } else {
-            tie = lo < n_new && static_cast<u32>(keys[lo] >> 32) == pp;
-          }
-          tie = tie || (a > 0 && excl == pp);
-        }
-        out_pos[a + lo] = pp;
-        out_id[a + lo] = oid;
-        where_new[oid] = a + lo;
-      }
-      ties = wave::any(tie) || ties;
-      carry_lo = umax(carry_lo, wave::bcast(lo_run, 63));
-      run_max = umax(run_max, wave::bcast(pm, 63));
-      seen_old += static_cast<u32>(wave::popc64(km));
-    }
-  }
-  wave::sync_lds();
-  if (out_of_order || seen_old != n_old) {
-    wave::sync_mem();
-    return false;  // nothing of the ranking has been replaced yet
-  }
-  for (u32 base = 0; base < n_new; base += 64) {
-    const u32 bq = base + lane;
-    bool tie = false;
-    if (bq < n_new) {
-      const u64 key = keys[bq];
-      const u32 pp = static_cast<u32>(key >> 32);
-      const u32 lo = cnt_lds[bq];
-      const u32 nid = new_id[static_cast<u32>(key)];
-      out_pos[bq + lo] = pp;
-      out_id[bq + lo] = nid;
-      where_new[nid] = bq + lo;
-      tie = bq + 1 < n_new && static_cast<u32>(keys[bq + 1] >> 32) == pp;
-    }
-    ties = wave::any(tie) || ties;
-  }
-  wave::sync_mem();
-  if (ties) rank_repair_ties<FWD>(ws, n, where, out_pos, out_id, where_new);
-  swap_ptr(pos, ws.tmp[0]);
-  swap_ptr(ids, ws.tmp[1]);
-  if (FWD) swap_ptr(ws.f_rank, ws.tmp[7]); else swap_ptr(ws.r_rank, ws.tmp[7]);
-  return true;
-}
-
 // all_new: treat every entry as newly bound (full sort; used by the phase-level test entry point)
 template <bool FWD>
 MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
   Workspace& ws = c.ws;
   const u32 n = wave::uniform(c.n_active);
   if (n < 2) return;
-  if (!all_new && rank_update_fast<FWD>(c)) return;
   const u32 lane = wave::lane();
   u32*& pos = FWD ? ws.f_pos : ws.r_pos;
   u32*& ids = FWD ? ws.f_id : ws.r_id;
@@ -645,7 +435,38 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
                         : rank_merge<FWD>(keys_glb, n_new, n_old, old_pos, old_id, new_id, out_pos,
                                           out_id, where_new, c.lds.stage);
   wave::sync_mem();
-  if (ties) rank_repair_ties<FWD>(ws, n, where, out_pos, out_id, where_new);
+  if (ties) {
+    // 4. order equal positions (epoch rule, then previous rank) with a stable odd-even
+    //    transposition, then rebuild the inverse permutation
+    bool bad = true;
+    while (bad) {
+      bad = false;
+      for (u32 parity = 0; parity < 2; ++parity) {
+        for (u32 base = 0; base < n; base += 128) {
+          const u32 k = base + 2 * lane + parity;
+          bool sw = false;
+          if (k + 1 < n) {
+            const u32 pa = out_pos[k], pb = out_pos[k + 1];
+            const u32 ia = out_id[k], ib = out_id[k + 1];
+            if (rank_pair_out_of_order<FWD>(ws, where, pa, ia, pb, ib)) {
+              out_pos[k] = pb;
+              out_pos[k + 1] = pa;
+              out_id[k] = ib;
+              out_id[k + 1] = ia;
+              sw = true;
+            }
+          }
+          bad = wave::any(sw) || bad;
+        }
+        wave::sync_mem();
+      }
+    }
+    for (u32 base = 0; base < n; base += 64) {
+      const u32 k = base + lane;
+      if (k < n) where_new[out_id[k]] = k;
+    }
+    wave::sync_mem();
+  }
   // 5. the new arrays become current
   swap_ptr(pos, ws.tmp[0]);
   swap_ptr(ids, ws.tmp[1]);
@@ -2346,8 +2167,6 @@ MODLE_DEV bool phase_process_collisions(Cell& c) {
         nf = process_secondary<true>(c, bc, list_fwd, cap, overflow, true, true));
   if (overflow) c.error = ERR_LIST_OVERFLOW;
   if (c.error != 0) return false;
-  c.n_fix[0] = nr;
-  c.n_fix[1] = nf;
   PHASE(c, 12, if (nr != 0) fix_secondary_rev(c, list_rev, nr);
         if (nf != 0) fix_secondary_fwd(c, list_fwd, nf));
   return true;
@@ -2891,9 +2710,6 @@ MODLE_DEV void init_cell(Cell& c, const Params& p, const Interval& iv, const Wor
   c.error = 0;
   c.n_hit[0] = 0;
   c.n_hit[1] = 0;
-  c.n_bind = 0;
-  c.n_fix[0] = 0;
-  c.n_fix[1] = 0;
 #ifdef MODLE_PHASE_TIMERS
   for (int i = 0; i < 16; ++i) c.ph[i] = 0;
 #endif

@@ -115,7 +115,7 @@ struct CellResult {
 // read and write contiguous memory.  What the reference indexes by LEF id (binding epoch, the
 // PRNG draw order of moves / release / bind) lives in id-ordered arrays, with the two inverse
 // permutations r_rank / f_rank connecting the views.
-constexpr u32 NUM_TMP = 10;
+constexpr u32 NUM_TMP = 8;
 struct Workspace {
   u32 *r_pos, *r_id, *r_move, *r_coll;  // rev units, by rev rank
   u32 *f_pos, *f_id, *f_move, *f_coll;  // fwd units, by fwd rank

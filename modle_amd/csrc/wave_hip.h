@@ -145,7 +145,6 @@ MODLE_DEV void atomic_add_u64(uint64_t* p, uint64_t v) {
   atomicAdd(reinterpret_cast<unsigned long long*>(p), static_cast<unsigned long long>(v));
 }
 MODLE_DEV uint32_t atomic_fetch_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
-MODLE_DEV uint32_t atomic_exch_u32(uint32_t* p, uint32_t v) { return atomicExch(p, v); }
 
 MODLE_DEV double f_log(double x) { return ::log(x); }
 MODLE_DEV double f_exp(double x) { return ::exp(x); }

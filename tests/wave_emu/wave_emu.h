@@ -179,7 +179,6 @@ MODLE_DEV void atomic_inc_u32(uint32_t* p) { __atomic_fetch_add(p, 1u, __ATOMIC_
 MODLE_DEV void atomic_add_u64(uint64_t* p, uint64_t v) {
   __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
 }
-MODLE_DEV uint32_t atomic_exch_u32(uint32_t* p, uint32_t v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
 MODLE_DEV uint32_t atomic_fetch_add_u32(uint32_t* p, uint32_t v) {
   return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
 }
