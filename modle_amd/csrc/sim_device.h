@@ -249,24 +249,37 @@ MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_
     const u32 pp = Pq[u];
     const u32 oid = Iq[u];
     bool tie = false;
-    u32 lo = 0;
+    // lo = number of keys that go before this unit.  Kept units and keys are both sorted, so the
+    // search continues from the previous batch's last answer: a few fixed steps reach almost
+    // every unit (a batch of 64 kept units has a couple of keys between them), the rest finish
+    // with a binary search
+    u32 lo = act ? carry_lo : 0;
     if (act) {
       const u64 thr = FWD ? ((static_cast<u64>(pp) + 1) << 32) : (static_cast<u64>(pp) << 32);
-      u32 hi = n_new;
-      while (lo < hi) {
-        const u32 mid = (lo + hi) >> 1;
-        if (keys[mid] < thr) lo = mid + 1; else hi = mid;
+#pragma unroll
+      for (u32 sft = 8; sft >= 1; sft >>= 1) {
+        if (lo + sft <= n_new && keys[lo + sft - 1] < thr) lo += sft;
       }
+      if (lo == carry_lo + 15 && lo < n_new) {
+        u32 hi = n_new;
+        while (lo < hi) {
+          const u32 mid = (lo + hi) >> 1;
+          if (keys[mid] < thr) lo = mid + 1; else hi = mid;
+        }
+      }
+    }
+    const u32 lo_first = carry_lo;
+    {
+      const u64 am = wave::ballot(act);
+      carry_lo = wave::bcast(lo, static_cast<u32>(63 - wave::clz64(am)));
     }
     if (use_cnt) {
       // keys [lo of the previous kept unit, lo) lie between that unit and this one
       const u32 lo_in = wave::shfl_up(lo, 1);
-      const u32 lo_prev = lane > 0 ? lo_in : carry_lo;
+      const u32 lo_prev = lane > 0 ? lo_in : lo_first;
       if (act) {
         for (u32 j = lo_prev; j < lo; ++j) cnt_lds[j] = a;
       }
-      const u64 am = wave::ballot(act);
-      carry_lo = wave::bcast(lo, static_cast<u32>(63 - wave::clz64(am)));
     }
     if (act) {
       if (pp != UNBOUND) {
@@ -1620,9 +1633,9 @@ MODLE_DEV u32 stalling_barrier_pos(const Interval& iv, u32 word) {
 // its first PRIMARY_NEAR units only: a rev unit's partner is almost always among them)
 constexpr u32 PRIMARY_NEAR = 128;
 struct PrimaryBatch {
-  u32 R, rev_move, rev_id, rc;
+  u32 R, rev_move, rev_id, rc, rbp;
   u32 sp[STAGE_CAP / 64];
-  u32 sm[PRIMARY_NEAR / 64], sc[PRIMARY_NEAR / 64], si[PRIMARY_NEAR / 64];
+  u32 sm[PRIMARY_NEAR / 64], sc[PRIMARY_NEAR / 64], si[PRIMARY_NEAR / 64], sb[PRIMARY_NEAR / 64];
 };
 MODLE_DEV void primary_load_batch(const Workspace& ws, u32 n, u32 base, u32 w0, u32 lane,
                                   PrimaryBatch& b) {
@@ -1632,6 +1645,10 @@ MODLE_DEV void primary_load_batch(const Workspace& ws, u32 n, u32 base, u32 w0, 
   b.rev_move = act ? ws.r_move[k] : 0;
   b.rev_id = act ? ws.r_id[k] : 0;
   b.rc = act ? ws.r_coll[k] : 0;
+  // position of the barrier that stalls the unit (meaningful where the word says LEF-BAR):
+  // having it here keeps a dependent load, and with it a wait for everything in flight, out of
+  // the batch's work
+  b.rbp = act ? stalling_barrier_positions<false>(ws)[k] : 0;
 #pragma unroll
   for (u32 q = 0; q < STAGE_CAP / 64; ++q) {
     const u32 t = lane + 64 * q;
@@ -1644,6 +1661,7 @@ MODLE_DEV void primary_load_batch(const Workspace& ws, u32 n, u32 base, u32 w0, 
     b.sm[q] = in ? ws.f_move[w0 + t] : 0;
     b.sc[q] = in ? ws.f_coll[w0 + t] : 0;
     b.si[q] = in ? ws.f_id[w0 + t] : 0;
+    b.sb[q] = in ? stalling_barrier_positions<true>(ws)[w0 + t] : 0;
   }
 }
 
@@ -1668,7 +1686,8 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
   u32* st_move = reinterpret_cast<u32*>(c.lds.sort_lds);
   u32* st_coll = st_move + PRIMARY_NEAR;
   u32* st_id = st_coll + PRIMARY_NEAR;
-  static_assert(3 * PRIMARY_NEAR <= 2 * SORT_LDS_CAP, "fwd slices do not fit the sort buffer");
+  u32* st_bp = st_id + PRIMARY_NEAR;
+  static_assert(4 * PRIMARY_NEAR <= 2 * SORT_LDS_CAP, "fwd slices do not fit the sort buffer");
   u32 carry_pos = 0;
   u32 carry_pf = 0;  // fwd units strictly upstream of the last rev unit handled so far
   // pf = number of fwd units strictly upstream of R.  pf is monotone in the rank, so slices of
@@ -1690,6 +1709,7 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
     const u32 rev_move_k = cur.rev_move;
     const u32 rev_id_k = cur.rev_id;
     const u32 rc_k = cur.rc;
+    const u32 rbp_k = cur.rbp;
     wave::lockstep();
 #pragma unroll
     for (u32 q = 0; q < STAGE_CAP / 64; ++q) stage[lane + 64 * q] = cur.sp[q];
@@ -1699,6 +1719,7 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
       st_move[t] = cur.sm[q];
       st_coll[t] = cur.sc[q];
       st_id[t] = cur.si[q];
+      st_bp[t] = cur.sb[q];
     }
     wave::sync_lds();
     const u32 prev_in = wave::shfl_up(R, 1);
@@ -1721,7 +1742,7 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
     const u32 next_pf = wave::bcast(pf, static_cast<u32>(63 - wave::clz64(am)));
     if (base + 64 < n) primary_load_batch(ws, n, base + 64, next_pf > 0 ? next_pf - 1 : 0, lane, cur);
     bool cand = false;
-    u32 F = 0, rev_move = 0, fwd_move = 0, fwd_id_s = 0, fc_s = 0;
+    u32 F = 0, rev_move = 0, fwd_move = 0, fwd_id_s = 0, fc_s = 0, fbp_s = 0;
     if (act && pf >= 1 && pf < i2) {
       const u32 kf = pf - 1;
       const bool staged = kf >= w0 && kf - w0 < STAGE_CAP;
@@ -1733,6 +1754,7 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
         fwd_move = near ? st_move[kf - w0] : ws.f_move[kf];
         fwd_id_s = near ? st_id[kf - w0] : ws.f_id[kf];
         fc_s = near ? st_coll[kf - w0] : ws.f_coll[kf];
+        fbp_s = near ? st_bp[kf - w0] : stalling_barrier_positions<true>(ws)[kf];
         const u32 delta = R - F;  // > 0 by construction
         cand = static_cast<u64>(delta) < static_cast<u64>(rev_move) + fwd_move;
       }
@@ -1759,7 +1781,7 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
         ws.f_coll[kf] = cw_make(rev_id, prim);
         both = true;
       } else if (rev_occ && !fwd_occ) {
-        const u32 barrier_pos = stalling_barrier_pos(iv, rc);
+        const u32 barrier_pos = cw_occurred_as(rc, EV_LEF_BAR) ? rbp_k : stalling_barrier_pos(iv, rc);
         ws.f_coll[kf] = cw_make(rev_id, prim);
         if (cpos_fwd > barrier_pos) {
           // the LEF-LEF collision happens before the predicted LEF-BAR one
@@ -1771,7 +1793,7 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
           ws.f_move[kf] = (R - rev_move_stalled) - F - 1;
         }
       } else if (!rev_occ && fwd_occ) {
-        const u32 barrier_pos = stalling_barrier_pos(iv, fc);
+        const u32 barrier_pos = cw_occurred_as(fc, EV_LEF_BAR) ? fbp_s : stalling_barrier_pos(iv, fc);
         ws.r_coll[k] = cw_make(fwd_id, prim);
         if (cpos_rev < barrier_pos) {
           ws.f_coll[kf] = cw_make(rev_id, prim);
