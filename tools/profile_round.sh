@@ -1,5 +1,5 @@
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r01f; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${PROFILE_TAG:-r01g}; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err; cat $O/bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof.err
 echo trace done
