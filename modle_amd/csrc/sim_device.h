@@ -275,7 +275,7 @@ MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_
     }
     if (use_cnt) {
       // keys [lo of the previous kept unit, lo) lie between that unit and this one
-      const u32 lo_in = wave::shfl_up(lo, 1);
+      const u32 lo_in = wave::shfl_up1(lo);
       const u32 lo_prev = lane > 0 ? lo_in : lo_first;
       if (act) {
         for (u32 j = lo_prev; j < lo; ++j) cnt_lds[j] = a;
@@ -293,7 +293,7 @@ MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_
       out_id[a + lo] = oid;
       where_new[oid] = a + lo;
     }
-    const u32 prev_in = wave::shfl_up(pp, 1);
+    const u32 prev_in = wave::shfl_up1(pp);
     const u32 prev = lane > 0 ? prev_in : carry_old;
     tie = tie || (act && pp != UNBOUND && prev == pp && (base != 0 || lane != 0));
     ties = wave::any(tie) || ties;
@@ -387,7 +387,7 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
     const bool carried = act && !fresh;
     const u32 pm = wave_prefix_max_u32(carried ? P : 0);
     const u32 incl_last = wave::bcast(pm, 63);
-    const u32 pm_prev = wave::shfl_up(pm, 1);
+    const u32 pm_prev = wave::shfl_up1(pm);
     const u32 excl = umax(run_max, lane > 0 ? pm_prev : 0);
     const bool displaced = carried && P < excl;
     const bool is_new = fresh || displaced;
@@ -693,7 +693,7 @@ MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp)
     const bool bnd = act && P != UNBOUND;
     const bool okself = do_adjust && bnd && static_cast<u64>(P) > start + M;
     const i64 d = okself ? static_cast<i64>(P - M) - static_cast<i64>(k) : 0;
-    const bool ok_next_in = wave::shfl_up(okself, 1);
+    const bool ok_next_in = wave::shfl_up1(okself);
     const bool ok_next = lane > 0 ? ok_next_in : carry_ok;
     const bool link = okself && ok_next;
     const SegScan sc = wave_prefix_segscan<false>(SegScan{d, link});
@@ -703,7 +703,7 @@ MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp)
     if (okself) Mnew = P - static_cast<u32>(val + static_cast<i64>(k));
     const bool cross = okself && static_cast<u64>(P) <= start + Mnew;
     if (act) mv_out[k] = (bnd && do_clamp) ? umin(Mnew, P - static_cast<u32>(start)) : Mnew;
-    const bool cross_next_in = wave::shfl_up(cross, 1);
+    const bool cross_next_in = wave::shfl_up1(cross);
     const bool cross_next = lane > 0 ? cross_next_in : carry_cross;
     const u64 vm = wave::ballot(link && cross_next);
     // highest rank k whose link to k+1 the scan got wrong (lowest lane); the replay starts at k+1
@@ -782,7 +782,7 @@ MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp)
     const bool bnd = act && P != UNBOUND;
     const bool okself = do_adjust && bnd && static_cast<u64>(P) + M <= last;
     const i64 d = okself ? static_cast<i64>(static_cast<u64>(P) + M) - static_cast<i64>(k) : 0;
-    const bool ok_prev_in = wave::shfl_up(okself, 1);
+    const bool ok_prev_in = wave::shfl_up1(okself);
     const bool ok_prev = lane > 0 ? ok_prev_in : carry_ok;
     const bool link = okself && ok_prev;  // link between k-1 and k
     const SegScan sc = wave_prefix_segscan<true>(SegScan{d, link});
@@ -792,7 +792,7 @@ MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp)
     if (okself) Mnew = static_cast<u32>(val + static_cast<i64>(k) - static_cast<i64>(P));
     const bool cross = okself && static_cast<u64>(P) + Mnew > last;
     if (act) mv_out[k] = (bnd && do_clamp) ? umin(Mnew, static_cast<u32>(last - P)) : Mnew;
-    const bool cross_prev_in = wave::shfl_up(cross, 1);
+    const bool cross_prev_in = wave::shfl_up1(cross);
     const bool cross_prev = lane > 0 ? cross_prev_in : carry_cross;
     const u64 vm = wave::ballot(link && cross_prev);
     // lowest rank k-1 whose updated move crosses the 3'-end while the scan linked it to k
@@ -1284,7 +1284,7 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
       const u32 P = Pq[u];
       const u32 M = Mq[u];
       const bool bnd = act && P != UNBOUND;
-      const u32 nbr_in = wave::shfl_up(P, 1);
+      const u32 nbr_in = wave::shfl_up1(P);
       const bool first = (bi == 0 && lane == 0);
       const u32 nbr = lane > 0 ? nbr_in : carry_pos;
       u64 lo_key = 0, hi_key = 0;  // see detect_lef_bar
@@ -1494,7 +1494,7 @@ MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
       const u32 M = Mq[u];
       const bool bnd = act && P != UNBOUND;
       // neighbour towards which the barriers are shadowed (rank k-1 for rev, k+1 for fwd)
-      const u32 nbr_in = wave::shfl_up(P, 1);
+      const u32 nbr_in = wave::shfl_up1(P);
       const bool first = (bi == 0 && lane == 0);
       const u32 nbr = lane > 0 ? nbr_in : carry_pos;
       // the unit can be stalled by barriers with lo_key <= position < hi_key
@@ -1722,15 +1722,19 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
       st_bp[t] = cur.sb[q];
     }
     wave::sync_lds();
-    const u32 prev_in = wave::shfl_up(R, 1);
+    const u32 prev_in = wave::shfl_up1(R);
     const u32 Rprev = lane > 0 ? prev_in : carry_pos;
     u32 pf = 0;
     if (act) {
-      u32 lo = 0, hi = STAGE_CAP;
-      while (lo < hi) {
-        const u32 mid = (lo + hi) >> 1;
-        if (stage[mid] < R) lo = mid + 1; else hi = mid;
+      // number of staged positions below R: a fixed-step search (no loop control, the eight
+      // steps are the same for every lane)
+      u32 lo = 0;
+      static_assert(STAGE_CAP == 256, "the search below covers 256 entries");
+#pragma unroll
+      for (u32 sft = 128; sft >= 1; sft >>= 1) {
+        if (stage[lo + sft - 1] < R) lo += sft;
       }
+      if (lo == STAGE_CAP - 1 && stage[STAGE_CAP - 1] < R) lo = STAGE_CAP;
       if (lo == STAGE_CAP && w0 + STAGE_CAP < n) {
         pf = lower_bound_u32(ws.f_pos, n, R);
       } else {
@@ -1936,7 +1940,7 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
       }
       const bool follower = do_secondary && act && (FWD ? (kk <= f_first) : (kk >= f_first));
       // vector pre-filter: follower free and able to reach the blocker's current position
-      const u32 bp_in = wave::shfl_up(P, 1);
+      const u32 bp_in = wave::shfl_up1(P);
       const u32 blocker_pos = lane > 0 ? bp_in : carry_pos;
       const bool pot = follower && !cw_occurred(C) &&
                        (FWD ? static_cast<u64>(P) + M >= blocker_pos
@@ -1945,7 +1949,7 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
       // stalled in this pass because it is a candidate itself (cascade): propagate "blocker may
       // be stalled" along runs of consecutive candidates with scalar bit operations.
       const u64 potm = wave::ballot(pot);
-      const bool blk_occ_in = wave::shfl_up(cw_occurred(C), 1);
+      const bool blk_occ_in = wave::shfl_up1(cw_occurred(C));
       const u64 occm = wave::ballot(lane > 0 ? blk_occ_in : cw_occurred(carry_coll));
       u64 pend = potm & occm;
       for (;;) {
@@ -1958,8 +1962,8 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
       // Bernoulli draws numbered in lane order (the reference's visiting order).  A batch
       // without cascades takes one round.
       while (pend != 0) {
-        const u32 bP_in = wave::shfl_up(P, 1), bM_in = wave::shfl_up(M, 1);
-        const u32 bC_in = wave::shfl_up(C, 1), bI_in = wave::shfl_up(id, 1);
+        const u32 bP_in = wave::shfl_up1(P), bM_in = wave::shfl_up1(M);
+        const u32 bC_in = wave::shfl_up1(C), bI_in = wave::shfl_up1(id);
         const u32 bP = lane > 0 ? bP_in : carry_pos;
         const u32 bM = lane > 0 ? bM_in : carry_move;
         const u32 bC = lane > 0 ? bC_in : carry_coll;

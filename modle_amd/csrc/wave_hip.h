@@ -101,6 +101,13 @@ MODLE_DEV T shfl_up(T v, unsigned delta) {
   return __shfl_up(v, delta, 64);
 }
 
+// lane l receives the value of lane l-1 (lane 0 keeps its own): one DPP lane move across the
+// whole wave (wave_shr:1) instead of a ds_bpermute round trip
+MODLE_DEV uint32_t shfl_up1(uint32_t v) {
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x138, 0xF, 0xF, false));
+}
+MODLE_DEV bool shfl_up1(bool v) { return shfl_up1(static_cast<uint32_t>(v)) != 0; }
+
 // One step of a 64-lane inclusive prefix scan made of DPP lane moves (no LDS round trip).  Lane
 // l receives the value of the lane the step names, or `identity` when the step gives it none:
 //   SCAN_SHR1/2/4/8  lane l - n of the same row of 16 lanes

@@ -150,6 +150,9 @@ MODLE_DEV T shfl_up(T v, unsigned delta, int line = __builtin_LINE()) {
   return shfl(v, src, line);
 }
 
+MODLE_DEV uint32_t shfl_up1(uint32_t v, int line = __builtin_LINE()) { return shfl_up(v, 1u, line); }
+MODLE_DEV bool shfl_up1(bool v, int line = __builtin_LINE()) { return shfl_up(v, 1u, line); }
+
 enum ScanStep { SCAN_SHR1, SCAN_SHR2, SCAN_SHR4, SCAN_SHR8, SCAN_BCAST15, SCAN_BCAST31 };
 template <int STEP>
 MODLE_DEV uint32_t scan_move(uint32_t v, uint32_t identity, int line = __builtin_LINE()) {
