@@ -72,3 +72,27 @@ def algorithmic_bytes(results, n_barriers, track_1d=True):
         total += 40 * r.sum_active_lefs + (22 * n_barriers + 64) * r.sim_epochs
         total += (8 + (16 if track_1d else 0)) * r.sampling_events
     return total
+
+
+def write_cooler(path, cfg, plan, matrices, assembly="unknown", generated_by="modle-hip",
+                 metadata_json="", force_overwrite=False):
+    """Writes the (reduced) contact matrices of a plan to a cooler file the way the reference's
+    IO thread does (simulation.cpp:117-168, 217-269): every chromosome of the genome is in the
+    file, intervals are appended in genome order, skipped intervals and intervals without a
+    matrix contribute no pixels.  `matrices[k]`: band matrix of plan entry k (uint32,
+    nrows * ncols [+1] words, layout of modle_hip_interval_outputs) or None."""
+    from . import cooler
+
+    chroms = []
+    for entry in plan:
+        iv = entry["interval"]
+        if not chroms or chroms[-1][0] != iv["name"]:
+            chroms.append((iv["name"], int(iv["size"])))
+    with cooler.CoolerWriter(path, chroms, int(cfg.bin_size), assembly=assembly,
+                             generated_by=generated_by, metadata_json=metadata_json,
+                             force_overwrite=force_overwrite) as w:
+        for entry, m in zip(plan, matrices):
+            if entry["skipped"] or m is None:
+                continue
+            iv = entry["interval"]
+            w.append(iv["name"], m, entry["nrows"], entry["ncols"], offset_bp=int(iv["start"]))

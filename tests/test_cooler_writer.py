@@ -1,0 +1,238 @@
+"""Cooler (v3) writer, SURVEY.md section 8(f) row 1: the file written through the C ABI holds
+exactly the pixel table the reference's append loop produces
+(contact_matrix_dense_io_impl.hpp:51-71: rows ascending, columns within the band, non-zero
+counts only, bin ids offset by the chromosome's first bin and the interval's start), the bin and
+chromosome tables, the offset indexes and the attributes of hictk 2.1.4.  Read back with the
+image's h5dump (no HDF5 binding for Python here)."""
+import json
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from modle_amd import cooler
+
+H5DUMP = shutil.which("h5dump") or "/opt/conda/bin/h5dump"
+pytestmark = pytest.mark.skipif(not os.path.exists(H5DUMP), reason="h5dump not available")
+
+
+def _dump(path, dataset):
+    out = subprocess.run([H5DUMP, "-d", dataset, "-y", "-w", "0", path], capture_output=True,
+                         text=True, check=True).stdout
+    body = out[out.index("DATA {") + 6:out.rindex("}")]
+    body = body[:body.rindex("}")]
+    return body
+
+
+def _ints(path, dataset):
+    return np.array([int(x) for x in re.findall(r"-?\d+", _dump(path, dataset))], dtype=np.int64)
+
+
+def _strings(path, dataset):
+    # fixed-length, null-padded strings (what cooler and hictk write): h5dump prints the padding
+    return [x.replace("\\000", "") for x in re.findall(r'"([^"]*)"', _dump(path, dataset))]
+
+
+def _attrs(path):
+    out = subprocess.run([H5DUMP, "-A", "-g", "/", path], capture_output=True, text=True, check=True).stdout
+    # root attributes come first; stop at the first GROUP inside "/"
+    root = out[:out.index('GROUP "bins"')] if 'GROUP "bins"' in out else out
+    attrs = {}
+    for name, block in re.findall(r'ATTRIBUTE "([^"]+)" \{(.*?)\n   \}', root, flags=re.S):
+        data = block[block.index("DATA {"):]
+        m = re.search(r'\(0\): (.*)', data)
+        val = m.group(1).strip()
+        attrs[name] = val[1:-1] if val.startswith('"') else int(val)
+    return attrs
+
+
+def _band(rng, nrows, ncols, density):
+    """random band matrix in the library's layout: cell (row, col) at col * nrows + (col - row)"""
+    band = np.zeros(nrows * ncols + 1, dtype=np.uint32)
+    mask = rng.random(nrows * ncols) < density
+    band[:nrows * ncols][mask] = rng.integers(1, 500, size=int(mask.sum()))
+    # cells above the matrix' first row do not exist (col - row > col)
+    for col in range(min(nrows, ncols)):
+        band[col * nrows + col + 1:(col + 1) * nrows] = 0
+    return band
+
+
+def _expected_pixels(band, nrows, ncols, bin_offset):
+    rows = []
+    for i in range(ncols):
+        for j in range(i, min(ncols, i + nrows)):
+            n = int(band[j * nrows + (j - i)])
+            if n != 0:
+                rows.append((bin_offset + i, bin_offset + j, n))
+    return rows
+
+
+def test_cooler_file_holds_the_reference_pixel_table(tmp_path):
+    rng = np.random.default_rng(7)
+    bin_size = 5000
+    chroms = [("chrA", 1_003_000), ("chrEmpty", 42_000), ("chrB", 600_000), ("chrLongerName", 77_777)]
+    nbins = [-(-s // bin_size) for _, s in chroms]
+    first_bin = np.concatenate([[0], np.cumsum(nbins)])
+    path = str(tmp_path / "out.cool")
+    expected = []
+    with cooler.CoolerWriter(path, chroms, bin_size, assembly="test-asm", generated_by="modle-hip test",
+                             metadata_json='{"seed": 0}') as w:
+        # whole chromosome A, band narrower than the matrix
+        nrows, ncols = 40, nbins[0]
+        band = _band(rng, nrows, ncols, 0.3)
+        w.append("chrA", band, nrows, ncols)
+        expected += _expected_pixels(band, nrows, ncols, int(first_bin[0]))
+        # an interval of chromosome B that starts at 150 kb; band as wide as the matrix
+        ncols = 50
+        nrows = 50
+        band = _band(rng, nrows, ncols, 0.5)
+        w.append("chrB", band, nrows, ncols, offset_bp=150_000)
+        expected += _expected_pixels(band, nrows, ncols, int(first_bin[2]) + 150_000 // bin_size)
+    b1, b2, cnt = _ints(path, "/pixels/bin1_id"), _ints(path, "/pixels/bin2_id"), _ints(path, "/pixels/count")
+    assert len(expected) > 1000
+    assert list(zip(b1.tolist(), b2.tolist(), cnt.tolist())) == expected
+    # sorted by (bin1, bin2), upper triangle
+    assert np.all(b1 <= b2)
+    assert np.all((np.diff(b1) > 0) | ((np.diff(b1) == 0) & (np.diff(b2) > 0)))
+    # tables
+    assert _strings(path, "/chroms/name") == [n for n, _ in chroms]
+    assert _ints(path, "/chroms/length").tolist() == [s for _, s in chroms]
+    bc, bs, be = _ints(path, "/bins/chrom"), _ints(path, "/bins/start"), _ints(path, "/bins/end")
+    assert len(bc) == sum(nbins)
+    for cid, (_, size) in enumerate(chroms):
+        sel = bc == cid
+        assert bs[sel].tolist() == list(range(0, size, bin_size))
+        assert be[sel].tolist() == [min(s + bin_size, size) for s in range(0, size, bin_size)]
+    # indexes
+    assert _ints(path, "/indexes/chrom_offset").tolist() == first_bin.tolist()
+    off = _ints(path, "/indexes/bin1_offset")
+    assert len(off) == sum(nbins) + 1 and off[0] == 0 and off[-1] == len(b1)
+    assert np.array_equal(off, np.searchsorted(b1, np.arange(sum(nbins) + 1), side="left"))
+    # attributes (hictk 2.1.4 cooler.hpp:50-73)
+    a = _attrs(path)
+    assert a["format"] == "HDF5::Cooler" and a["format-version"] == 3
+    assert a["bin-type"] == "fixed" and a["bin-size"] == bin_size
+    assert a["storage-mode"] == "symmetric-upper"
+    assert a["nbins"] == sum(nbins) and a["nchroms"] == len(chroms) and a["nnz"] == len(b1)
+    assert a["sum"] == int(cnt.sum()) and a["cis"] == int(cnt.sum())
+    assert a["assembly"] == "test-asm" and a["generated-by"] == "modle-hip test"
+    assert json.loads(a["metadata"].replace('\\"', '"')) == {"seed": 0}
+    assert a["format-url"] == "https://github.com/open2c/cooler"
+
+
+def test_cooler_writer_errors(tmp_path):
+    path = str(tmp_path / "x.cool")
+    chroms = [("c1", 100_000), ("c2", 50_000)]
+    w = cooler.CoolerWriter(path, chroms, 10_000)
+    band = np.ones(3 * 5 + 1, dtype=np.uint32)
+    w.append("c2", band, 3, 5)
+    with pytest.raises(cooler.CoolerError) as e:  # out of genome order
+        w.append("c1", band, 3, 5)
+    assert e.value.code == -1
+    w.close()
+    with pytest.raises(cooler.CoolerError) as e:  # exists, no overwrite
+        cooler.CoolerWriter(path, chroms, 10_000)
+    assert e.value.code == -2
+    w = cooler.CoolerWriter(path, chroms, 10_000, force_overwrite=True)
+    with pytest.raises(cooler.CoolerError) as e:  # 11 columns do not fit 10 bins
+        w.append("c1", np.ones(2 * 11 + 1, dtype=np.uint32), 2, 11)
+    assert e.value.code == -3
+    big = np.zeros(2 * 4 + 1, dtype=np.uint32)
+    big[0] = 2**31
+    with pytest.raises(cooler.CoolerError) as e:  # count beyond int32
+        w.append("c1", big, 2, 4)
+    assert e.value.code == -3
+    w.close()
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(os.path.dirname(__file__), "..", "include", "modle_cooler.h")).read()
+    names = set(re.findall(r"\b(modle_cool_[a-z_]+)\s*\(", header))
+    assert names == {"modle_cool_create", "modle_cool_append_matrix", "modle_cool_close"}
+    lb = cooler.lib()
+    for n in names:
+        assert hasattr(lb, n)
+
+
+def _small_genome():
+    from modle_amd import synthetic
+
+    return [synthetic.synthetic_chromosome("chrA", 3_000_000, seed=1),
+            synthetic.synthetic_chromosome("chrB", 2_000_000, seed=2, with_barriers=False),
+            synthetic.synthetic_chromosome("chrC", 2_500_000, seed=3)]
+
+
+def _check_genome_cooler(path, cfg, plan, matrices):
+    """pixels of the file == non-zero cells of the band matrices, chromosome by chromosome"""
+    bin_size = int(cfg.bin_size)
+    b1, b2, cnt = _ints(path, "/pixels/bin1_id"), _ints(path, "/pixels/bin2_id"), _ints(path, "/pixels/count")
+    chrom_offset = _ints(path, "/indexes/chrom_offset")
+    assert _strings(path, "/chroms/name") == [e["interval"]["name"] for e in plan]
+    total = 0
+    for k, (entry, m) in enumerate(zip(plan, matrices)):
+        sel = (b1 >= chrom_offset[k]) & (b1 < chrom_offset[k + 1])
+        if m is None:
+            assert not sel.any()  # the chromosome is in the file, without pixels
+            continue
+        nrows, ncols = entry["nrows"], entry["ncols"]
+        assert chrom_offset[k + 1] - chrom_offset[k] == -(-entry["interval"]["size"] // bin_size)
+        dense = np.zeros(nrows * ncols, dtype=np.int64)
+        i, j = b1[sel] - chrom_offset[k], b2[sel] - chrom_offset[k]
+        dense[j * nrows + (j - i)] = cnt[sel]
+        assert np.array_equal(dense, m[:nrows * ncols].astype(np.int64))
+        total += int(m[:nrows * ncols].sum())
+    assert total > 0 and _attrs(path)["sum"] == total
+
+
+def test_oracle_genome_to_cooler(oracle, tmp_path):
+    """host logic + oracle + writer on a three-chromosome genome (the middle one has no barriers
+    and is skipped, like scheduler_simulate.cpp:111-124, but stays in the file)"""
+    from modle_amd import api, driver
+
+    cfg = api.make_config(num_cells=4, diagonal_width=1_000_000, target_contact_density=0.2)
+    plan = driver.plan_genome(cfg, _small_genome())
+    matrices = []
+    for entry in plan:
+        if entry["skipped"]:
+            matrices.append(None)
+            continue
+        iv = entry["interval"]
+        stp_a, stp_i = api.barrier_stps(cfg, iv["bar_occupancy"])
+        c, _, _, _ = oracle.simulate_interval(cfg, iv["start"], iv["end"], iv["bar_pos"], iv["bar_dir"],
+                                              stp_a, stp_i, entry["tasks"], nthreads=4)
+        matrices.append(c)
+    assert matrices[1] is None
+    path = str(tmp_path / "genome.cool")
+    driver.write_cooler(path, cfg, plan, matrices, assembly="synthetic")
+    _check_genome_cooler(path, cfg, plan, matrices)
+
+
+@pytest.mark.gpu
+def test_gpu_genome_to_cooler(oracle, tmp_path):
+    """the same through the HIP library; the file's pixels also equal the oracle's matrices"""
+    from modle_amd import api, driver
+
+    cfg = api.make_config(num_cells=4, diagonal_width=1_000_000, target_contact_density=0.2)
+    plan = driver.plan_genome(cfg, _small_genome())
+    sim = api.Simulator(cfg, 0)
+    try:
+        ids = driver.enqueue_plan(sim, cfg, plan)
+        sim.launch()
+        sim.wait()
+        matrices = [None if iid is None else sim.copy_outputs(iid)[0] for iid in ids]
+    finally:
+        sim.close()
+    for entry, m in zip(plan, matrices):
+        if m is None:
+            continue
+        iv = entry["interval"]
+        stp_a, stp_i = api.barrier_stps(cfg, iv["bar_occupancy"])
+        c, _, _, _ = oracle.simulate_interval(cfg, iv["start"], iv["end"], iv["bar_pos"], iv["bar_dir"],
+                                              stp_a, stp_i, entry["tasks"], nthreads=4)
+        assert np.array_equal(c, m)
+    path = str(tmp_path / "genome_gpu.cool")
+    driver.write_cooler(path, cfg, plan, matrices, assembly="synthetic")
+    _check_genome_cooler(path, cfg, plan, matrices)
