@@ -106,7 +106,7 @@ __device__ __forceinline__ Workspace device_carve(char* base, u32 max_lefs, u32 
 }
 
 struct BlockLds {
-  u64 jump[JUMP_TABLE_WORDS];
+  alignas(16) u64 jump[JUMP_TABLE_WORDS];  // rows are read 128 bits at a time
   f64 zig[kZigWords];
   u64 ring[kWavesPerBlock][RNG_RING];
   u64 rng_state[kWavesPerBlock][4 * 64];

@@ -145,35 +145,34 @@ MODLE_DEV_CALL void rng_gen_block_call(MODLE_LDS u64* ring, const MODLE_LDS u64*
   for (u32 t = 0; t < RNG_CHUNK; ++t) {
     ring[base + (t ^ (lane & (RNG_CHUNK - 1)))] = xo_next(a0, a1, a2, a3);
   }
-  // T^RNG_BLOCK * state: XOR of one table row per state nibble.  The rows are fetched in groups
-  // (all loads of a group in flight, then folded) -- left alone the compiler waits for every
-  // LDS load before issuing the next one.
-  u64 j0 = 0, j1 = 0, j2 = 0, j3 = 0;
+  // T^RNG_BLOCK * state: XOR of one table row (4 words) per state nibble.  Rows are fetched in
+  // groups of four (all loads of a group in flight, then folded; left alone the compiler waits
+  // for every LDS load before issuing the next one), each row as two 128-bit reads, and folded
+  // on 32-bit halves with three-input XORs.
+  u32 acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   constexpr int GROUP = 4;
 #pragma unroll
   for (int g = 0; g < 64 / GROUP; ++g) {
-    u64 r[GROUP][4];
+    wave::LdsRow r[GROUP];
 #pragma unroll
     for (int q = 0; q < GROUP; ++q) {
       const int nib = g * GROUP + q;  // nibble k of state word wi
       const int wi = nib / 16, k = nib % 16;
-      const u32 v = static_cast<u32>(w[wi] >> (4 * k)) & 15u;
-      const MODLE_LDS u64* row = jump + ((wi * 16 + k) * 16 + v) * 4;
-      r[q][0] = row[0];
-      r[q][1] = row[1];
-      r[q][2] = row[2];
-      r[q][3] = row[3];
+      const u32 half = k < 8 ? static_cast<u32>(w[wi]) : static_cast<u32>(w[wi] >> 32);
+      const u32 v = (half >> (4 * (k % 8))) & 15u;
+      r[q] = wave::lds_load_row(jump + ((wi * 16 + k) * 16) * 4, v);
     }
     wave::sched_fence();
 #pragma unroll
-    for (int q = 0; q < GROUP; ++q) {
-      j0 ^= r[q][0];
-      j1 ^= r[q][1];
-      j2 ^= r[q][2];
-      j3 ^= r[q][3];
+    for (int h = 0; h < 8; ++h) {
+      acc[h] = wave::xor3(acc[h], r[0].h[h], r[1].h[h]);
+      acc[h] = wave::xor3(acc[h], r[2].h[h], r[3].h[h]);
+      wave::pin(acc[h]);  // fold this group before the next group's rows are fetched
     }
     wave::sched_fence();
   }
+  const u64 j0 = (static_cast<u64>(acc[1]) << 32) | acc[0], j1 = (static_cast<u64>(acc[3]) << 32) | acc[2],
+            j2 = (static_cast<u64>(acc[5]) << 32) | acc[4], j3 = (static_cast<u64>(acc[7]) << 32) | acc[6];
   state[0 * 64 + lane] = j0;
   state[1 * 64 + lane] = j1;
   state[2 * 64 + lane] = j2;

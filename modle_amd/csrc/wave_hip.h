@@ -141,6 +141,25 @@ MODLE_DEV void sync_lds() {
 // lane overwrites data another lane has just read.  (The emulator yields here.)
 MODLE_DEV void lockstep() { __builtin_amdgcn_wave_barrier(); }
 
+// the value has to exist in a register at this point of the program: keeps the optimizer from
+// sinking the computation that produces it (sched_fence only binds the instruction scheduler)
+MODLE_DEV void pin(uint32_t& v) { asm volatile("" : "+v"(v)); }
+// a ^ b ^ c in one instruction (v_bitop3_b32)
+MODLE_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+  return static_cast<uint32_t>(__builtin_amdgcn_bitop3_b32(a, b, c, 0x96));
+}
+// Row `v` of a 16-row LDS table of 4 x 64-bit words (32 bytes per row, the table 16-byte aligned):
+// two 128-bit reads.  h[2 i], h[2 i + 1] = low / high half of word i.
+struct LdsRow {
+  uint32_t h[8];
+};
+MODLE_DEV LdsRow lds_load_row(const MODLE_LDS uint64_t* table, uint32_t v) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const MODLE_LDS u32x4* row = reinterpret_cast<const MODLE_LDS u32x4*>(table) + 2 * v;
+  const u32x4 a = row[0], b = row[1];
+  return LdsRow{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+}
+
 // the instruction scheduler may not move anything across this point
 MODLE_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 

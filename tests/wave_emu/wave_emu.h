@@ -176,6 +176,20 @@ MODLE_DEV void sync_lds(int line = __builtin_LINE()) { (void)wave_emu::collectiv
 MODLE_DEV void lockstep(int line = __builtin_LINE()) { (void)wave_emu::collective(0, 0, line); }
 
 MODLE_DEV uint64_t clock() { return 0; }
+MODLE_DEV void pin(uint32_t&) {}
+MODLE_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }
+struct LdsRow {
+  uint32_t h[8];
+};
+MODLE_DEV LdsRow lds_load_row(const uint64_t* table, uint32_t v) {
+  LdsRow r;
+  for (int i = 0; i < 4; ++i) {
+    const uint64_t x = table[4 * v + i];
+    r.h[2 * i] = static_cast<uint32_t>(x);
+    r.h[2 * i + 1] = static_cast<uint32_t>(x >> 32);
+  }
+  return r;
+}
 MODLE_DEV void sched_fence() {}
 
 MODLE_DEV void atomic_inc_u32(uint32_t* p) { __atomic_fetch_add(p, 1u, __ATOMIC_RELAXED); }
