@@ -1248,7 +1248,7 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
   constexpr u32 c0 = 0;
   u32 g0 = 0, g1 = 0, cnt = 0;      // the window holds list entries [g0, g1): cp[0 .. cnt)
   bool staged = false;
-  u64 lo_cover = 1, hi_cover = 0;   // nothing staged yet
+  u32 lo_cover = 1, hi_cover = 0;   // nothing staged yet (0xFFFFFFFF: no bound)
   u32 anchor = 0;                   // rev: entries below it lie before the batch; fwd: entries at
                                     // or above it lie beyond the batch (relative to c0)
   const u32 nbatch = (n + 63) / 64;
@@ -1259,9 +1259,10 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
   const auto load_units = [&](u32 bg, UnitRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
-      const i64 kk = FWD ? static_cast<i64>(j_fwd0) - static_cast<i64>(bg + u) * 64 - lane
-                         : static_cast<i64>(j_rev0) + static_cast<i64>(bg + u) * 64 + lane;
-      const bool act = kk >= 0 && kk < static_cast<i64>(n);
+      // (ranks stay far below 2^31: 32-bit index arithmetic)
+      const i32 kk = FWD ? static_cast<i32>(j_fwd0) - static_cast<i32>((bg + u) * 64 + lane)
+                         : static_cast<i32>(j_rev0 + (bg + u) * 64 + lane);
+      const bool act = kk >= 0 && static_cast<u32>(kk) < n;
       r.P[u] = act ? pos[static_cast<u32>(kk)] : 0;
       r.M[u] = act ? moves[static_cast<u32>(kk)] : 0;
     }
@@ -1276,9 +1277,9 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 bi = bg + u;
-      const i64 kk = FWD ? static_cast<i64>(j_fwd0) - static_cast<i64>(bi) * 64 - lane
-                         : static_cast<i64>(j_rev0) + static_cast<i64>(bi) * 64 + lane;
-      const bool act = kk >= 0 && kk < static_cast<i64>(n);
+      const i32 kk = FWD ? static_cast<i32>(j_fwd0) - static_cast<i32>(bi * 64 + lane)
+                         : static_cast<i32>(j_rev0 + bi * 64 + lane);
+      const bool act = kk >= 0 && static_cast<u32>(kk) < n;
       if (!wave::any(act)) break;
       const u32 k = act ? static_cast<u32>(kk) : 0;
       const u32 P = Pq[u];
@@ -1287,16 +1288,19 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
       const u32 nbr_in = wave::shfl_up1(P);
       const bool first = (bi == 0 && lane == 0);
       const u32 nbr = lane > 0 ? nbr_in : carry_pos;
-      u64 lo_key = 0, hi_key = 0;  // see detect_lef_bar
+      // see detect_lef_bar; 32-bit keys: positions lie below 2^32 - 2 (the host rejects longer
+      // intervals), and a reach beyond that is as good as 2^32 - 2
+      u32 lo_key = 0, hi_key = 0;
       if (bnd) {
         if (!FWD) {
           const u32 reach = P - M;
           lo_key = first ? reach : umax(reach, nbr);
           hi_key = P;
         } else {
-          const u64 reach = static_cast<u64>(P) + M;
-          lo_key = static_cast<u64>(P) + 1;
-          hi_key = (first ? reach : umin64(reach, nbr)) + 1;
+          const u32 sum = P + M;
+          const u32 reach = (sum < P || sum > 0xFFFFFFFEu) ? 0xFFFFFFFEu : sum;
+          lo_key = P + 1;
+          hi_key = (first ? reach : umin(reach, nbr)) + 1;
         }
       }
       const u64 bm = wave::ballot(bnd);
@@ -1305,8 +1309,8 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
       const u32 l_first = static_cast<u32>(wave::ctz64(bm));
       const u32 l_last = static_cast<u32>(63 - wave::clz64(bm));
       // keys the batch spans (lanes hold ascending positions for rev, descending for fwd)
-      const u64 need_lo = wave::bcast(lo_key, FWD ? l_last : l_first);
-      const u64 need_hi = wave::bcast(hi_key, FWD ? l_first : l_last);
+      const u32 need_lo = wave::bcast(lo_key, FWD ? l_last : l_first);
+      const u32 need_hi = wave::bcast(hi_key, FWD ? l_first : l_last);
       if (need_lo < lo_cover || need_hi > hi_cover) {
         // Move the window along the list to where this batch starts (one coalesced load of
         // positions and indices).  Entries the window has already passed are dropped by counting;
@@ -1315,7 +1319,7 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
         for (;;) {
           if (staged) {
             // window entries before the batch (rev: below need_lo; fwd: below need_hi)
-            const u64 key = FWD ? need_hi : need_lo;
+            const u32 key = FWD ? need_hi : need_lo;
             u32 below = 0;
 #pragma unroll
             for (u32 t = 0; t < BAR_WIN / 64; ++t) {
@@ -1343,8 +1347,8 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
             const u32 edge_lo = g0 > 0 ? hpos[g0 - 1] : 0;
             const u32 edge_hi = g1 < nh ? hpos[g1] : 0;
             stage_stalling_window_call((MODLE_LDS u32*)cp, (MODLE_LDS u32*)ci, hpos + g0, hidx + g0, cnt);
-            lo_cover = g0 > 0 ? static_cast<u64>(wave::uniform(edge_lo)) + 1 : 0;
-            hi_cover = g1 < nh ? static_cast<u64>(wave::uniform(edge_hi)) : ~u64(0);
+            lo_cover = g0 > 0 ? wave::uniform(edge_lo) + 1 : 0;
+            hi_cover = g1 < nh ? wave::uniform(edge_hi) : 0xFFFFFFFFu;
           }
           wave::sync_lds();
           staged = true;
@@ -1889,8 +1893,8 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
   u32 n_list = 0;
   // rev: followers i = max(1, n5) .. n-1 ascending, blocker = rank i-1
   // fwd: followers i-1 for i = (n - min(n3, n3-1) - 1) .. 1 descending, blocker = rank i
-  const i64 f_first = FWD ? static_cast<i64>(bc.n3 == 0 ? n - 1 : n - bc.n3) - 1
-                          : static_cast<i64>(umax(1u, bc.n5));
+  const i32 f_first = FWD ? static_cast<i32>(bc.n3 == 0 ? n - 1 : n - bc.n3) - 1
+                          : static_cast<i32>(umax(1u, bc.n5));
   // every rank is visited in direction order (so that every LEF-BAR move gets corrected); only
   // ranks from f_first on (in visiting order) can be followers
   u32 carry_pos = 0, carry_move = 0, carry_coll = 0, carry_id = 0;
@@ -1903,9 +1907,10 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 bi = bg + u;
-      const i64 kk = FWD ? static_cast<i64>(n) - 1 - static_cast<i64>(bi) * 64 - lane
-                         : static_cast<i64>(bi) * 64 + lane;
-      const bool act = kk >= 0 && kk < static_cast<i64>(n);
+      // (ranks stay far below 2^31: 32-bit index arithmetic)
+      const i32 kk = FWD ? static_cast<i32>(n) - 1 - static_cast<i32>(bi * 64 + lane)
+                         : static_cast<i32>(bi * 64 + lane);
+      const bool act = kk >= 0 && static_cast<u32>(kk) < n;
       const u32 k = act ? static_cast<u32>(kk) : 0;
       r.P[u] = act ? pos[k] : 0;
       r.I[u] = act ? ids[k] : 0;
@@ -1928,9 +1933,10 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
     for (u32 u = 0; u < UX; ++u) {
       const u32 bi = bg + u;
       if (bi >= nbatch) break;
-      const i64 kk = FWD ? static_cast<i64>(n) - 1 - static_cast<i64>(bi) * 64 - lane
-                         : static_cast<i64>(bi) * 64 + lane;
-      const bool act = kk >= 0 && kk < static_cast<i64>(n);
+      // (ranks stay far below 2^31: 32-bit index arithmetic)
+      const i32 kk = FWD ? static_cast<i32>(n) - 1 - static_cast<i32>(bi * 64 + lane)
+                         : static_cast<i32>(bi * 64 + lane);
+      const bool act = kk >= 0 && static_cast<u32>(kk) < n;
       const u32 k = act ? static_cast<u32>(kk) : 0;
       const u32 P = Pq[u], id = Iq[u], M0 = Mq[u], C0 = Cq[u];
       u32 M = M0, C = C0;
