@@ -654,6 +654,8 @@ MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp)
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
   const u64 start = c.iv->start;
+  // landing positions minus ranks fit 32 bits on every real chromosome: scans at half the cost
+  const bool narrow = wave::uniform(c.iv->end) < 0x7F000000u;
   const u32* mv_in = ws.r_move;
   u32* mv_out = ws.tmp[0];
   const u32 nbatch = (n + 63) / 64;
@@ -696,7 +698,8 @@ MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp)
     const bool ok_next_in = wave::shfl_up1(okself);
     const bool ok_next = lane > 0 ? ok_next_in : carry_ok;
     const bool link = okself && ok_next;
-    const SegScan sc = wave_prefix_segscan<false>(SegScan{d, link});
+    const SegScan sc = narrow ? wave_prefix_segscan32<false>(static_cast<i32>(d), link)
+                              : wave_prefix_segscan<false>(SegScan{d, link});
     i64 val = sc.val;
     if (sc.cont) val = imin64(val, carry_d);
     u32 Mnew = M;
@@ -746,6 +749,7 @@ MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp)
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
   const u64 last = static_cast<u64>(c.iv->end) - 1;
+  const bool narrow = wave::uniform(c.iv->end) < 0x7F000000u;  // see adjust_moves_rev
   const u32* mv_in = ws.f_move;
   u32* mv_out = ws.tmp[0];
   const u32 nbatch = (n + 63) / 64;
@@ -785,7 +789,8 @@ MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp)
     const bool ok_prev_in = wave::shfl_up1(okself);
     const bool ok_prev = lane > 0 ? ok_prev_in : carry_ok;
     const bool link = okself && ok_prev;  // link between k-1 and k
-    const SegScan sc = wave_prefix_segscan<true>(SegScan{d, link});
+    const SegScan sc = narrow ? wave_prefix_segscan32<true>(static_cast<i32>(d), link)
+                              : wave_prefix_segscan<true>(SegScan{d, link});
     i64 val = sc.val;
     if (sc.cont) val = imax64(val, carry_d);
     u32 Mnew = M;

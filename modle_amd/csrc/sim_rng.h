@@ -92,6 +92,32 @@ MODLE_DEV SegScan wave_prefix_segscan(SegScan x) {
   return out;
 }
 
+// The same on 32-bit values (half the lane moves and no 64-bit compare / select); the callers
+// use it when every value of the pass fits (positions below 2^31).
+template <bool MAX>
+MODLE_DEV SegScan wave_prefix_segscan32(i32 value, bool cont) {
+  u32 v = static_cast<u32>(value);
+  u32 ct = cont ? 1u : 0u;
+  const u32 neutral = MAX ? 0x80000000u : 0x7FFFFFFFu;
+#define MODLE_STEP(S)                                                          \
+  {                                                                            \
+    const u32 bv = wave::scan_move<S>(v, neutral);                             \
+    const u32 bct = wave::scan_move<S>(ct, 1u);                                \
+    const i32 a = static_cast<i32>(v), b = static_cast<i32>(bv);               \
+    const i32 r = MAX ? (a > b ? a : b) : (a < b ? a : b);                     \
+    if (ct != 0) {                                                             \
+      v = static_cast<u32>(r);                                                 \
+      ct = bct;                                                                \
+    }                                                                          \
+  }
+  MODLE_SCAN_STEPS(MODLE_STEP)
+#undef MODLE_STEP
+  SegScan out;
+  out.val = static_cast<i64>(static_cast<i32>(v));
+  out.cont = ct != 0;
+  return out;
+}
+
 constexpr f64 TWO64 = 18446744073709551616.0;
 constexpr f64 TWO_M64 = 5.42101086242752217e-20;
 constexpr f64 TWO_M56 = 1.387778780781445675529539585113525390625e-17;

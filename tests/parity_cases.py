@@ -44,12 +44,29 @@ CASES = {
                                  cfg=dict(num_cells=16, target_contact_density=-1.0,
                                           target_simulation_epochs=40, skip_burnin=1,
                                           contact_sampling_strategy=3)),
+    # a 4 Mb window that ends 10 Mb below the 32-bit position limit of the device layout, on a
+    # chromosome longer than any real one: positions above 2^31 (the 64-bit scans of the move
+    # adjustment, saturating key arithmetic in LEF-BAR detection)
+    "window_near_position_limit": dict(size=4_290_000_000, barriers=True, window=(4_280_000_000, 4_284_000_000),
+                                       cfg=dict(num_cells=64, diagonal_width=1_000_000)),
 }
 
 
 def build_case(name):
     spec = CASES[name]
     cfg = api.make_config(**spec["cfg"])
+    if "window" in spec:
+        # barriers only where the window is (a genome-scale barrier set is not needed)
+        start, end = spec["window"]
+        local = synthetic.synthetic_chromosome("chrT", end - start, with_barriers=spec["barriers"])
+        chrom = dict(name="chrT", size=spec["size"], start=start, end=end,
+                     bar_pos=local["bar_pos"] + np.uint64(start), bar_dir=local["bar_dir"],
+                     bar_occupancy=local["bar_occupancy"])
+        stp_active, stp_inactive = api.barrier_stps(cfg, chrom["bar_occupancy"])
+        tasks = api.make_tasks(cfg, chrom["name"], chrom["size"], chrom["start"], chrom["end"])
+        nrows, ncols = api.matrix_shape(cfg, end - start)
+        return dict(cfg=cfg, chrom=chrom, stp_active=stp_active, stp_inactive=stp_inactive,
+                    tasks=tasks, nrows=nrows, ncols=ncols)
     chrom = synthetic.synthetic_chromosome("chrT", spec["size"], with_barriers=spec["barriers"])
     stp_active, stp_inactive = api.barrier_stps(cfg, chrom["bar_occupancy"])
     tasks = api.make_tasks(cfg, chrom["name"], chrom["size"], chrom["start"], chrom["end"])
