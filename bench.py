@@ -118,6 +118,11 @@ def cpu_baseline(cfg, genome, unit, sample_cells):
 
 def main():
     args = parse_args()
+    # stdout carries exactly one line, the JSON result: everything libraries print there while
+    # the job runs (RCCL's version banner, for one) goes to stderr instead
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
 
@@ -264,7 +269,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, genome, unit, args.cpu_sample_cells)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     sim.close()
     if use_dist:
         import torch.distributed as dist
