@@ -86,6 +86,9 @@ MODLE_DEV_NOINLINE void phase_bind(Cell& c, u32 epoch_now) {
   const u32 lane = wave::lane();
   const u64 range = static_cast<u64>(iv.end) - 1 - iv.start;
   const u64 bucket = range != 0 ? uniform_int_bucket(range) : 1;
+  // bucket >= 2^32 here (range < 2^32), so quotients stay below 2^32 + 1: see udiv_by_uniform
+  const bool fast_div = bucket <= (u64(1) << 62) && bucket >= (u64(1) << 24);
+  const f64 inv_bucket = 1.0 / static_cast<f64>(bucket);
   constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
   struct LefRegs {
     u32 E[UX], R[UX], F[UX];
@@ -120,7 +123,8 @@ MODLE_DEV_NOINLINE void phase_bind(Cell& c, u32 epoch_now) {
       const u32 cnt = static_cast<u32>(wave::popc64(mask));
       rng_ensure(c.g, cnt);
       const u32 k = static_cast<u32>(wave::popc64(mask & lanemask_lt(lane)));
-      const u64 r = rng_peek(c.g, c.g.pos + k) / bucket;
+      const u64 raw = rng_peek(c.g, c.g.pos + k);
+      const u64 r = fast_div ? udiv_by_uniform(raw, bucket, inv_bucket) : raw / bucket;
       if (wave::any(unb && r > range)) {
         // a draw was rejected (p ~ range / 2^64): replay the batch sequentially
         u64 m = mask;

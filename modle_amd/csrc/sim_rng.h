@@ -263,6 +263,21 @@ MODLE_DEV u64 uniform_int_bucket(u64 range) {
   if (~u64(0) % (range + 1) == range) ++bucket;
   return bucket;
 }
+// floor(raw / d) for a wave-uniform divisor, without the (long) 64-bit division sequence: a
+// double-precision product gives the quotient to within one, the remainder tells which way.
+// `inv` = 1.0 / (f64)d.  Exact while d <= 2^62 and the quotient stays below 2^40 (relative error
+// of the product < 2^-50), which holds for position draws: d = bucket >= 2^32.
+MODLE_DEV u64 udiv_by_uniform(u64 raw, u64 d, f64 inv) {
+  u64 q = static_cast<u64>(static_cast<f64>(raw) * inv);
+  const u64 rem = raw - q * d;  // modulo 2^64
+  if (static_cast<i64>(rem) < 0) {
+    --q;  // candidate one too large: rem in [-d, 0)
+  } else if (rem >= d) {
+    ++q;  // one too small: rem in [d, 2 d)
+  }
+  return q;
+}
+
 // uniform_int_distribution<u64>{0, range}, range != 0 and != 2^64-1
 MODLE_DEV u64 uniform_int_exact(Rng& g, u64 range, u64 bucket) {
   for (;;) {

@@ -116,3 +116,23 @@ def test_no_cpu_fallback_without_gpu():
         pytest.skip("a GPU is present")
     with pytest.raises(api.ModleHipError, match="no CPU fallback"):
         api.Simulator(api.make_config())
+
+
+def test_device_division_by_a_uniform_bucket_is_exact():
+    """phase_bind divides the raw PRNG output by the (wave-uniform) bucket of uniform_int with a
+    double-precision product and a remainder fix-up instead of a 64-bit division (sim_rng.h:
+    udiv_by_uniform); the quotient must be the integer quotient for every input, including the
+    multiples of the bucket and their neighbours."""
+    import ctypes as C
+
+    from phase_backend import emu_lib
+
+    lib = emu_lib()
+    lib.emu_check_udiv_by_uniform.restype = C.c_uint64
+    lib.emu_check_udiv_by_uniform.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    rng = np.random.default_rng(3)
+    n = 400_000
+    raws = rng.integers(0, 2**64, size=n, dtype=np.uint64)
+    ranges = rng.integers(1, 2**32 - 1, size=n, dtype=np.uint64)
+    ranges[:64] = (np.uint64(1) << (np.arange(64, dtype=np.uint64) % np.uint64(32))) + np.arange(64, dtype=np.uint64) // np.uint64(32)
+    assert lib.emu_check_udiv_by_uniform(raws.ctypes.data, ranges.ctypes.data, n) == 0

@@ -148,6 +148,22 @@ extern "C" {
 
 void emu_set_lane_schedule(unsigned schedule) { wave_emu::set_lane_schedule(schedule); }
 
+// the device code's division by a wave-uniform bucket (sim_rng.h: udiv_by_uniform) against the
+// plain quotient, over `n` (raw, range) pairs; returns the number of mismatches
+uint64_t emu_check_udiv_by_uniform(const uint64_t* raws, const uint64_t* ranges, size_t n) {
+  uint64_t bad = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const uint64_t bucket = modle_dev::uniform_int_bucket(ranges[i]);
+    if (bucket > (uint64_t(1) << 62) || bucket < (uint64_t(1) << 24)) continue;
+    const double inv = 1.0 / static_cast<double>(bucket);
+    for (uint64_t raw : {raws[i], raws[i] / bucket * bucket, raws[i] / bucket * bucket + (bucket - 1),
+                         uint64_t(0), ~uint64_t(0)}) {
+      bad += modle_dev::udiv_by_uniform(raw, bucket, inv) != raw / bucket;
+    }
+  }
+  return bad;
+}
+
 int emu_simulate_interval(const modle_hip_config* cfg, uint64_t start, uint64_t end,
                           const uint64_t* bar_pos, const uint8_t* bar_dir,
                           const double* bar_stp_active, const double* bar_stp_inactive,
