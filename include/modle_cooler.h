@@ -40,8 +40,10 @@ int modle_cool_create(const char* path, int force_overwrite, const char* const* 
 /* Appends the non-zero pixels of one interval's band matrix (layout of
  * modle_hip_interval_outputs: cell (row, col), row <= col, col - row < nrows, at
  * band[col * nrows + (col - row)]), visited row by row like the reference.  `offset_bp` is the
- * interval's start within the chromosome.  Chromosomes must be appended in ascending chrom_id
- * order, at most once each (pixels stay sorted, like the reference's genome-order writes). */
+ * interval's start within the chromosome.  Intervals must be appended in genome order (ascending
+ * chrom_id, ascending non-overlapping bin ranges within a chromosome): a chromosome may
+ * contribute several disjoint intervals, as with the reference's --genomic-intervals, and the
+ * pixels stay sorted like the reference's genome-order writes. */
 int modle_cool_append_matrix(modle_cool_file* f, size_t chrom_id, uint64_t offset_bp,
                              const uint32_t* band, uint64_t nrows, uint64_t ncols, char* err,
                              size_t errlen);

@@ -27,6 +27,7 @@ extern "C" {
 #define MODLE_HIP_ERR_DEVICE (-2)
 #define MODLE_HIP_ERR_UNSUPPORTED (-3)
 #define MODLE_HIP_ERR_STATE (-4)
+#define MODLE_HIP_ERR_CANCELLED (-5)
 
 /* contact_sampling_strategy flags (reference: simulation_config.hpp:33-38) */
 #define MODLE_HIP_CS_NOISIFY 1u
@@ -105,7 +106,7 @@ typedef struct modle_hip_cell_result {
   uint64_t burnin_epochs;
   uint64_t num_contacts;
   uint64_t raws_consumed;   /* 64-bit PRNG outputs drawn by the cell */
-  uint64_t prng_final[4];   /* PRNG state after the last draw */
+  uint64_t prng_final[4];   /* xoshiro256++ state after the last draw (State::rand_eng at return) */
   uint64_t sum_active_lefs; /* sum over simulated epochs of the number of active LEFs */
   uint64_t sampling_events; /* contact-sampling events executed */
   uint64_t sim_epochs;      /* epochs whose move / collision phase ran */
@@ -142,6 +143,13 @@ int modle_hip_make_tasks(const modle_hip_config* c, const char* chrom_name, uint
  * (reference: src/libmodle/internal/extrusion_barriers_impl.hpp:106-128) */
 double modle_hip_stp_active_from_occupancy(double stp_inactive, double occupancy);
 double modle_hip_occupancy_from_stp(double stp_active, double stp_inactive);
+/* ExtrusionBarriers::sort (reference: src/libmodle/internal/extrusion_barriers.cpp:237-257, run
+ * for every task by State::operator=, simulation.cpp:741-761): sorts the four parallel arrays by
+ * position, in place.  Barriers at the same position keep their input order (the reference
+ * leaves that order to an unstable sort).  modle_hip_add_interval applies it itself; it is
+ * exported for callers that need to know which barrier a collision word's index refers to. */
+void modle_hip_sort_barriers(uint64_t* bar_pos, uint8_t* bar_dir, double* bar_stp_active,
+                             double* bar_stp_inactive, size_t n_barriers);
 
 /* ---------------------------------------------------------------------------------------------
  * Device path.
@@ -152,8 +160,8 @@ modle_hip_handle* modle_hip_create(const modle_hip_config* c, int device, char* 
 void modle_hip_destroy(modle_hip_handle* h);
 
 /* Registers one genomic interval (reference: GenomicInterval, genome.hpp) with its extrusion
- * barriers sorted by position (reference: State::operator=, simulation.cpp:741-761 sorts them
- * per task; here the caller sorts once).  `d_contacts` (uint32[nrows*ncols+1], band layout of
+ * barriers in any order: they are sorted by position here, once per interval (the reference
+ * sorts them per task, State::operator=, simulation.cpp:741-761; modle_hip_sort_barriers).  `d_contacts` (uint32[nrows*ncols+1], band layout of
  * contact_matrix_internal_impl.hpp:19-42) and `d_occupancy` (uint64[ncols]) are caller-owned
  * DEVICE buffers that the kernel accumulates into; pass NULL to let the library own them.
  * Returns the interval id (>= 0) or a negative error. */
@@ -172,6 +180,12 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
 /* Waits for the launch and collects per-task results (the counterpart of _ctx.shutdown(),
  * scheduler_simulate.cpp:162). */
 int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen);
+/* Asks a launch in flight to stop (the counterpart of the `_ctx` flag the reference polls once
+ * per epoch, simulation.cpp:933): every cell leaves at the top of its next epoch, cells that
+ * have not started are skipped, and modle_hip_wait returns MODLE_HIP_ERR_CANCELLED.  Contacts
+ * registered before the stop stay in the matrices.  May be called from another host thread than
+ * the one that waits.  No-op when nothing is in flight. */
+int modle_hip_cancel(modle_hip_handle* h, char* err, size_t errlen);
 /* Duration of the last simulation kernel, measured with HIP events on the launch stream. */
 int modle_hip_last_kernel_ms(modle_hip_handle* h, float* ms);
 /* Results of the tasks submitted for `interval_id`, in submission order. */

@@ -22,7 +22,8 @@ EXPORTS = [
     "modle_hip_destroy", "modle_hip_add_interval", "modle_hip_submit_tasks", "modle_hip_launch",
     "modle_hip_wait", "modle_hip_last_kernel_ms", "modle_hip_get_results",
     "modle_hip_interval_outputs", "modle_hip_copy_outputs", "modle_hip_reset",
-    "modle_hip_simulate_interval", "modle_hip_test_phases",
+    "modle_hip_simulate_interval", "modle_hip_test_phases", "modle_hip_sort_barriers",
+    "modle_hip_cancel",
 ]
 
 u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
@@ -66,6 +67,9 @@ def lib():
     L.modle_hip_stp_active_from_occupancy.restype = C.c_double
     L.modle_hip_occupancy_from_stp.argtypes = [C.c_double, C.c_double]
     L.modle_hip_occupancy_from_stp.restype = C.c_double
+    L.modle_hip_sort_barriers.argtypes = [u64p, u8p, f64p, f64p, C.c_size_t]
+    L.modle_hip_sort_barriers.restype = None
+    L.modle_hip_cancel.argtypes = [C.c_void_p] + err
     L.modle_hip_create.argtypes = [P(Config), C.c_int] + err
     L.modle_hip_create.restype = C.c_void_p
     L.modle_hip_destroy.argtypes = [C.c_void_p]

@@ -105,6 +105,16 @@ def barrier_stps(cfg, occupancy):
     return stp_active, stp_inactive
 
 
+def sort_barriers(bar_pos, bar_dir, stp_active, stp_inactive):
+    """ExtrusionBarriers::sort: the four arrays ordered by position (copies)."""
+    pos = np.array(bar_pos, dtype=np.uint64)
+    dirs = np.array(bar_dir, dtype=np.uint8)
+    sa = np.array(stp_active, dtype=np.float64)
+    si = np.array(stp_inactive, dtype=np.float64)
+    lib().modle_hip_sort_barriers(pos, dirs, sa, si, len(pos))
+    return pos, dirs, sa, si
+
+
 def slice_tasks(tasks, lo, hi):
     n = hi - lo
     out = (Task * n)()
@@ -169,6 +179,10 @@ class Simulator:
     def wait(self):
         err = _errbuf()
         _check(self._L.modle_hip_wait(self._h, err, len(err)), err)
+
+    def cancel(self):
+        err = _errbuf()
+        _check(self._L.modle_hip_cancel(self._h, err, len(err)), err)
 
     def kernel_ms(self):
         ms = C.c_float(0)

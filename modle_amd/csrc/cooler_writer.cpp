@@ -203,12 +203,15 @@ extern "C" int modle_cool_append_matrix(modle_cool_file* f, size_t chrom_id, uin
     set_err(err, errlen, "modle_cool_append_matrix: invalid argument");
     return MODLE_COOL_ERR_ARG;
   }
-  if (chrom_id < f->next_chrom) {
-    set_err(err, errlen, "modle_cool_append_matrix: chromosomes must be appended in ascending order, once each");
-    return MODLE_COOL_ERR_ARG;
-  }
   const int64_t chrom_first = f->chrom_offset[chrom_id], chrom_last = f->chrom_offset[chrom_id + 1];
   const int64_t bin_offset = chrom_first + static_cast<int64_t>(offset_bp / f->bin_size);
+  // Intervals arrive in genome order; a chromosome may contribute several disjoint intervals
+  // (--genomic-intervals, reference: genome.cpp import_genomic_intervals), each with its own
+  // offset.  What keeps the pixel table sorted is the order of the bins, not of the chromosomes.
+  if (chrom_id + 1 < f->next_chrom || bin_offset < f->next_bin1) {
+    set_err(err, errlen, "modle_cool_append_matrix: intervals must be appended in genome order and must not overlap");
+    return MODLE_COOL_ERR_ARG;
+  }
   if (bin_offset + static_cast<int64_t>(ncols) > chrom_last) {
     set_err(err, errlen, "modle_cool_append_matrix: the matrix does not fit the chromosome's bins");
     return MODLE_COOL_ERR_RANGE;

@@ -11,6 +11,8 @@
 //   src/libmodle/cpu/simulation.cpp:1076-1090                      compute_num_lefs & co.
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
+#include <vector>
 #include <cstdio>
 #include <cstring>
 #include <limits>
@@ -325,6 +327,28 @@ int modle_hip_make_tasks(const modle_hip_config* c, const char* chrom_name, uint
     modle_host::xoshiro_jump(state);
   }
   return MODLE_HIP_OK;
+}
+
+void modle_hip_sort_barriers(uint64_t* bar_pos, uint8_t* bar_dir, double* bar_stp_active,
+                             double* bar_stp_inactive, size_t n_barriers) {
+  if (n_barriers < 2 || bar_pos == nullptr) return;
+  bool sorted = true;
+  for (size_t i = 1; i < n_barriers && sorted; ++i) sorted = bar_pos[i - 1] <= bar_pos[i];
+  if (sorted) return;
+  std::vector<size_t> idx(n_barriers);
+  for (size_t i = 0; i < n_barriers; ++i) idx[i] = i;
+  std::stable_sort(idx.begin(), idx.end(),
+                   [&](size_t a, size_t b) { return bar_pos[a] < bar_pos[b]; });
+  const auto permute = [&](auto* v) {
+    if (v == nullptr) return;
+    std::vector<std::remove_reference_t<decltype(*v)>> tmp(n_barriers);
+    for (size_t i = 0; i < n_barriers; ++i) tmp[i] = v[idx[i]];
+    std::copy(tmp.begin(), tmp.end(), v);
+  };
+  permute(bar_pos);
+  permute(bar_dir);
+  permute(bar_stp_active);
+  permute(bar_stp_inactive);
 }
 
 }  // extern "C"

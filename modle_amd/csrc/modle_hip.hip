@@ -53,6 +53,7 @@ struct SimArgs {
   CellResult* results;
   u32* status;        // one word per task
   u32* task_counter;
+  const u32* abort_flag;  // raised by modle_hip_cancel while the kernel runs
   u64* trace;  // diagnostic per-epoch trace of task 0 (MODLE_HIP_TRACE) or nullptr
   u32 trace_cap;
   u32 pad2_;
@@ -110,6 +111,7 @@ struct BlockLds {
   f64 zig[kZigWords];
   u64 ring[kWavesPerBlock][RNG_RING];
   u64 rng_state[kWavesPerBlock][4 * 64];
+  u64 rng_snap[kWavesPerBlock][8];
   u64 sort_keys[kWavesPerBlock][SORT_LDS_CAP];
   u32 stage[kWavesPerBlock][STAGE_CAP];
 };
@@ -118,6 +120,8 @@ __device__ __forceinline__ WaveLds make_wave_lds(BlockLds& s, int wave_in_block)
   WaveLds l;
   l.ring = s.ring[wave_in_block];
   l.rng_state = s.rng_state[wave_in_block];
+  l.rng_snap = s.rng_snap[wave_in_block];
+  l.abort_flag = nullptr;
   l.jump_table = s.jump;
   l.zig_norm_x = s.zig;
   l.zig_norm_y = s.zig + 129;
@@ -159,10 +163,19 @@ __global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs
     if (leader == 0) t = atomicAdd(wave::as_global(a.task_counter), 1u);
     t = wave::bcast(t, 0);  // scalar from here on: the queue loop is a scalar loop
     if (t >= a.n_tasks) break;  // every wave leaves once the queue is empty
+    if (wave::uniform(wave::load_agent_u32(wave::as_global(a.abort_flag))) != 0) {
+      // cancelled: tasks that never started are reported as such (all lanes store the same word)
+      CellResult none;
+      __builtin_memset(&none, 0, sizeof(none));
+      wave::as_global(a.results)[t] = none;
+      wave::as_global(a.status)[t] = ERR_CANCELLED;
+      continue;
+    }
     const Task task = wave::as_global(a.tasks)[t];
     CellResult res;
     WaveLds lds_t = lds;
     lds_t.phase_ticks = wave::as_global(a.phase_ticks);
+    lds_t.abort_flag = wave::as_global(a.abort_flag);
     if (t == 0 && a.trace != nullptr) {
       lds_t.trace = a.trace;
       lds_t.trace_cap = a.trace_cap;
@@ -280,6 +293,12 @@ struct modle_hip_handle {
   DevBuf<CellResult> d_results;
   DevBuf<u32> d_status;
   DevBuf<u32> d_counter;
+  DevBuf<u32> d_abort;
+  hipStream_t cancel_stream = nullptr;  // non-blocking: raises the abort word beside the kernel
+  bool cancelled = false;
+  void* trace_host = nullptr;           // MODLE_HIP_TRACE_SHM mapping, registered once per handle
+  size_t trace_bytes = 0;
+  u64* trace_dev = nullptr;
   DevBuf<char> d_workspace;
   DevBuf<u64> d_phase_out;
   DevBuf<u64> d_trace;
@@ -336,6 +355,8 @@ modle_hip_handle* modle_hip_create(const modle_hip_config* c, int device, char* 
   zig.insert(zig.end(), ZIG_EXP_Y, ZIG_EXP_Y + 257);
   if (h->d_jump.ensure(jump.size()) != hipSuccess || h->d_zig.ensure(zig.size()) != hipSuccess ||
       h->d_counter.ensure(1) != hipSuccess || h->d_phase_out.ensure(2) != hipSuccess ||
+      h->d_abort.ensure(1) != hipSuccess || hipMemset(h->d_abort.p, 0, 4) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->cancel_stream, hipStreamNonBlocking) != hipSuccess ||
       hipMemcpy(h->d_jump.p, jump.data(), jump.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(h->d_zig.p, zig.data(), zig.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
       hipEventCreate(&h->ev_start) != hipSuccess || hipEventCreate(&h->ev_stop) != hipSuccess) {
@@ -351,6 +372,11 @@ void modle_hip_destroy(modle_hip_handle* h) {
   if (h->in_flight) (void)hipStreamSynchronize(h->stream);
   if (h->ev_start != nullptr) (void)hipEventDestroy(h->ev_start);
   if (h->ev_stop != nullptr) (void)hipEventDestroy(h->ev_stop);
+  if (h->cancel_stream != nullptr) (void)hipStreamDestroy(h->cancel_stream);
+  if (h->trace_host != nullptr) {
+    (void)hipHostUnregister(h->trace_host);
+    ::munmap(h->trace_host, h->trace_bytes);
+  }
   delete h;
 }
 
@@ -388,23 +414,30 @@ int modle_hip_add_interval(modle_hip_handle* h, uint64_t start, uint64_t end,
   rec->end = end;
   rec->n_barriers = n_barriers;
   modle_hip_matrix_shape(&h->cfg, end - start, &rec->nrows, &rec->ncols);
+  // The reference sorts the barriers of every task by position (State::operator=,
+  // simulation.cpp:741-761 -> ExtrusionBarriers::sort, extrusion_barriers.cpp:237-257); here
+  // that happens once per interval, so callers may pass them in BED order.  Barrier indices in
+  // collision words refer to the sorted order.
+  std::vector<uint64_t> spos(bar_pos, bar_pos + n_barriers);
+  std::vector<u8> dir(bar_dir, bar_dir + n_barriers);
+  std::vector<f64> sa(bar_stp_active, bar_stp_active + n_barriers);
+  std::vector<f64> si(bar_stp_inactive, bar_stp_inactive + n_barriers);
+  modle_hip_sort_barriers(spos.data(), dir.data(), sa.data(), si.data(), n_barriers);
   std::vector<u32> pos(n_barriers);
-  std::vector<u8> dir(n_barriers);
   std::vector<f64> stp(3 * n_barriers);
   for (size_t i = 0; i < n_barriers; ++i) {
-    if (bar_pos[i] < start || bar_pos[i] >= end || (i > 0 && bar_pos[i] < bar_pos[i - 1])) {
-      set_err(err, errlen, "barriers must be sorted by position and lie inside the interval");
+    if (spos[i] < start || spos[i] >= end) {
+      set_err(err, errlen, "barriers must lie inside the interval");
       return MODLE_HIP_ERR_ARG;
     }
-    if (bar_dir[i] != MODLE_HIP_DIR_FWD && bar_dir[i] != MODLE_HIP_DIR_REV) {
+    if (dir[i] != MODLE_HIP_DIR_FWD && dir[i] != MODLE_HIP_DIR_REV) {
       set_err(err, errlen, "barrier direction must be MODLE_HIP_DIR_FWD or MODLE_HIP_DIR_REV");
       return MODLE_HIP_ERR_ARG;
     }
-    pos[i] = static_cast<u32>(bar_pos[i]);
-    dir[i] = bar_dir[i];
-    stp[i] = bar_stp_active[i];
-    stp[n_barriers + i] = bar_stp_inactive[i];
-    stp[2 * n_barriers + i] = modle_hip_occupancy_from_stp(bar_stp_active[i], bar_stp_inactive[i]);
+    pos[i] = static_cast<u32>(spos[i]);
+    stp[i] = sa[i];
+    stp[n_barriers + i] = si[i];
+    stp[2 * n_barriers + i] = modle_hip_occupancy_from_stp(sa[i], si[i]);
   }
   HIP_TRY(rec->bar_pos.ensure(n_barriers));
   HIP_TRY(rec->bar_dir.ensure(n_barriers));
@@ -470,14 +503,15 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
   }
   HIP_TRY(hipSetDevice(h->device));
   h->stream = static_cast<hipStream_t>(stream);
-  // gather pending tasks, largest chromosomes first (long tasks must not start last)
+  // Gather pending tasks, largest chromosomes first (long tasks must not start last).  Nothing
+  // of the handle's bookkeeping changes until the kernel has been enqueued: a launch that fails
+  // on the way leaves every task pending and every result slot as it was.
   std::vector<Task> tasks;
-  h->launch_map.clear();
+  std::vector<std::pair<int, size_t>> launch_map;
   u32 max_lefs = 1, max_barriers = 0;
   for (size_t iv = 0; iv < h->intervals.size(); ++iv) {
-    IntervalRec& rec = *h->intervals[iv];
+    const IntervalRec& rec = *h->intervals[iv];
     const size_t base = rec.results.size();
-    rec.results.resize(base + rec.pending.size());
     for (size_t k = 0; k < rec.pending.size(); ++k) {
       const modle_hip_task& t = rec.pending[k];
       Task d;
@@ -489,14 +523,16 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
       d.contacts_per_epoch = modle_hip_compute_contacts_per_epoch(&h->cfg, t.num_lefs);
       std::memcpy(d.prng, t.prng, sizeof(d.prng));
       tasks.push_back(d);
-      h->launch_map.emplace_back(static_cast<int>(iv), base + k);
+      launch_map.emplace_back(static_cast<int>(iv), base + k);
       max_lefs = std::max(max_lefs, d.num_lefs);
     }
     if (!rec.pending.empty()) max_barriers = std::max<u32>(max_barriers, static_cast<u32>(rec.n_barriers));
-    rec.pending.clear();
   }
-  h->n_launched = tasks.size();
-  if (tasks.empty()) return MODLE_HIP_OK;
+  if (tasks.empty()) {
+    h->n_launched = 0;
+    h->launch_map.clear();
+    return MODLE_HIP_OK;
+  }
   std::vector<size_t> order(tasks.size());
   std::iota(order.begin(), order.end(), size_t(0));
   std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
@@ -510,9 +546,8 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
   std::vector<std::pair<int, size_t>> sorted_map(tasks.size());
   for (size_t i = 0; i < order.size(); ++i) {
     sorted[i] = tasks[order[i]];
-    sorted_map[i] = h->launch_map[order[i]];
+    sorted_map[i] = launch_map[order[i]];
   }
-  h->launch_map.swap(sorted_map);
 
   std::vector<Interval> ivs(h->intervals.size());
   for (size_t iv = 0; iv < h->intervals.size(); ++iv) {
@@ -551,9 +586,11 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
   HIP_TRY(hipMemcpyAsync(h->d_tasks.p, sorted.data(), sorted.size() * sizeof(Task),
                          hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemsetAsync(h->d_counter.p, 0, 4, h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_abort.p, 0, 4, h->stream));
   HIP_TRY(hipMemsetAsync(h->d_status.p, 0xFF, sorted.size() * 4, h->stream));
   // the source vectors must outlive the async copies
   HIP_TRY(hipStreamSynchronize(h->stream));
+  h->cancelled = false;
 
   SimArgs a;
   a.params = h->params;
@@ -564,24 +601,36 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
   a.results = h->d_results.p;
   a.status = h->d_status.p;
   a.task_counter = h->d_counter.p;
+  a.abort_flag = h->d_abort.p;
   a.trace = nullptr;
   a.trace_cap = 0;
   a.pad2_ = 0;
   if (const char* shm = std::getenv("MODLE_HIP_TRACE_SHM"); shm != nullptr) {
     // diagnostic: the trace of task 0 goes to a file-backed, host-coherent mapping so that it
-    // survives a GPU fault that aborts the process
+    // survives a GPU fault that aborts the process (mapped and registered once per handle)
     constexpr u32 kTraceEpochs = 4096;
     const size_t bytes = static_cast<size_t>(kTraceEpochs) * TRACE_STAGES * TRACE_WORDS_PER_STAGE * 8;
-    const int fd = ::open(shm, O_RDWR | O_CREAT | O_TRUNC, 0644);
-    if (fd >= 0 && ::ftruncate(fd, static_cast<off_t>(bytes)) == 0) {
-      void* hp = ::mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-      ::close(fd);
-      void* dp = nullptr;
-      if (hp != MAP_FAILED && hipHostRegister(hp, bytes, hipHostRegisterMapped) == hipSuccess &&
-          hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
-        a.trace = static_cast<u64*>(dp);
-        a.trace_cap = kTraceEpochs;
+    if (h->trace_host == nullptr) {
+      const int fd = ::open(shm, O_RDWR | O_CREAT | O_TRUNC, 0644);
+      if (fd >= 0 && ::ftruncate(fd, static_cast<off_t>(bytes)) == 0) {
+        void* hp = ::mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        void* dp = nullptr;
+        if (hp != MAP_FAILED) {
+          if (hipHostRegister(hp, bytes, hipHostRegisterMapped) == hipSuccess &&
+              hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+            h->trace_host = hp;
+            h->trace_bytes = bytes;
+            h->trace_dev = static_cast<u64*>(dp);
+          } else {
+            ::munmap(hp, bytes);
+          }
+        }
       }
+      if (fd >= 0) ::close(fd);
+    }
+    if (h->trace_dev != nullptr) {
+      a.trace = h->trace_dev;
+      a.trace_cap = kTraceEpochs;
     }
   }
   a.phase_ticks = nullptr;
@@ -600,7 +649,26 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
   hipLaunchKernelGGL(modle_simulate_cells, dim3(grid), dim3(kThreadsPerBlock), 0, h->stream, a);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
+  // enqueued: commit the bookkeeping
+  for (auto& recp : h->intervals) {
+    IntervalRec& rec = *recp;
+    rec.results.resize(rec.results.size() + rec.pending.size());
+    rec.pending.clear();
+  }
+  h->launch_map.swap(sorted_map);
+  h->n_launched = sorted.size();
   h->in_flight = true;
+  return MODLE_HIP_OK;
+}
+
+int modle_hip_cancel(modle_hip_handle* h, char* err, size_t errlen) {
+  if (h == nullptr) return MODLE_HIP_ERR_ARG;
+  if (!h->in_flight) return MODLE_HIP_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  // every wave reads the word at the top of its next epoch and stops pulling tasks
+  HIP_TRY(hipMemsetAsync(h->d_abort.p, 0x01, 4, h->cancel_stream));
+  HIP_TRY(hipStreamSynchronize(h->cancel_stream));
+  h->cancelled = true;
   return MODLE_HIP_OK;
 }
 
@@ -636,7 +704,12 @@ int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen) {
     const auto [iv, idx] = h->launch_map[i];
     static_assert(sizeof(CellResult) == sizeof(modle_hip_cell_result), "result layouts differ");
     std::memcpy(&h->intervals[static_cast<size_t>(iv)]->results[idx], &res[i], sizeof(CellResult));
-    if (status[i] != 0 && rc == MODLE_HIP_OK) {
+    if (status[i] == ERR_CANCELLED) {
+      if (rc == MODLE_HIP_OK) {
+        set_err(err, errlen, "the launch was cancelled (modle_hip_cancel)");
+        rc = MODLE_HIP_ERR_CANCELLED;
+      }
+    } else if (status[i] != 0 && (rc == MODLE_HIP_OK || rc == MODLE_HIP_ERR_CANCELLED)) {
       set_err(err, errlen,
               "task " + std::to_string(i) + " failed on the device with status " +
                   std::to_string(status[i]) + " (internal capacity exceeded)");
@@ -705,10 +778,36 @@ int modle_hip_simulate_interval(modle_hip_handle* h, uint64_t start, uint64_t en
                                 uint64_t* missed_updates, uint64_t* occupancy,
                                 modle_hip_cell_result* results, char* err, size_t errlen) {
   if (h == nullptr) return MODLE_HIP_ERR_ARG;
+  if (h->in_flight) {
+    set_err(err, errlen, "a launch is in flight");
+    return MODLE_HIP_ERR_STATE;
+  }
+  for (const auto& r : h->intervals) {
+    if (!r->pending.empty()) {
+      // the one-call form launches every pending task of the handle: refuse to mix
+      set_err(err, errlen, "tasks submitted through modle_hip_submit_tasks are still pending");
+      return MODLE_HIP_ERR_STATE;
+    }
+  }
   const int id = modle_hip_add_interval(h, start, end, bar_pos, bar_dir, bar_stp_active,
                                         bar_stp_inactive, n_barriers, nullptr, nullptr, err,
                                         errlen);
   if (id < 0) return id;
+  // the interval registered above (device matrix included: 119 MB for chr1) lives for this call
+  // only; it is the last one of the handle and goes away on every return path
+  struct Release {
+    modle_hip_handle* h;
+    ~Release() {
+      (void)hipSetDevice(h->device);
+      if (h->in_flight) {
+        (void)hipStreamSynchronize(h->stream);
+        h->in_flight = false;
+      }
+      h->intervals.pop_back();
+      h->launch_map.clear();
+      h->n_launched = 0;
+    }
+  } release{h};
   IntervalRec& rec = *h->intervals[static_cast<size_t>(id)];
   if (rec.nrows != nrows || rec.ncols != ncols) {
     set_err(err, errlen, "contact matrix shape does not match bin_size / diagonal_width");

@@ -48,6 +48,7 @@ struct Cell {
 constexpr u32 ERR_LIST_OVERFLOW = 1;
 constexpr u32 ERR_TRIAL_OVERFLOW = 2;
 constexpr u32 ERR_INTERNAL = 3;
+constexpr u32 ERR_CANCELLED = 4;  // the host raised the abort word (reference: _ctx polled per epoch)
 
 template <class T>
 MODLE_DEV void swap_ptr(T*& a, T*& b) {
@@ -2757,6 +2758,7 @@ MODLE_DEV void init_cell(Cell& c, const Params& p, const Interval& iv, const Wor
   c.g.ring = lds.ring;
   c.g.jump = lds.jump_table;
   c.g.state = lds.rng_state;
+  c.g.snap = lds.rng_snap;
   rng_init(c.g, prng);
 }
 
@@ -2824,6 +2826,11 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
     if (p.target_contact_density >= 0) {
       if (num_contacts >= task.num_target_contacts) break;
     } else if (epoch - num_burnin_epochs >= task.num_target_epochs) {
+      break;
+    }
+    // cancellation, checked once per epoch like the reference's `_ctx` (simulation.cpp:933)
+    if (lds.abort_flag != nullptr && wave::uniform(wave::load_agent_u32(lds.abort_flag)) != 0) {
+      status = ERR_CANCELLED;
       break;
     }
     if (!burnin_completed) {
@@ -2912,7 +2919,7 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
   res.burnin_epochs = num_burnin_epochs;
   res.num_contacts = num_contacts;
   res.raws_consumed = c.g.pos;
-  res.prng_final[0] = res.prng_final[1] = res.prng_final[2] = res.prng_final[3] = 0;
+  rng_final_state(c.g, res.prng_final);
   res.sum_active_lefs = sum_active;
   res.sampling_events = events_done;
   res.sim_epochs = sim_epochs;

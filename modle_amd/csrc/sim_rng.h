@@ -131,6 +131,8 @@ struct Rng {
   const u64* jump;     // T^RNG_BLOCK nibble table (LDS)
   u64* state;          // per lane xoshiro state at the start of its chunk of the NEXT block:
                        // word w of lane l at state[w * 64 + l] (LDS)
+  u64* snap;           // generator state at the start of each of the two blocks in the ring: word w
+                       // of the block with parity b at snap[4 * b + w] (LDS)
   u64 gen_end;         // uniform: raws [gen_end - RNG_RING, gen_end) are in the ring
   u64 pos;             // uniform: stream position of the next raw to be consumed
 };
@@ -161,11 +163,20 @@ MODLE_DEV u32 ring_index(u64 p) {
 // nibble table).  A real call: it is reached from every phase that draws, and its registers
 // stay out of the callers' allocation.
 MODLE_DEV_CALL void rng_gen_block_call(MODLE_LDS u64* ring, const MODLE_LDS u64* jump,
-                                       MODLE_LDS u64* state, u32 ring_base) {
+                                       MODLE_LDS u64* state, MODLE_LDS u64* snap, u32 ring_base) {
   const u32 lane = wave::lane();
   u64 a0 = state[0 * 64 + lane], a1 = state[1 * 64 + lane], a2 = state[2 * 64 + lane],
       a3 = state[3 * 64 + lane];
   const u64 w[4] = {a0, a1, a2, a3};
+  if (lane == 0) {
+    // lane 0 sits at the first output of the block: the engine state a sequential generator
+    // would have there (rng_final_state recovers the state at any position inside the ring)
+    MODLE_LDS u64* sn = snap + 4 * (ring_base / RNG_BLOCK);
+    sn[0] = a0;
+    sn[1] = a1;
+    sn[2] = a2;
+    sn[3] = a3;
+  }
   const u32 base = ring_base + RNG_CHUNK * lane;
 #pragma unroll
   for (u32 t = 0; t < RNG_CHUNK; ++t) {
@@ -208,7 +219,7 @@ MODLE_DEV_CALL void rng_gen_block_call(MODLE_LDS u64* ring, const MODLE_LDS u64*
 MODLE_DEV void rng_gen_block(Rng& g) {
   wave::lockstep();  // other lanes may still be reading the block that is about to be replaced
   rng_gen_block_call((MODLE_LDS u64*)g.ring, (const MODLE_LDS u64*)g.jump, (MODLE_LDS u64*)g.state,
-                     ((static_cast<u32>(g.gen_end) / RNG_BLOCK) & 1u) * RNG_BLOCK);
+                     (MODLE_LDS u64*)g.snap, ((static_cast<u32>(g.gen_end) / RNG_BLOCK) & 1u) * RNG_BLOCK);
   g.gen_end += RNG_BLOCK;
   wave::sync_lds();
 }
@@ -228,6 +239,34 @@ MODLE_DEV void rng_init(Rng& g, const u64 state[4]) {
   g.gen_end = 0;
   g.pos = 0;
   wave::sync_lds();
+}
+
+// State of the sequential engine after g.pos outputs (what the reference's PRNG object holds when
+// the cell returns).  The block that contains g.pos is one of the two in the ring (g.pos >
+// g.gen_end - RNG_RING: a block is only generated when a consumer needs outputs beyond
+// gen_end), or the one that has not been generated yet.  Once per cell; uniform.
+MODLE_DEV void rng_final_state(const Rng& g, u64 out[4]) {
+  const u64 q = g.pos / RNG_BLOCK;
+  u64 s0, s1, s2, s3;
+  if (q * RNG_BLOCK == g.gen_end) {
+    // next block: lane 0's chunk starts there
+    s0 = wave::uniform(g.state[0 * 64]);
+    s1 = wave::uniform(g.state[1 * 64]);
+    s2 = wave::uniform(g.state[2 * 64]);
+    s3 = wave::uniform(g.state[3 * 64]);
+  } else {
+    const u32 b = static_cast<u32>(q & 1u);
+    s0 = wave::uniform(g.snap[4 * b + 0]);
+    s1 = wave::uniform(g.snap[4 * b + 1]);
+    s2 = wave::uniform(g.snap[4 * b + 2]);
+    s3 = wave::uniform(g.snap[4 * b + 3]);
+  }
+  const u32 r = static_cast<u32>(g.pos - q * RNG_BLOCK);
+  for (u32 k = 0; k < r; ++k) (void)xo_next(s0, s1, s2, s3);
+  out[0] = s0;
+  out[1] = s1;
+  out[2] = s2;
+  out[3] = s3;
 }
 
 // makes raws [pos, pos + k) readable (k <= RNG_BLOCK); uniform

@@ -145,6 +145,8 @@ struct WaveLds {
   const f64* zig_exp_y;   // 257
   u64* sort_lds;          // SORT_LDS_CAP keys (ranking of newly bound units)
   u32* stage;             // STAGE_CAP words (staged slice of sorted positions)
+  u64* rng_snap;          // 2 x 4 words: generator state at the start of the two blocks in the ring
+  const u32* abort_flag;  // device word polled once per epoch (cancellation) or nullptr
   u64* trace;             // optional per-epoch trace (4 words per epoch) or nullptr
   u32 trace_cap;          // epochs the trace buffer holds
   u64* phase_ticks;       // profiling build: 16 per-phase tick counters (device memory) or nullptr

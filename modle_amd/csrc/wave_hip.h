@@ -166,6 +166,10 @@ MODLE_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // constant-rate (100 MHz) timestamp, for the profiling build
 MODLE_DEV uint64_t clock() { return wall_clock64(); }
 
+// word written by another agent (the host) while the kernel runs: bypasses this CU's L1
+MODLE_DEV uint32_t load_agent_u32(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 MODLE_DEV void atomic_inc_u32(uint32_t* p) { atomicAdd(p, 1u); }
 MODLE_DEV void atomic_add_u64(uint64_t* p, uint64_t v) {
   atomicAdd(reinterpret_cast<unsigned long long*>(p), static_cast<unsigned long long>(v));

@@ -1346,11 +1346,92 @@ static void release_lefs(cell_t* s, int burnin_completed) {
   }
 }
 
+/* ExtrusionBarriers::sort (extrusion_barriers.cpp:237-257): index sort by position, then the
+ * four arrays are permuted.  The reference uses an unstable pdq_sort; equal positions keep their
+ * input order here (a documented choice, like the device's). */
+typedef struct {
+  uint64_t pos;
+  size_t idx;
+} bar_key_t;
+static int bar_key_cmp(const void* a, const void* b) {
+  const bar_key_t *x = (const bar_key_t*)a, *y = (const bar_key_t*)b;
+  if (x->pos != y->pos) return x->pos < y->pos ? -1 : 1;
+  return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+void mo_sort_barriers(size_t nb, uint64_t* pos, uint8_t* dir, double* stp_active,
+                      double* stp_inactive) {
+  if (nb < 2) return;
+  bar_key_t* k = (bar_key_t*)malloc(nb * sizeof(bar_key_t));
+  uint64_t* tp = (uint64_t*)malloc(nb * sizeof(uint64_t));
+  uint8_t* td = (uint8_t*)malloc(nb);
+  double* ta = (double*)malloc(nb * sizeof(double));
+  double* ti = (double*)malloc(nb * sizeof(double));
+  for (size_t i = 0; i < nb; ++i) {
+    k[i].pos = pos[i];
+    k[i].idx = i;
+  }
+  qsort(k, nb, sizeof(bar_key_t), bar_key_cmp);
+  for (size_t i = 0; i < nb; ++i) {
+    tp[i] = pos[k[i].idx];
+    td[i] = dir[k[i].idx];
+    ta[i] = stp_active[k[i].idx];
+    ti[i] = stp_inactive[k[i].idx];
+  }
+  memcpy(pos, tp, nb * sizeof(uint64_t));
+  memcpy(dir, td, nb);
+  memcpy(stp_active, ta, nb * sizeof(double));
+  memcpy(stp_inactive, ti, nb * sizeof(double));
+  free(k);
+  free(tp);
+  free(td);
+  free(ta);
+  free(ti);
+}
+
+static int simulate_cell_sorted(const mo_params_t* p, uint64_t start, uint64_t end, size_t nb,
+                                const uint64_t* bar_pos, const uint8_t* bar_dir,
+                                const double* bar_stp_active, const double* bar_stp_inactive,
+                                const mo_task_t* task, uint32_t* contacts, uint64_t nrows,
+                                uint64_t ncols, uint64_t* missed, uint64_t* occupancy,
+                                mo_cell_result_t* res);
+
+/* State::operator=(const Task&) copies the interval's barriers and sorts them for every task
+ * (simulation.cpp:741-761); the copy is only made here when the input is not sorted already. */
 int mo_simulate_cell(const mo_params_t* p, uint64_t start, uint64_t end, size_t nb,
                      const uint64_t* bar_pos, const uint8_t* bar_dir, const double* bar_stp_active,
                      const double* bar_stp_inactive, const mo_task_t* task, uint32_t* contacts,
                      uint64_t nrows, uint64_t ncols, uint64_t* missed, uint64_t* occupancy,
                      mo_cell_result_t* res) {
+  int sorted = 1;
+  for (size_t i = 1; i < nb && sorted; ++i) sorted = bar_pos[i - 1] <= bar_pos[i];
+  if (sorted)
+    return simulate_cell_sorted(p, start, end, nb, bar_pos, bar_dir, bar_stp_active,
+                                bar_stp_inactive, task, contacts, nrows, ncols, missed, occupancy,
+                                res);
+  uint64_t* sp = (uint64_t*)malloc(nb * sizeof(uint64_t));
+  uint8_t* sd = (uint8_t*)malloc(nb);
+  double* sa = (double*)malloc(nb * sizeof(double));
+  double* si = (double*)malloc(nb * sizeof(double));
+  memcpy(sp, bar_pos, nb * sizeof(uint64_t));
+  memcpy(sd, bar_dir, nb);
+  memcpy(sa, bar_stp_active, nb * sizeof(double));
+  memcpy(si, bar_stp_inactive, nb * sizeof(double));
+  mo_sort_barriers(nb, sp, sd, sa, si);
+  const int rc = simulate_cell_sorted(p, start, end, nb, sp, sd, sa, si, task, contacts, nrows,
+                                      ncols, missed, occupancy, res);
+  free(sp);
+  free(sd);
+  free(sa);
+  free(si);
+  return rc;
+}
+
+static int simulate_cell_sorted(const mo_params_t* p, uint64_t start, uint64_t end, size_t nb,
+                                const uint64_t* bar_pos, const uint8_t* bar_dir,
+                                const double* bar_stp_active, const double* bar_stp_inactive,
+                                const mo_task_t* task, uint32_t* contacts, uint64_t nrows,
+                                uint64_t ncols, uint64_t* missed, uint64_t* occupancy,
+                                mo_cell_result_t* res) {
   cell_t s;
   memset(&s, 0, sizeof(s));
   s.p = p;

@@ -222,6 +222,9 @@ void mo_generate_moves(const mo_params_t* p, uint64_t start, uint64_t end, size_
 /* ---- whole-cell simulation --------------------------------------------------------------- */
 /* contacts: nrows*ncols+1 uint32 (band layout), accumulated into with atomic adds;
  * missed: updates that fell outside the band; occupancy: ncols uint64 or NULL. */
+/* ExtrusionBarriers::sort (extrusion_barriers.cpp:237-257), in place */
+void mo_sort_barriers(size_t nb, uint64_t* pos, uint8_t* dir, double* stp_active,
+                      double* stp_inactive);
 int mo_simulate_cell(const mo_params_t* p, uint64_t start, uint64_t end, size_t nb,
                      const uint64_t* bar_pos, const uint8_t* bar_dir, const double* bar_stp_active,
                      const double* bar_stp_inactive, const mo_task_t* task, uint32_t* contacts,

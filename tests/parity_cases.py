@@ -81,6 +81,8 @@ def assert_same_results(res_a, res_b, what):
         for field in ("epochs", "burnin_epochs", "num_contacts", "raws_consumed",
                       "sum_active_lefs", "sampling_events", "sim_epochs"):
             assert getattr(a, field) == getattr(b, field), f"{what}: cell {i}: {field}"
+        # State::rand_eng at return (SURVEY.md section 8d lists the final PRNG state in the gate)
+        assert list(a.prng_final) == list(b.prng_final), f"{what}: cell {i}: prng_final"
 
 
 def assert_same_outputs(a, b, what):

@@ -136,3 +136,64 @@ def test_device_division_by_a_uniform_bucket_is_exact():
     ranges = rng.integers(1, 2**32 - 1, size=n, dtype=np.uint64)
     ranges[:64] = (np.uint64(1) << (np.arange(64, dtype=np.uint64) % np.uint64(32))) + np.arange(64, dtype=np.uint64) // np.uint64(32)
     assert lib.emu_check_udiv_by_uniform(raws.ctypes.data, ranges.ctypes.data, n) == 0
+
+
+def test_c11_consumer_compiles_and_agrees_with_the_python_view(tmp_path):
+    """include/modle_hip.h and include/modle_cooler.h are valid C11 for a real consumer (not only
+    for the regex above): a C program compiled with -Wall -Wextra -Werror links against the two
+    libraries and its host-logic calls give what the ctypes view gives."""
+    import shutil
+    import subprocess
+
+    from modle_amd import cooler
+
+    cooler.lib()
+    src = os.path.join(ROOT, "tests", "c_consumer", "consumer.c")
+    exe = str(tmp_path / "consumer")
+    libdir = os.path.join(ROOT, "modle_amd")
+    cc = shutil.which("gcc") or shutil.which("cc")
+    assert cc, "no C compiler"
+    subprocess.run([cc, "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic",
+                    "-I" + os.path.join(ROOT, "include"), src, "-o", exe, "-L" + libdir,
+                    "-lmodle_hip", "-lmodle_cooler", "-Wl,-rpath," + libdir,
+                    "-Wl,-rpath,/opt/rocm/lib"],
+                   check=True, capture_output=True, text=True)
+    cool = str(tmp_path / "c.cool")
+    out = subprocess.run([exe, cool], check=True, capture_output=True, text=True).stdout.split("\n")
+    cfg = api.make_config(num_cells=4)
+    size = 5_000_000
+    tasks = api.make_tasks(cfg, "chrC", size, 0, size)
+    assert out[0] == f"hash {api.interval_hash('chrC', size, 0, size, cfg.seed)}"
+    assert out[1] == "shape %d %d" % api.matrix_shape(cfg, size)
+    assert out[2] == f"nlefs {api.compute_num_lefs(cfg, size)}"
+    for i in range(4):
+        t = tasks[i]
+        assert out[3 + i] == f"task {t.cell_id} {t.num_target_contacts} {t.prng[0]} {t.prng[3]}"
+    assert out[7] == "sorted 100 500 900 2 0.8 0.1"
+    assert float(out[8].split()[1]) == api.stp_active_from_occupancy(cfg.barrier_not_occupied_stp, 0.85)
+    assert out[9] in ("create ok", "create refused")
+    assert out[10] == "cooler ok" and os.path.getsize(cool) > 0
+
+
+def test_sort_barriers_is_stable_and_matches_the_oracle(oracle):
+    import ctypes as C
+
+    rng = np.random.default_rng(5)
+    n = 500
+    pos = rng.integers(0, 200, size=n).astype(np.uint64)  # many duplicates
+    dirs = rng.integers(1, 3, size=n).astype(np.uint8)
+    sa, si = rng.random(n), rng.random(n)
+    p2, d2, a2, i2 = api.sort_barriers(pos, dirs, sa, si)
+    order = np.argsort(pos, kind="stable")
+    assert np.array_equal(p2, pos[order]) and np.array_equal(d2, dirs[order])
+    assert np.array_equal(a2, sa[order]) and np.array_equal(i2, si[order])
+    L = oracle.lib()
+    u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+    u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+    f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+    L.mo_sort_barriers.argtypes = [C.c_size_t, u64p, u8p, f64p, f64p]
+    L.mo_sort_barriers.restype = None
+    p3, d3, a3, i3 = pos.copy(), dirs.copy(), sa.copy(), si.copy()
+    L.mo_sort_barriers(n, p3, d3, a3, i3)
+    assert np.array_equal(p2, p3) and np.array_equal(d2, d3)
+    assert np.array_equal(a2, a3) and np.array_equal(i2, i3)

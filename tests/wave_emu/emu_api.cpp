@@ -32,6 +32,7 @@ namespace {
 struct LdsImage {
   std::vector<u64> ring;
   std::vector<u64> rng_state;
+  std::vector<u64> rng_snap;
   std::vector<u64> jump;
   std::vector<u64> sort_lds;
   std::vector<u32> stage;
@@ -39,6 +40,8 @@ struct LdsImage {
     WaveLds l;
     l.ring = ring.data();
     l.rng_state = rng_state.data();
+    l.rng_snap = rng_snap.data();
+    l.abort_flag = nullptr;
     l.jump_table = jump.data();
     l.zig_norm_x = ZIG_NORM_X;
     l.zig_norm_y = ZIG_NORM_Y;
@@ -54,6 +57,7 @@ struct LdsImage {
   LdsImage()
       : ring(RNG_RING),
         rng_state(4 * 64),
+        rng_snap(8),
         jump(modle_host::build_jump_table(RNG_BLOCK)),
         sort_lds(SORT_LDS_CAP),
         stage(STAGE_CAP) {
