@@ -8,7 +8,14 @@ task of this rank's shard is simulated by the HIP kernel (one wavefront per cell
 the per-rank contact matrices are summed with RCCL.  Default workload = BASELINE.json configs[2]:
 the whole GRCh38-shaped genome (24 chromosomes, synthetic barriers with the bundled BED's
 statistics), 2048 cells per GPU, all parameters at the reference defaults, seed 0.  Cells are
-sharded over ranks (weak scaling: 2048 cells per GPU; configs[3] is the 8-GPU point).
+sharded over ranks.  Default = weak scaling, 2048 cells per GPU (configs[3], 16384 cells, is the
+8-GPU point); the reference splits a fixed number of target contacts over the cells
+(scheduler_simulate.cpp:129-141), so a cell of the 8-GPU point samples an eighth of the contacts
+of a cell of the 1-GPU point: `cell_epochs_per_s` is reported next to `value` for that reason.
+`--scaling strong --total-cells N` keeps the workload fixed (N cells in total at every GPU count).
+
+After the timed region the outputs of the last step are verified (driver.verify_outputs:
+contact conservation per interval, per-cell targets, occupancy, device status): `"checked": true`.
 
 Prints ONE JSON line on rank 0 (contract in the task statement): metric = simulated
 genome-cells/s (whole job), plus `roofline` (algorithmic HBM bytes of the simulation kernel over
@@ -48,7 +55,10 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["grch38", "chr1"], default="grch38")
-    ap.add_argument("--cells", type=int, default=None, help="cells per GPU")
+    ap.add_argument("--cells", type=int, default=None, help="cells per GPU (weak scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--total-cells", type=int, default=None,
+                    help="cells of the whole job with --scaling strong (default 2048 / 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=None)
     return ap.parse_args()
@@ -134,6 +144,7 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for N > 1")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -145,18 +156,27 @@ def main():
 
         dist.init_process_group("nccl", device_id=dev)
 
-    cells_per_gpu = args.cells or (2048 if args.workload == "grch38" else 512)
+    default_cells = 2048 if args.workload == "grch38" else 512
+    if args.scaling == "strong":
+        total_cells = args.total_cells or default_cells
+        if total_cells < world:
+            raise SystemExit("--total-cells must be at least the number of GPUs")
+        cells_per_gpu = -(-total_cells // world)  # largest shard
+        cells_txt = f"{total_cells} cells in total (strong scaling)"
+    else:
+        cells_per_gpu = args.cells or default_cells
+        total_cells = cells_per_gpu * world
+        cells_txt = f"{cells_per_gpu} cells per GPU"
     if args.workload == "grch38":
         genome = synthetic.grch38_like(seed=42)
         workload = (f"GRCh38-shaped genome (24 chromosomes, synthetic H1-like barriers), "
-                    f"{cells_per_gpu} cells per GPU, reference defaults (BASELINE configs[2]/[3])")
+                    f"{cells_txt}, reference defaults (BASELINE configs[2]/[3])")
         unit = "genome-cells/s"
     else:
         genome = synthetic.grch38_like(seed=42, chroms={"chr1"})
         workload = (f"chr1-shaped interval (248 956 422 bp, 3129 synthetic barriers), "
-                    f"{cells_per_gpu} cells per GPU, reference defaults (BASELINE configs[1])")
+                    f"{cells_txt}, reference defaults (BASELINE configs[1])")
         unit = "chr1-cells/s"
-    total_cells = cells_per_gpu * world
     cfg = api.make_config(num_cells=total_cells, seed=0)
 
     plan = driver.plan_genome(cfg, genome, rank, world)
@@ -176,9 +196,9 @@ def main():
     stream = torch.cuda.current_stream(dev)
 
     kernel_ms = []
-    alg_bytes = []
+    check = {}
 
-    def step(first):
+    def step(first, last=False):
         if not first:
             for entry, iid in zip(plan, ids):
                 if iid is not None:
@@ -187,8 +207,15 @@ def main():
             if t is not None:
                 t[0].zero_()
                 t[1].zero_()
+        if last:
+            check["missed_before"] = driver.read_missed(sim, ids)
         sim.launch(stream.cuda_stream)
         sim.wait()
+        if last:
+            # this rank's own outputs, before the reduce folds the other ranks' into them: 48
+            # device-side sums (about 1 ms of 1.5 GB reads against seconds of simulation)
+            check["matrix"] = [None if t is None else t[0].sum(dtype=torch.int64) for t in tensors]
+            check["occ"] = [None if t is None else t[1].sum() for t in tensors]
         if use_dist:
             import torch.distributed as dist
 
@@ -213,8 +240,8 @@ def main():
     kernel_ms.clear()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(first)
+    for k in range(args.steps):
+        step(first, last=(k == args.steps - 1))
         first = False
     sync()
     dt = time.perf_counter() - t0
@@ -242,6 +269,22 @@ def main():
     avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3 if kernel_ms else float("nan")
     achieved = step_bytes / avg_kernel_s / 1e9
 
+    # verify the outputs of the last step (every rank checks its own shard; a violation raises
+    # and fails the job: the number printed below comes from a launch whose results were looked at)
+    missed_after = driver.read_missed(sim, ids)
+    missed_delta = [None if a is None else a - b for a, b in zip(missed_after, check["missed_before"])]
+    msum = [None if x is None else int(x.item()) for x in check["matrix"]]
+    osum = [None if x is None else int(x.item()) for x in check["occ"]]
+    verified = driver.verify_outputs(sim, cfg, plan, ids, msum, missed_delta, osum)
+    if use_dist:
+        import torch.distributed as dist
+
+        tot = torch.tensor([epochs, n_tasks], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        job_epochs, job_tasks = int(tot[0].item()), int(tot[1].item())
+    else:
+        job_epochs, job_tasks = epochs, n_tasks
+
     if rank == 0:
         out = {
             "metric": "simulated cells/sec (whole node), GRCh38 default barriers",
@@ -252,7 +295,12 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
+            "checked": True,
+            "check": dict(verified, what="rank 0's shard of the last step: matrix + missed == contacts "
+                                         "per interval, per-cell targets, occupancy parity, status 0"),
+            "cell_epochs_per_s": job_epochs * args.steps / dt,
+            "tasks_per_s": job_tasks * args.steps / dt,
             "vs_baseline": None,
             "dtype": "u32/f64",
             "data": "synthetic",

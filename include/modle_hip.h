@@ -232,6 +232,10 @@ int modle_hip_simulate_interval(modle_hip_handle* h, uint64_t start, uint64_t en
 #define MODLE_HIP_PH_SECONDARY 0x200u          /* process_secondary_lef_lef_collisions */
 #define MODLE_HIP_PH_FIX_SECONDARY 0x400u      /* fix_secondary_lef_lef_collisions */
 #define MODLE_HIP_PH_USE_BOUNDARY_COUNTS 0x800u /* feed the boundary counts to later passes */
+#define MODLE_HIP_PH_BIND 0x1000u              /* select_and_bind_lefs (simulation.cpp:988-993): binds
+                                                * every released LEF of the image at the epoch held
+                                                * in bits 16..31 of the mask, then ranks */
+#define MODLE_HIP_PH_GEN_MOVES 0x2000u         /* generate_moves (simulation.cpp:299-330) */
 
 int modle_hip_test_phases(modle_hip_handle* h, uint32_t phase_mask, uint64_t start, uint64_t end,
                           size_t n_lefs, uint64_t* rev_pos, uint64_t* fwd_pos, uint64_t* epoch,
@@ -240,6 +244,26 @@ int modle_hip_test_phases(modle_hip_handle* h, uint32_t phase_mask, uint64_t sta
                           size_t n_barriers, const uint64_t* bar_pos, const uint8_t* bar_dir,
                           const uint8_t* bar_active, uint64_t prng[4], uint64_t* raws_consumed,
                           char* err, size_t errlen);
+
+/* Unit-level entry point: the small pieces of the path that the reference tests on their own,
+ * evaluated by the device code.  `in` holds n pairs of 64-bit values, `out` 2 n words:
+ *   LOOP_STATS        in = (rev position, fwd position) of every LEF; out[0], out[1] = bit images
+ *                     of the mean and the population standard deviation of the loop sizes
+ *                     (stats::mean / standard_dev as compute_loop_size_stats uses them,
+ *                     simulation.cpp:795-819; reference vectors: test/units/stats/descriptive_test.cpp)
+ *   MATRIX_INCREMENT  in = (row, col) per ContactMatrixDense::increment call; `contacts`
+ *                     (uint32[nrows * ncols + 1], band layout) and `missed_updates` are updated in
+ *                     place (reference vectors: test/units/contact_matrix/*_test.cpp)
+ *   COLLISION_WORDS   in = (index, event); out = (Collision<> word, predicate bits: 0 occurred,
+ *                     1 avoided, 2..5 occurred(CHROM_BOUNDARY, LEF_BAR, LEF_LEF_PRIMARY,
+ *                     LEF_LEF_SECONDARY), 6..9 avoided(the same)) (reference vectors:
+ *                     test/units/simulation_cpu/collision_encoding_test.cpp) */
+#define MODLE_HIP_UNIT_LOOP_STATS 1u
+#define MODLE_HIP_UNIT_MATRIX_INCREMENT 2u
+#define MODLE_HIP_UNIT_COLLISION_WORDS 3u
+int modle_hip_test_units(modle_hip_handle* h, uint32_t what, const uint64_t* in, size_t n,
+                         uint64_t nrows, uint64_t ncols, uint32_t* contacts,
+                         uint64_t* missed_updates, uint64_t* out, char* err, size_t errlen);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,7 @@ EXPORTS = [
     "modle_hip_wait", "modle_hip_last_kernel_ms", "modle_hip_get_results",
     "modle_hip_interval_outputs", "modle_hip_copy_outputs", "modle_hip_reset",
     "modle_hip_simulate_interval", "modle_hip_test_phases", "modle_hip_sort_barriers",
-    "modle_hip_cancel",
+    "modle_hip_cancel", "modle_hip_test_units",
 ]
 
 u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
@@ -94,6 +94,8 @@ def lib():
                                          C.c_size_t] + [u64p] * 9 +
                                         [C.c_size_t, u64p, u8p, u8p, P(C.c_uint64),
                                          P(C.c_uint64)] + err)
+    L.modle_hip_test_units.argtypes = [C.c_void_p, C.c_uint32, u64p, C.c_size_t, C.c_uint64,
+                                       C.c_uint64, C.c_void_p, P(C.c_uint64), u64p] + err
     for name in EXPORTS:
         getattr(L, name)  # raises AttributeError if a declared symbol is not exported
     _lib = L

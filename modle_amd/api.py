@@ -232,6 +232,19 @@ class Simulator:
             contacts, nrows, ncols, C.byref(missed), occ.ctypes.data, res, err, len(err)), err)
         return contacts, missed.value, occ, res
 
+    def test_units(self, what, pairs, nrows=0, ncols=0, contacts=None, missed=0):
+        """Unit-level entry point (modle_hip_test_units); returns (out words, contacts, missed)."""
+        pairs = np.ascontiguousarray(pairs, dtype=np.uint64).reshape(-1)
+        n = len(pairs) // 2
+        out = np.zeros(2 * n, dtype=np.uint64)
+        m = C.c_uint64(missed)
+        err = _errbuf()
+        _check(self._L.modle_hip_test_units(
+            self._h, what, pairs, n, nrows, ncols,
+            contacts.ctypes.data if contacts is not None else None, C.byref(m), out, err,
+            len(err)), err)
+        return out, contacts, m.value
+
     def test_phases(self, mask, st, prng_state):
         """Phase-level entry point (mirrors Simulation::test_* hooks) on KatState-like arrays."""
         prng = (C.c_uint64 * 4)(*prng_state)

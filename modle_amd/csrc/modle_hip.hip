@@ -224,6 +224,28 @@ __global__ __launch_bounds__(64) void modle_test_phases(PhaseArgs a) {
   }
 }
 
+struct UnitArgs {
+  Params params;
+  DeviceTables tables;
+  Interval interval;
+  char* workspace;
+  const u64* in;
+  u64* out;
+  u32* status_out;
+  u32 what;
+  u32 n;
+};
+
+__global__ __launch_bounds__(64) void modle_test_units(UnitArgs a) {
+  __shared__ BlockLds s;
+  load_block_tables(s, a.tables, 64);
+  const WaveLds lds = make_wave_lds(s, 0);
+  const Workspace ws = device_carve(a.workspace, a.n, 0, 4);
+  const u32 st = run_test_units(a.params, a.interval, ws, lds, a.what, wave::as_global(a.in), a.n,
+                                wave::as_global(a.out));
+  if (wave::lane() == 0) *a.status_out = st;
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -914,6 +936,70 @@ int modle_hip_test_phases(modle_hip_handle* h, uint32_t phase_mask, uint64_t sta
   if (static_cast<u32>(out[1]) != 0) {
     set_err(err, errlen, "device phase runner reported status " + std::to_string(out[1]));
     return MODLE_HIP_ERR_STATE;
+  }
+  return MODLE_HIP_OK;
+}
+
+int modle_hip_test_units(modle_hip_handle* h, uint32_t what, const uint64_t* in, size_t n,
+                         uint64_t nrows, uint64_t ncols, uint32_t* contacts,
+                         uint64_t* missed_updates, uint64_t* out, char* err, size_t errlen) {
+  if (h == nullptr || n == 0 || in == nullptr) return MODLE_HIP_ERR_ARG;
+  if (h->in_flight) return MODLE_HIP_ERR_STATE;
+  if (n >= (1u << 24)) return MODLE_HIP_ERR_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  const auto layout = modle_host::workspace_layout(static_cast<u32>(n), 0, 4);
+  DevBuf<char> d_ws;
+  DevBuf<u64> d_in, d_out, d_missed;
+  DevBuf<u32> d_contacts, d_status;
+  const size_t nwords = what == UNIT_MATRIX_INCREMENT ? nrows * ncols + 1 : 1;
+  if (what == UNIT_MATRIX_INCREMENT && (contacts == nullptr || nrows == 0 || ncols == 0)) {
+    set_err(err, errlen, "matrix unit needs a contact buffer and its shape");
+    return MODLE_HIP_ERR_ARG;
+  }
+  HIP_TRY(d_ws.ensure(layout.total_bytes));
+  HIP_TRY(d_in.ensure(2 * n));
+  HIP_TRY(d_out.ensure(2 * n));
+  HIP_TRY(d_missed.ensure(1));
+  HIP_TRY(d_status.ensure(1));
+  HIP_TRY(d_contacts.ensure(nwords));
+  HIP_TRY(hipMemcpy(d_in.p, in, 2 * n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(d_out.p, 0, 2 * n * 8));
+  HIP_TRY(hipMemset(d_missed.p, 0, 8));
+  HIP_TRY(hipMemset(d_status.p, 0xFF, 4));
+  if (what == UNIT_MATRIX_INCREMENT) {
+    HIP_TRY(hipMemcpy(d_contacts.p, contacts, nwords * 4, hipMemcpyHostToDevice));
+    if (missed_updates != nullptr) HIP_TRY(hipMemcpy(d_missed.p, missed_updates, 8, hipMemcpyHostToDevice));
+  }
+  UnitArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.params = h->params;
+  a.tables.jump = h->d_jump.p;
+  a.tables.zig = h->d_zig.p;
+  a.interval.start = 0;
+  a.interval.end = 0xFFFFFFF0u;
+  a.interval.contacts = d_contacts.p;
+  a.interval.missed_updates = d_missed.p;
+  a.interval.nrows = nrows == 0 ? 1 : nrows;
+  a.interval.ncols = ncols == 0 ? 1 : ncols;
+  a.workspace = d_ws.p;
+  a.in = d_in.p;
+  a.out = d_out.p;
+  a.status_out = d_status.p;
+  a.what = what;
+  a.n = static_cast<u32>(n);
+  hipLaunchKernelGGL(modle_test_units, dim3(1), dim3(64), 0, nullptr, a);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  u32 st = 0;
+  HIP_TRY(hipMemcpy(&st, d_status.p, 4, hipMemcpyDeviceToHost));
+  if (st != 0) {
+    set_err(err, errlen, "device unit runner reported status " + std::to_string(st));
+    return MODLE_HIP_ERR_STATE;
+  }
+  if (out != nullptr) HIP_TRY(hipMemcpy(out, d_out.p, 2 * n * 8, hipMemcpyDeviceToHost));
+  if (what == UNIT_MATRIX_INCREMENT) {
+    HIP_TRY(hipMemcpy(contacts, d_contacts.p, nwords * 4, hipMemcpyDeviceToHost));
+    if (missed_updates != nullptr) HIP_TRY(hipMemcpy(missed_updates, d_missed.p, 8, hipMemcpyDeviceToHost));
   }
   return MODLE_HIP_OK;
 }

@@ -2549,14 +2549,16 @@ MODLE_DEV u64 phase_sample_contacts(Cell& c, u64 events_per_epoch, u64 num_targe
 // =============================================================================================
 // Burn-in (reference: simulation.cpp:795-894)
 // =============================================================================================
-MODLE_DEV_NOINLINE void compute_loop_size_stats(Cell& c) {
+struct LoopStats {
+  f64 avg, std;  // stats::mean / stats::standard_dev of the loop sizes (population std)
+};
+MODLE_DEV LoopStats loop_size_stats(Cell& c) {
   // reference: simulation.cpp:795-819 and stats/descriptive_impl.hpp:22-31, 63-101.  The mean is
   // a sum of integers below 2^53 (order independent); the squared deviations are accumulated
   // strictly left to right in LEF-id order like std::accumulate.
   Workspace& ws = c.ws;
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
-  const u32 cap = c.p->hist_len;
   // pass A, rank order (contiguous reads, four batches in flight): every unit drops its position
   // at its LEF's slot of two id-ordered scratch arrays; the sum of all loop sizes is the sum of
   // the fwd positions minus the sum of the rev positions (released LEFs have both units at
@@ -2630,7 +2632,15 @@ MODLE_DEV_NOINLINE void compute_loop_size_stats(Cell& c) {
       for (u32 l = 0; l < 64; ++l) ssd = ssd + wave::bcast(term, l);
     }
   }
-  const f64 std = wave::f_sqrt(ssd / static_cast<f64>(n));
+  return LoopStats{avg, wave::f_sqrt(ssd / static_cast<f64>(n))};
+}
+
+MODLE_DEV_NOINLINE void compute_loop_size_stats(Cell& c) {
+  Workspace& ws = c.ws;
+  const u32 lane = wave::lane();
+  const u32 cap = c.p->hist_len;
+  const LoopStats st = loop_size_stats(c);
+  const f64 avg = st.avg, std = st.std;
   // push_back with pop_front at capacity (two deque<double>)
   f64* cfx = ws.hist;
   f64* avgb = ws.hist + cap;
@@ -2937,7 +2947,10 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
 constexpr u32 PH_RANK = 0x001, PH_RANK_INIT = 0x002, PH_ADJUST = 0x004, PH_CLAMP = 0x008,
               PH_BOUNDARIES = 0x010, PH_LEF_BAR = 0x020, PH_PRIMARY = 0x040,
               PH_CORRECT_LEF_BAR = 0x080, PH_CORRECT_PRIMARY = 0x100, PH_SECONDARY = 0x200,
-              PH_FIX_SECONDARY = 0x400, PH_USE_BOUNDARY_COUNTS = 0x800;
+              PH_FIX_SECONDARY = 0x400, PH_USE_BOUNDARY_COUNTS = 0x800,
+              PH_BIND = 0x1000,       // select_and_bind_lefs: bind every released LEF, then rank
+              PH_GEN_MOVES = 0x2000;  // generate_moves: draw, adjust, clamp
+// bits 16..31 of the mask: the current epoch (binding epoch of the LEFs PH_BIND binds)
 
 struct TestImage {  // all by LEF id except the two rank arrays; n entries each
   u32 *rev_pos, *fwd_pos, *epoch, *rev_rank, *fwd_rank, *rev_moves, *fwd_moves, *rev_coll,
@@ -3010,11 +3023,19 @@ MODLE_DEV u32 run_test_phases(const Params& p, const Interval& iv, const Workspa
     }
   }
   wave::sync_mem();
+  if (mask & PH_BIND) {
+    // Simulation::select_and_bind_lefs (simulation.cpp:988-993): the released LEFs of the image
+    // are the ones to bind; the ranking that follows is the partially sorted one
+    phase_bind(c, mask >> 16);
+    rank_update<false>(c, false);
+    rank_update<true>(c, false);
+  }
   if (mask & PH_RANK) {
     // positions only: move / collision arrays are not meaningful across a re-ranking
     rank_update<false>(c, true);
     rank_update<true>(c, true);
   }
+  if (mask & PH_GEN_MOVES) phase_generate_moves(c, true);
   if (mask & (PH_ADJUST | PH_CLAMP)) {
     adjust_moves_rev(c, (mask & PH_ADJUST) != 0, (mask & PH_CLAMP) != 0);
     adjust_moves_fwd(c, (mask & PH_ADJUST) != 0, (mask & PH_CLAMP) != 0);
@@ -3072,11 +3093,82 @@ MODLE_DEV u32 run_test_phases(const Params& p, const Interval& iv, const Workspa
       img.fwd_pos[fid] = c.ws.f_pos[k];
       img.fwd_moves[fid] = c.ws.f_move[k];
       img.fwd_coll[fid] = c.ws.f_coll[k];
+      img.epoch[k] = c.ws.epoch[k];  // binding epochs change under PH_BIND
     }
   }
   wave::sync_mem();
   raws_consumed = c.g.pos;
   return overflow ? ERR_LIST_OVERFLOW : c.error;
+}
+
+// =============================================================================================
+// Unit-level entry point: the small pieces of the path the reference tests on their own
+// (test/units/stats/descriptive_test.cpp, test/units/contact_matrix/*_test.cpp,
+// test/units/simulation_cpu/collision_encoding_test.cpp), run by the device code itself.
+// =============================================================================================
+constexpr u32 UNIT_LOOP_STATS = 1, UNIT_MATRIX_INCREMENT = 2, UNIT_COLLISION_WORDS = 3;
+
+// predicates of one collision word, packed: bit 0 collision_occurred(), bit 1 collision_avoided(),
+// bits 2..5 collision_occurred(CHROM_BOUNDARY / LEF_BAR / LEF_LEF_PRIMARY / LEF_LEF_SECONDARY),
+// bits 6..9 collision_avoided(the same four)
+MODLE_DEV u32 cw_predicates(u32 w) {
+  const u32 kinds[4] = {EV_CHROM_BOUNDARY, EV_LEF_BAR, EV_LEF_LEF_PRIMARY, EV_LEF_LEF_SECONDARY};
+  u32 f = (cw_occurred(w) ? 1u : 0u) | ((!cw_occurred(w) && w != 0) ? 2u : 0u);
+#pragma unroll
+  for (u32 k = 0; k < 4; ++k) {
+    f |= cw_occurred_as(w, kinds[k]) ? (4u << k) : 0u;
+    f |= cw_avoided_as(w, kinds[k]) ? (64u << k) : 0u;
+  }
+  return f;
+}
+
+// `in`: n pairs of 64-bit values; `out`: what the unit produces (see the cases); uniform
+MODLE_DEV u32 run_test_units(const Params& p, const Interval& iv, const Workspace& ws,
+                             const WaveLds& lds, u32 what, const u64* in, u32 n, u64* out) {
+  const u32 lane = wave::lane();
+  const Interval ivg = interval_in_device_memory(iv);
+  const u64 zero[4] = {1, 2, 3, 4};
+  Cell c;
+  init_cell(c, p, ivg, ws, lds, n, zero);
+  c.n_active = n;
+  if (what == UNIT_LOOP_STATS) {
+    // pairs (rev position, fwd position) of LEF i; identity ranking
+    for (u32 base = 0; base < n; base += 64) {
+      const u32 k = base + lane;
+      if (k < n) {
+        c.ws.r_pos[k] = static_cast<u32>(in[2 * k]);
+        c.ws.f_pos[k] = static_cast<u32>(in[2 * k + 1]);
+        c.ws.r_id[k] = k;
+        c.ws.f_id[k] = k;
+      }
+    }
+    wave::sync_mem();
+    const LoopStats st = loop_size_stats(c);
+    if (lane == 0) {
+      out[0] = static_cast<u64>(__builtin_bit_cast(i64, st.avg));
+      out[1] = static_cast<u64>(__builtin_bit_cast(i64, st.std));
+    }
+  } else if (what == UNIT_MATRIX_INCREMENT) {
+    // pairs (row, col): ContactMatrixDense::increment
+    for (u32 base = 0; base < n; base += 64) {
+      const u32 k = base + lane;
+      if (k < n) matrix_increment(ivg, in[2 * k], in[2 * k + 1]);
+    }
+  } else if (what == UNIT_COLLISION_WORDS) {
+    // pairs (index, event): out = (word, predicates)
+    for (u32 base = 0; base < n; base += 64) {
+      const u32 k = base + lane;
+      if (k < n) {
+        const u32 w = cw_make(static_cast<u32>(in[2 * k]), static_cast<u32>(in[2 * k + 1]));
+        out[2 * k] = (static_cast<u64>(cw_event(w)) << 56) | cw_index(w);
+        out[2 * k + 1] = cw_predicates(w);
+      }
+    }
+  } else {
+    return ERR_INTERNAL;
+  }
+  wave::sync_mem();
+  return 0;
 }
 
 }  // namespace modle_dev

@@ -74,6 +74,52 @@ def algorithmic_bytes(results, n_barriers, track_1d=True):
     return total
 
 
+def read_missed(sim, ids):
+    """missed-update counters of every registered interval (they accumulate over launches)"""
+    return [None if iid is None else sim.copy_outputs(iid, want_contacts=False)[1] for iid in ids]
+
+
+def verify_outputs(sim, cfg, plan, ids, matrix_sums, missed_delta, occupancy_sums=None):
+    """Self-check of one launch's outputs (what a caller can assert without an oracle):
+
+    * every registered contact is in the band matrix or was counted as a missed update
+      (ContactMatrixDense::add, contact_matrix_dense_safe_impl.hpp:55-68);
+    * with a target contact density, every cell stops exactly on its share of the target
+      (stop condition, simulation.cpp:925-931; split, scheduler_simulate.cpp:129-141);
+    * the 1-D occupancy track holds at most two entries per sampling event, an even number;
+    * burn-in: all LEFs activated before it can end, and at least one epoch simulated.
+
+    `matrix_sums[k]` / `occupancy_sums[k]`: sum of the interval's matrix / occupancy words of this
+    launch (this rank's shard, before any reduce); `missed_delta[k]`: missed updates of this
+    launch.  Uses the results of the LAST launch.  Raises AssertionError; returns a summary."""
+    n_tasks = n_contacts = n_missed = 0
+    for k, (entry, iid) in enumerate(zip(plan, ids)):
+        if iid is None:
+            continue
+        name = entry["interval"]["name"]
+        ntasks = len(entry["tasks"])
+        res = sim.results(iid)
+        last = res[len(res) - ntasks:]
+        contacts = sum(r.num_contacts for r in last)
+        assert int(matrix_sums[k]) + int(missed_delta[k]) == contacts, \
+            f"{name}: {int(matrix_sums[k])} matrix + {int(missed_delta[k])} missed != {contacts} contacts"
+        if cfg.target_contact_density >= 0:
+            got = [r.num_contacts for r in last]
+            want = [t.num_target_contacts for t in entry["tasks"]]
+            assert got == want, f"{name}: per-cell contacts differ from the target split"
+        if occupancy_sums is not None and cfg.track_1d_lef_position:
+            occ = int(occupancy_sums[k])
+            assert occ % 2 == 0 and occ <= 2 * sum(r.sampling_events for r in last), \
+                f"{name}: occupancy track inconsistent with the sampling events"
+        for r, t in zip(last, entry["tasks"]):
+            if t.num_target_contacts != 0 and not cfg.skip_burnin and cfg.target_contact_density >= 0:
+                assert r.burnin_epochs >= 1 and r.epochs >= r.sim_epochs >= 1, f"{name}: epoch counters"
+        n_tasks += ntasks
+        n_contacts += contacts
+        n_missed += int(missed_delta[k])
+    return {"tasks": n_tasks, "contacts": n_contacts, "missed_updates": n_missed}
+
+
 def write_cooler(path, cfg, plan, matrices, assembly="unknown", generated_by="modle-hip",
                  metadata_json="", force_overwrite=False):
     """Writes the (reduced) contact matrices of a plan to a cooler file the way the reference's

@@ -1185,6 +1185,52 @@ static void matrix_increment(cell_t* s, uint64_t row, uint64_t col) {
   __atomic_fetch_add(&s->contacts[j * s->nrows + i], 1u, __ATOMIC_RELAXED);
 }
 
+/* stats::mean / stats::sum_of_squared_deviations / stats::variance / stats::standard_dev over the
+ * loop sizes (stats/descriptive_impl.hpp:22-31, 63-101): std::accumulate in double, left to
+ * right, population variance. */
+void mo_loop_size_stats(size_t n, const uint64_t* rev_pos, const uint64_t* fwd_pos, double* avg_out,
+                        double* ssd_out, double* var_out, double* std_out) {
+  double acc = 0.0;
+  for (size_t i = 0; i < n; ++i) acc = acc + (double)(fwd_pos[i] - rev_pos[i]);
+  const double avg = acc / (double)n;
+  double ssd = 0.0;
+  for (size_t i = 0; i < n; ++i) {
+    const double d = (double)(fwd_pos[i] - rev_pos[i]) - avg;
+    ssd = ssd + (d * d);
+  }
+  if (avg_out) *avg_out = avg;
+  if (ssd_out) *ssd_out = ssd;
+  if (var_out) *var_out = ssd / (double)n;
+  if (std_out) *std_out = sqrt(ssd / (double)n);
+}
+
+/* ContactMatrixDense::increment on a bare band buffer (unit hook for the reference's
+ * contact-matrix tests); same arithmetic as matrix_increment above */
+void mo_matrix_increment(uint32_t* contacts, uint64_t nrows, uint64_t ncols, uint64_t row,
+                         uint64_t col, uint64_t* missed) {
+  cell_t s;
+  memset(&s, 0, sizeof(s));
+  s.contacts = contacts;
+  s.nrows = nrows;
+  s.ncols = ncols;
+  s.missed = missed;
+  matrix_increment(&s, row, col);
+}
+
+/* Collision<> word and its predicates (collision_encoding_impl.hpp:75-242); bit layout of the
+ * result as in include/modle_hip.h (MODLE_HIP_UNIT_COLLISION_WORDS) */
+uint64_t mo_collision_word(uint64_t idx, unsigned ev) { return coll_make(idx, ev); }
+unsigned mo_collision_predicates(uint64_t w) {
+  static const unsigned kinds[4] = {MO_EV_CHROM_BOUNDARY, MO_EV_LEF_BAR, MO_EV_LEF_LEF_PRIMARY,
+                                    MO_EV_LEF_LEF_SECONDARY};
+  unsigned f = (coll_occurred(w) ? 1u : 0u) | ((!coll_occurred(w) && w != 0) ? 2u : 0u);
+  for (unsigned k = 0; k < 4; ++k) {
+    f |= coll_occurred_as(w, kinds[k]) ? (4u << k) : 0u;
+    f |= coll_avoided_as(w, kinds[k]) ? (64u << k) : 0u;
+  }
+  return f;
+}
+
 static void compute_loop_size_stats(cell_t* s) {
   /* simulation.cpp:795-819 + stats/descriptive_impl.hpp:22-31, 63-101 */
   const size_t n = s->num_active;
@@ -1193,15 +1239,8 @@ static void compute_loop_size_stats(cell_t* s) {
     s->hist_len = 0;
     return;
   }
-  double acc = 0.0;
-  for (size_t i = 0; i < n; ++i) acc = acc + (double)(s->fwd_pos[i] - s->rev_pos[i]);
-  const double avg = acc / (double)n;
-  double ssd = 0.0;
-  for (size_t i = 0; i < n; ++i) {
-    const double d = (double)(s->fwd_pos[i] - s->rev_pos[i]) - avg;
-    ssd = ssd + (d * d);
-  }
-  const double std = sqrt(ssd / (double)n);
+  double avg, std;
+  mo_loop_size_stats(n, s->rev_pos, s->fwd_pos, &avg, NULL, NULL, &std);
   if (s->hist_len == cap) {
     memmove(s->avg_buff, s->avg_buff + 1, (cap - 1) * sizeof(double));
     memmove(s->cfx_buff, s->cfx_buff + 1, (cap - 1) * sizeof(double));
@@ -1238,19 +1277,27 @@ static int evaluate_burnin(const cell_t* s) {
   return series_is_stable(s->avg_buff, cap, w);
 }
 
-static void bind_lefs(cell_t* s, uint64_t epoch_now) {
-  /* simulation_impl.hpp:30-91 */
-  const size_t n = s->num_active;
+/* Simulation::select_and_bind_lefs (simulation.cpp:988-993): select_lefs_to_bind (mask = the
+ * released LEFs) + bind_lefs (simulation_impl.hpp:30-91) + rank_lefs.  `scratch`: 3 n words. */
+void mo_select_and_bind_lefs(uint64_t start, uint64_t end, size_t n, uint64_t* rev_pos,
+                             uint64_t* fwd_pos, uint64_t* epoch, uint64_t* rev_rank,
+                             uint64_t* fwd_rank, uint64_t epoch_now, mo_prng_t* g,
+                             uint64_t* scratch) {
   for (size_t i = 0; i < n; ++i) {
-    if (!bound(s->epoch, i)) {
-      const uint64_t pos = mo_uniform_int(&s->g, s->start, s->end - 1);
-      s->rev_pos[i] = pos;
-      s->fwd_pos[i] = pos;
-      s->epoch[i] = epoch_now;
+    if (!bound(epoch, i)) {
+      const uint64_t pos = mo_uniform_int(g, start, end - 1);
+      rev_pos[i] = pos;
+      fwd_pos[i] = pos;
+      epoch[i] = epoch_now;
     }
   }
-  rank_sort(n, s->rev_rank, s->rev_pos, s->epoch, 0, s->scratch);
-  rank_sort(n, s->fwd_rank, s->fwd_pos, s->epoch, 1, s->scratch);
+  rank_sort(n, rev_rank, rev_pos, epoch, 0, scratch);
+  rank_sort(n, fwd_rank, fwd_pos, epoch, 1, scratch);
+}
+
+static void bind_lefs(cell_t* s, uint64_t epoch_now) {
+  mo_select_and_bind_lefs(s->start, s->end, s->num_active, s->rev_pos, s->fwd_pos, s->epoch,
+                          s->rev_rank, s->fwd_rank, epoch_now, &s->g, s->scratch);
 }
 
 static inline int lef_within_bound(const cell_t* s, size_t i, uint64_t lo, uint64_t hi) {

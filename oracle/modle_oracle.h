@@ -222,6 +222,18 @@ void mo_generate_moves(const mo_params_t* p, uint64_t start, uint64_t end, size_
 /* ---- whole-cell simulation --------------------------------------------------------------- */
 /* contacts: nrows*ncols+1 uint32 (band layout), accumulated into with atomic adds;
  * missed: updates that fell outside the band; occupancy: ncols uint64 or NULL. */
+/* unit hooks for the reference's stats / contact-matrix / collision-encoding tests */
+void mo_loop_size_stats(size_t n, const uint64_t* rev_pos, const uint64_t* fwd_pos, double* avg,
+                        double* ssd, double* var, double* std);
+void mo_matrix_increment(uint32_t* contacts, uint64_t nrows, uint64_t ncols, uint64_t row,
+                         uint64_t col, uint64_t* missed);
+uint64_t mo_collision_word(uint64_t idx, unsigned ev);
+unsigned mo_collision_predicates(uint64_t word);
+/* Simulation::select_and_bind_lefs (simulation.cpp:988-993); scratch: 3 n words */
+void mo_select_and_bind_lefs(uint64_t start, uint64_t end, size_t n, uint64_t* rev_pos,
+                             uint64_t* fwd_pos, uint64_t* epoch, uint64_t* rev_rank,
+                             uint64_t* fwd_rank, uint64_t epoch_now, mo_prng_t* g,
+                             uint64_t* scratch);
 /* ExtrusionBarriers::sort (extrusion_barriers.cpp:237-257), in place */
 void mo_sort_barriers(size_t nb, uint64_t* pos, uint8_t* dir, double* stp_active,
                       double* stp_inactive);

@@ -120,7 +120,8 @@ def main(out_path):
             body = text[h.start():end]
             name = h.group(1)
             if name.startswith(("Bind LEFs", "Generate LEF moves")):
-                continue  # property tests with RNG: restated as tests, no golden data
+                continue  # property tests with RNG: their parameters are extracted by
+                # extract_reference_unit_vectors.py and replayed by tests/unit_vector_runner.py
             line = text.count("\n", 0, h.start()) + 1
             c = parse_case(name, line, body)
             c["source_file"] = "test/units/simulation_cpu/" + fn

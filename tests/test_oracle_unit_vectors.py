@@ -1,0 +1,67 @@
+"""The reference's small unit tests that touch the hot path (tests/golden/reference_unit_vectors.json)
+on the CPU oracle and on the device code under the lane emulator; the property tests also compare
+the two word for word (positions, moves, ranks, PRNG outputs consumed)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from unit_vector_runner import DeviceUnits, OracleUnits, all_vectors, run_vector
+
+VECTORS = all_vectors()
+IDS = [v["name"] for _, v in VECTORS]
+
+
+def _emu_backend(oracle):
+    from modle_amd.params import Config
+    from phase_backend import emu_lib, emu_phases
+
+    L = emu_lib()
+    u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+    L.emu_test_units.argtypes = [C.POINTER(Config), C.c_uint32, u64p, C.c_size_t, C.c_uint64,
+                                 C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), u64p]
+    L.emu_test_units.restype = C.c_int
+
+    def units(cfg, what, pairs, nrows, ncols, contacts, missed):
+        pairs = np.ascontiguousarray(pairs, dtype=np.uint64).reshape(-1)
+        out = np.zeros(len(pairs), dtype=np.uint64)
+        m = C.c_uint64(missed)
+        rc = L.emu_test_units(C.byref(cfg), what, pairs, len(pairs) // 2, nrows, ncols,
+                              contacts.ctypes.data if contacts is not None else None, C.byref(m), out)
+        assert rc == 0
+        return out, m.value
+
+    return DeviceUnits("emulator", units, emu_phases, oracle)
+
+
+@pytest.mark.parametrize("group,v", VECTORS, ids=IDS)
+def test_reference_unit_vector_on_oracle(oracle, group, v):
+    run_vector(OracleUnits(oracle), group, v)
+
+
+@pytest.mark.parametrize("group,v", VECTORS, ids=IDS)
+def test_reference_unit_vector_on_emulated_device_code(oracle, group, v):
+    be = _emu_backend(oracle)
+    kw = {"iters": 40} if v["name"].startswith("Generate LEF moves") else {}
+    got = run_vector(be, group, v, **kw)
+    if group == "property_tests":
+        st_o, n_o = run_vector(OracleUnits(oracle), group, v, **kw)
+        st_d, n_d = got
+        assert n_o == n_d, "PRNG outputs consumed"
+        fields = ["rev_pos", "fwd_pos", "epoch", "rev_rank", "fwd_rank"]
+        if not v["name"].startswith("Bind"):  # the move arrays mean nothing before generate_moves
+            fields += ["rev_moves", "fwd_moves"]
+        for f in fields:
+            assert np.array_equal(getattr(st_o, f), getattr(st_d, f)), f
+
+
+def test_loop_stats_bit_identical_on_random_loops(oracle):
+    """beyond the reference's one vector: oracle and device code agree to the last bit on the
+    burn-in statistics of random loop-size sets (sequential fp64 accumulation)"""
+    rng = np.random.default_rng(9)
+    be_o, be_d = OracleUnits(oracle), _emu_backend(oracle)
+    for n in (1, 2, 63, 64, 65, 300, 1000):
+        rev = rng.integers(1, 200_000_000, size=n).astype(np.uint64)
+        fwd = rev + rng.integers(0, 3_000_000, size=n).astype(np.uint64)
+        a, b = be_o.loop_stats(rev, fwd), be_d.loop_stats(rev, fwd)
+        assert a["mean"] == b["mean"] and a["std"] == b["std"], n

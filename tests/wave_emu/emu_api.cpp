@@ -262,4 +262,39 @@ int emu_test_phases(const modle_hip_config* cfg, uint32_t phase_mask, uint64_t s
   return job.status == 0 ? MODLE_HIP_OK : MODLE_HIP_ERR_STATE;
 }
 
+struct UnitJob {
+  const Params* p;
+  const Interval* iv;
+  Workspace ws;
+  WaveLds lds;
+  u32 what, n;
+  const u64* in;
+  u64* out;
+  u32 status;
+};
+static void unit_body(void* arg) {
+  UnitJob* j = static_cast<UnitJob*>(arg);
+  const u32 st = run_test_units(*j->p, *j->iv, j->ws, j->lds, j->what, j->in, j->n, j->out);
+  if (wave::lane() == 0) j->status = st;
+}
+
+int emu_test_units(const modle_hip_config* cfg, uint32_t what, const uint64_t* in, size_t n,
+                   uint64_t nrows, uint64_t ncols, uint32_t* contacts, uint64_t* missed_updates,
+                   uint64_t* out) {
+  const Params p = modle_host::make_params(*cfg);
+  uint32_t dummy = 0;
+  IntervalImage img(0, 0xFFFFFFF0ull, nullptr, nullptr, nullptr, nullptr, 0,
+                    contacts != nullptr ? contacts : &dummy, nrows == 0 ? 1 : nrows,
+                    ncols == 0 ? 1 : ncols, nullptr);
+  if (missed_updates != nullptr) img.missed = *missed_updates;
+  LdsImage lds;
+  const auto layout = modle_host::workspace_layout(static_cast<u32>(n), 0, 4);
+  std::vector<uint64_t> wsmem(layout.total_bytes / 8 + 1);
+  UnitJob job{&p, &img.iv, modle_host::carve_workspace(wsmem.data(), static_cast<u32>(n), 0, 4),
+              lds.view(), what, static_cast<u32>(n), in, out, 0};
+  wave_emu::run_wave(unit_body, &job);
+  if (missed_updates != nullptr) *missed_updates = img.missed;
+  return job.status == 0 ? MODLE_HIP_OK : MODLE_HIP_ERR_STATE;
+}
+
 }  // extern "C"
