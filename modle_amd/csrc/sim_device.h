@@ -1581,21 +1581,85 @@ MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
         off = wave_prefix_sum_u32(ntr);
         total = wave::bcast(off, 63);
         off -= ntr;
-        if (total > RNG_BLOCK) {
-          c.error = ERR_TRIAL_OVERFLOW;  // more Bernoulli trials in one batch than the ring holds
-          return;
-        }
-        if (total != 0) rng_ensure(c.g, total);
       }
       bool hard = false;
       u32 bpos = 0;
-      const u32 winner = staged_only ? lef_bar_pick<FWD, true>(v, p, c.g, b_lo, b_hi, off, hard, bpos)
-                                     : lef_bar_pick<FWD, false>(v, p, c.g, b_lo, b_hi, off, hard, bpos);
+      u32 winner = 0xFFFFFFFFu;
+      if (total <= RNG_BLOCK) {
+        if (total != 0) rng_ensure(c.g, total);
+        winner = staged_only ? lef_bar_pick<FWD, true>(v, p, c.g, b_lo, b_hi, off, hard, bpos)
+                             : lef_bar_pick<FWD, false>(v, p, c.g, b_lo, b_hi, off, hard, bpos);
+        c.g.pos += total;
+      } else {
+        // More Bernoulli trials in this batch than one block of the PRNG ring serves (dense
+        // barrier annotations with a fractional blocking probability): the lanes are resolved in
+        // rounds, each taking the longest run of lanes (in lane = stream order) whose trials fit
+        // one block; a single unit with more trials than that is replayed sequentially.
+        u64 pend = wave::ballot(bnd);
+        u32 base_tr = 0;  // trials consumed by the lanes resolved so far
+#ifdef MODLE_TRACE
+        if (wave::lane() == 0 && getenv("MO_TRACE_TRIALS"))
+          fprintf(stderr, "trial rounds: %u trials in one batch\n", total);
+#endif
+        while (pend != 0) {
+          const bool mine_pending = ((pend >> lane) & 1u) != 0;
+          const bool fits = mine_pending && (off + ntr - base_tr <= RNG_BLOCK);
+          const u64 fm = wave::ballot(fits);
+          if (fm == 0) {
+            const u32 l = static_cast<u32>(wave::ctz64(pend));
+            const u32 lo = wave::bcast(b_lo, l), hi = wave::bcast(b_hi, l);
+            const u32 major_dir = FWD ? DIR_FWD : DIR_REV;
+#ifdef MODLE_TRACE
+            if (wave::lane() == 0 && getenv("MO_TRACE_TRIALS"))
+              fprintf(stderr, "  sequential unit: %u barriers in its window\n", hi - lo);
+#endif
+            u32 w = 0xFFFFFFFFu;
+            bool h = false;
+            for (u32 q = lo; q < hi; ++q) {
+              const u32 b = FWD ? (hi - 1 - (q - lo)) : q;  // reference visiting order
+              const u32 fl = wave::uniform(v.flag<false>(b));
+              if (!(fl & 1u)) continue;
+              const f64 pb = (fl >> 1) == major_dir ? p.pblock_major : p.pblock_minor;
+              bool hit;
+              if (pb == 1.0) {
+                hit = true;
+              } else if (pb == 0.0) {
+                hit = false;
+              } else {
+                hit = bernoulli_raw(rng_next(c.g), pb);
+              }
+              if (hit) {
+                w = b;
+                h = (fl >> 1) == major_dir;
+              }
+            }
+            if (lane == l) {
+              winner = w;
+              hard = h;
+              if (w != 0xFFFFFFFFu) bpos = v.pos<false>(w);
+            }
+            base_tr += wave::bcast(ntr, l);
+            pend &= ~(u64(1) << l);
+          } else {
+            // fitting lanes are a run of pending lanes starting at the first one
+            const u32 l_last_fit = static_cast<u32>(63 - wave::clz64(fm));
+            const u32 cnt = wave::bcast(off + ntr, l_last_fit) - base_tr;
+            if (cnt != 0) rng_ensure(c.g, cnt);
+            if (fits) {
+              winner = staged_only
+                           ? lef_bar_pick<FWD, true>(v, p, c.g, b_lo, b_hi, off - base_tr, hard, bpos)
+                           : lef_bar_pick<FWD, false>(v, p, c.g, b_lo, b_hi, off - base_tr, hard, bpos);
+            }
+            c.g.pos += cnt;
+            base_tr += cnt;
+            pend &= ~fm;
+          }
+        }
+      }
       if (winner != 0xFFFFFFFFu) {
         coll[k] = cw_make(winner, EV_COLLISION | EV_LEF_BAR) | (hard ? CW_HARD : 0u);
         barpos[k] = bpos;
       }
-      c.g.pos += total;
       // where the next batch continues: past the last bound unit's window (rev) / below it (fwd)
       const u32 l_last = static_cast<u32>(63 - wave::clz64(bm));
       anchor = FWD ? wave::bcast(b_lo, l_last) : wave::bcast(b_hi, l_last);

@@ -44,6 +44,21 @@ CASES = {
                                  cfg=dict(num_cells=16, target_contact_density=-1.0,
                                           target_simulation_epochs=40, skip_burnin=1,
                                           contact_sampling_strategy=3)),
+    # Bernoulli trials of LEF-BAR detection beyond one PRNG block per batch of 64 units (a barrier
+    # every 100 bp, fractional blocking probabilities): the batch is resolved in rounds
+    "dense_barriers_trials": dict(size=2_000_000, barriers=True, spacing=100,
+                                  cfg=dict(num_cells=8, number_of_lefs_per_mbp=64.0, skip_burnin=1,
+                                           target_contact_density=0.02,
+                                           lef_bar_major_collision_pblock=0.7,
+                                           lef_bar_minor_collision_pblock=0.4)),
+    # ... and beyond one block for a single unit (a barrier every 3 bp: ~800 barriers within one
+    # move): that unit is replayed sequentially
+    "ultra_dense_barriers_trials": dict(size=300_000, barriers=True, spacing=3,
+                                        cfg=dict(num_cells=4, number_of_lefs_per_mbp=40.0,
+                                                 skip_burnin=1, target_contact_density=0.05,
+                                                 diagonal_width=300_000,
+                                                 lef_bar_major_collision_pblock=0.5,
+                                                 lef_bar_minor_collision_pblock=0.5)),
     # a 4 Mb window that ends 10 Mb below the 32-bit position limit of the device layout, on a
     # chromosome longer than any real one: positions above 2^31 (the 64-bit scans of the move
     # adjustment, saturating key arithmetic in LEF-BAR detection)
@@ -67,7 +82,8 @@ def build_case(name):
         nrows, ncols = api.matrix_shape(cfg, end - start)
         return dict(cfg=cfg, chrom=chrom, stp_active=stp_active, stp_inactive=stp_inactive,
                     tasks=tasks, nrows=nrows, ncols=ncols)
-    chrom = synthetic.synthetic_chromosome("chrT", spec["size"], with_barriers=spec["barriers"])
+    chrom = synthetic.synthetic_chromosome("chrT", spec["size"], with_barriers=spec["barriers"],
+                                           spacing=spec.get("spacing", synthetic.BARRIER_SPACING_BP))
     stp_active, stp_inactive = api.barrier_stps(cfg, chrom["bar_occupancy"])
     tasks = api.make_tasks(cfg, chrom["name"], chrom["size"], chrom["start"], chrom["end"])
     nrows, ncols = api.matrix_shape(cfg, chrom["end"] - chrom["start"])

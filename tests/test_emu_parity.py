@@ -10,7 +10,9 @@ from parity_cases import assert_same_outputs, assert_same_results, build_case
 @pytest.mark.parametrize("name,ncells", [("config0_5mb_nobarriers", 2), ("chr6mb_skip_burnin", 1),
                                          ("chr8mb_loop_only", 1), ("tiny_single_lef", 3),
                                          ("zero_target_cells", 6), ("epochs_stop_tad_only", 1),
-                                         ("window_near_position_limit", 1)])
+                                         ("window_near_position_limit", 1),
+                                         ("dense_barriers_trials", 1),
+                                         ("ultra_dense_barriers_trials", 1)])
 def test_emulated_device_code_matches_oracle(oracle, name, ncells):
     case = build_case(name)
     cfg, chrom = case["cfg"], case["chrom"]
