@@ -55,6 +55,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["grch38", "chr1"], default="grch38")
+    ap.add_argument("--chrom", default=None,
+                    help="diagnostic: restrict the grch38 workload to one chromosome (e.g. chr21)")
     ap.add_argument("--cells", type=int, default=None, help="cells per GPU (weak scaling)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--total-cells", type=int, default=None,
@@ -167,7 +169,11 @@ def main():
         cells_per_gpu = args.cells or default_cells
         total_cells = cells_per_gpu * world
         cells_txt = f"{cells_per_gpu} cells per GPU"
-    if args.workload == "grch38":
+    if args.workload == "grch38" and args.chrom:
+        genome = synthetic.grch38_like(seed=42, chroms={args.chrom})
+        workload = f"{args.chrom}-shaped interval only (diagnostic), {cells_txt}, reference defaults"
+        unit = f"{args.chrom}-cells/s"
+    elif args.workload == "grch38":
         genome = synthetic.grch38_like(seed=42)
         workload = (f"GRCh38-shaped genome (24 chromosomes, synthetic H1-like barriers), "
                     f"{cells_txt}, reference defaults (BASELINE configs[2]/[3])")

@@ -261,6 +261,12 @@ int modle_hip_test_phases(modle_hip_handle* h, uint32_t phase_mask, uint64_t sta
 #define MODLE_HIP_UNIT_LOOP_STATS 1u
 #define MODLE_HIP_UNIT_MATRIX_INCREMENT 2u
 #define MODLE_HIP_UNIT_COLLISION_WORDS 3u
+/*   MATH_LOG_EXP      in = bit images of (x, y); out = bit images of (log x, exp y)
+ *   MATH_POW_SQRT     in = bit images of (x, y); out = bit images of (pow(x, y), sqrt x)
+ *                     -- the floating-point routines the device path calls, for bit-for-bit
+ *                     comparison with the oracle's (both compile modle_amd/csrc/modle_math.h) */
+#define MODLE_HIP_UNIT_MATH_LOG_EXP 4u
+#define MODLE_HIP_UNIT_MATH_POW_SQRT 5u
 int modle_hip_test_units(modle_hip_handle* h, uint32_t what, const uint64_t* in, size_t n,
                          uint64_t nrows, uint64_t ncols, uint32_t* contacts,
                          uint64_t* missed_updates, uint64_t* out, char* err, size_t errlen);

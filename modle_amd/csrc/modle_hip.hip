@@ -63,7 +63,7 @@ struct SimArgs {
   u32 n_tasks;
   u32 max_lefs;
   u32 max_barriers;
-  u32 pad_;
+  u32 active_waves;  // waves of every workgroup that pull tasks (diagnostic: MODLE_HIP_ACTIVE_WAVES)
 };
 
 __device__ __forceinline__ Workspace device_carve(char* base, u32 max_lefs, u32 max_barriers, u32 hist_len) {
@@ -151,6 +151,7 @@ __global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs
   const WaveLds lds = make_wave_lds(s, wave_in_block);
   const Workspace ws = device_carve(a.workspace + static_cast<u64>(slot) * a.workspace_stride,
                                     a.max_lefs, a.max_barriers, a.params.hist_len);
+  if (static_cast<u32>(wave_in_block) >= a.active_waves) return;
   for (;;) {
     // Pop one task.  Only lane 0 touches the counter, so this block branches on the lane id; the
     // wave barrier (a convergent operation the optimizer may not duplicate) and the laundered
@@ -666,7 +667,12 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
   a.n_tasks = static_cast<u32>(sorted.size());
   a.max_lefs = max_lefs;
   a.max_barriers = max_barriers;
-  a.pad_ = 0;
+  a.active_waves = kWavesPerBlock;
+  if (const char* aw = std::getenv("MODLE_HIP_ACTIVE_WAVES"); aw != nullptr) {
+    // diagnostic: how the kernel time scales with the waves in flight per CU
+    const int v = std::atoi(aw);
+    if (v >= 1 && v <= kWavesPerBlock) a.active_waves = static_cast<u32>(v);
+  }
   HIP_TRY(hipEventRecord(h->ev_start, h->stream));
   hipLaunchKernelGGL(modle_simulate_cells, dim3(grid), dim3(kThreadsPerBlock), 0, h->stream, a);
   HIP_TRY(hipGetLastError());

@@ -643,6 +643,39 @@ MODLE_DEV_NOINLINE void generate_moves_dir(Cell& c, f64 speed, f64 std) {
   }
 }
 
+// The same when every active LEF is bound (always the case inside the epoch loop: generate_moves
+// runs after select_and_bind_lefs): LEF i takes the i-th accepted draw of the direction, so the
+// moves are a function of the stream alone.  They are stored in LEF-id order with coalesced
+// stores -- no per-LEF state is read -- and the move adjustment, which walks the units in rank
+// order, fetches each unit's move through its LEF id from this freshly written, compact array
+// (instead of this pass scattering 4-byte stores over the rank-ordered array).
+MODLE_DEV_NOINLINE void generate_moves_by_id(Cell& c, f64 speed, f64 std, u32* mv_by_id) {
+  const u32 n = wave::uniform(c.n_active);
+  const u32 lane = wave::lane();
+  if (std == 0.0) {
+    const u32 move_int = static_cast<u32>(static_cast<u64>(wave::f_round(speed)));
+    for (u32 base = 0; base < n; base += 64) {
+      const u32 i = base + lane;
+      if (i < n) mv_by_id[i] = move_int;
+    }
+    return;
+  }
+  const u32* q_move = c.lds.stage;
+  const u32* q_end = c.lds.stage + MOVQ_CAP;
+  u32 head = 0, tail = 0;  // entries consumed / produced
+  for (u32 base = 0; base < n; base += 64) {
+    const u32 need = umin(64u, n - base);
+    while (tail - head < need) tail = draw_moves_step(c, speed, std, tail);
+    if (lane < need) mv_by_id[base + lane] = q_move[(head + lane) % MOVQ_CAP];
+    head += need;
+  }
+  if (head != 0) {
+    // hand back what the last step evaluated beyond the draw of the last LEF
+    const u32 end_low = wave::uniform(q_end[(head - 1) % MOVQ_CAP]);
+    c.g.pos -= static_cast<u32>(static_cast<u32>(c.g.pos) - end_low);
+  }
+}
+
 // =============================================================================================
 // adjust_moves_of_consecutive_extr_units (reference: simulation.cpp:350-407) as two segmented
 // scans over rank order, fused with clamp_moves (reference: simulation.cpp:332-347).
@@ -654,7 +687,10 @@ MODLE_DEV_NOINLINE void generate_moves_dir(Cell& c, f64 speed, f64 std) {
 // update changes the answer are replayed sequentially from the first affected rank.
 // `do_adjust` / `do_clamp` exist for the phase-level test entry point.
 // =============================================================================================
-MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp) {
+// `mv_by_id`: moves in LEF-id order (generate_moves_by_id) or nullptr when they already sit in
+// r_move in rank order (phase-level test entry point).
+MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp,
+                                         const u32* mv_by_id = nullptr) {
   Workspace& ws = c.ws;
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
@@ -664,6 +700,7 @@ MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp)
   const u32* mv_in = ws.r_move;
   u32* mv_out = ws.tmp[0];
   const u32 nbatch = (n + 63) / 64;
+  const bool by_id = mv_by_id != nullptr;
   i64 carry_d = 0;
   bool carry_ok = false, carry_cross = false;
   i64 viol_rank = -1;
@@ -673,20 +710,38 @@ MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp)
   struct UnitRegs {
     u32 P[UX], M[UX];
   };
-  const auto load_units = [&](u32 bg, UnitRegs& r) {
+  struct IdRegs {
+    u32 I[UX];
+  };
+  // the ids of a group are requested one group ahead of its positions and (gathered) moves
+  const auto load_ids = [&](u32 bg, IdRegs& r) {
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const bool in = bg + u < nbatch;
+      const u32 kq = (nbatch - 1 - (bg + u)) * 64 + (63 - lane);
+      r.I[u] = by_id && in && kq < n ? ws.r_id[kq] : 0;
+    }
+  };
+  const auto load_units = [&](u32 bg, const IdRegs& ids, UnitRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const bool in = bg + u < nbatch;
       const u32 kq = (nbatch - 1 - (bg + u)) * 64 + (63 - lane);
       r.P[u] = in && kq < n ? ws.r_pos[kq] : UNBOUND;
-      r.M[u] = in && kq < n ? mv_in[kq] : 0;
+      r.M[u] = in && kq < n ? (by_id ? mv_by_id[ids.I[u]] : mv_in[kq]) : 0;
     }
   };
+  IdRegs ids;
   UnitRegs cur;
-  load_units(0, cur);
+  load_ids(0, ids);
+  load_units(0, ids, cur);
+  if (UX < nbatch) load_ids(UX, ids);
   for (u32 bg = 0; bg < nbatch; bg += UX) {
     const UnitRegs g = cur;
-    if (bg + UX < nbatch) load_units(bg + UX, cur);
+    if (bg + UX < nbatch) {
+      load_units(bg + UX, ids, cur);
+      if (bg + 2 * UX < nbatch) load_ids(bg + 2 * UX, ids);
+    }
     const u32* Pq = g.P;
     const u32* Mq = g.M;
 #pragma unroll
@@ -730,7 +785,7 @@ MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp)
     bool first = true;
     u32 M2u = 0;
     for (u32 i = static_cast<u32>(viol_rank); i > 0; --i) {
-      u32 M1 = mv_in[i - 1];
+      u32 M1 = by_id ? mv_by_id[ws.r_id[i - 1]] : mv_in[i - 1];
       const u64 P1 = ws.r_pos[i - 1], P2 = ws.r_pos[i];
       const bool both = P1 != UNBOUND && P2 != UNBOUND;
       if (both) {
@@ -749,7 +804,8 @@ MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp)
   swap_ptr(ws.r_move, ws.tmp[0]);
 }
 
-MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp) {
+MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp,
+                                         const u32* mv_by_id = nullptr) {
   Workspace& ws = c.ws;
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
@@ -758,6 +814,7 @@ MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp)
   const u32* mv_in = ws.f_move;
   u32* mv_out = ws.tmp[0];
   const u32 nbatch = (n + 63) / 64;
+  const bool by_id = mv_by_id != nullptr;
   i64 carry_d = 0;
   bool carry_ok = false, carry_cross = false;
   i64 viol_rank = -1;
@@ -765,19 +822,35 @@ MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp)
   struct UnitRegs {
     u32 P[UX], M[UX];
   };
-  const auto load_units = [&](u32 bg, UnitRegs& r) {
+  struct IdRegs {
+    u32 I[UX];
+  };
+  const auto load_ids = [&](u32 bg, IdRegs& r) {
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 kq = (bg + u) * 64 + lane;
+      r.I[u] = by_id && kq < n ? ws.f_id[kq] : 0;
+    }
+  };
+  const auto load_units = [&](u32 bg, const IdRegs& ids, UnitRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 kq = (bg + u) * 64 + lane;
       r.P[u] = kq < n ? ws.f_pos[kq] : UNBOUND;
-      r.M[u] = kq < n ? mv_in[kq] : 0;
+      r.M[u] = kq < n ? (by_id ? mv_by_id[ids.I[u]] : mv_in[kq]) : 0;
     }
   };
+  IdRegs ids;
   UnitRegs cur;
-  load_units(0, cur);
+  load_ids(0, ids);
+  load_units(0, ids, cur);
+  if (UX < nbatch) load_ids(UX, ids);
   for (u32 bg = 0; bg < nbatch; bg += UX) {
     const UnitRegs g = cur;
-    if (bg + UX < nbatch) load_units(bg + UX, cur);
+    if (bg + UX < nbatch) {
+      load_units(bg + UX, ids, cur);
+      if (bg + 2 * UX < nbatch) load_ids(bg + 2 * UX, ids);
+    }
     const u32* Pq = g.P;
     const u32* Mq = g.M;
 #pragma unroll
@@ -819,7 +892,7 @@ MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp)
     bool first = true;
     u32 M1u = 0;
     for (u32 i = static_cast<u32>(viol_rank) + 1; i < n; ++i) {
-      u32 M2 = mv_in[i];
+      u32 M2 = by_id ? mv_by_id[ws.f_id[i]] : mv_in[i];
       const u64 P1 = ws.f_pos[i - 1], P2 = ws.f_pos[i];
       const bool both = P1 != UNBOUND && P2 != UNBOUND;
       if (both) {
@@ -838,12 +911,24 @@ MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp)
   swap_ptr(ws.f_move, ws.tmp[0]);
 }
 
-MODLE_DEV void phase_generate_moves(Cell& c, bool burnin_completed) {
+// `all_bound`: every active LEF is bound (the epoch loop's invariant at this point)
+MODLE_DEV void phase_generate_moves(Cell& c, bool burnin_completed, bool all_bound = true) {
   const Params& p = *c.p;
-  PHASE(c, 5, generate_moves_dir<false>(c, burnin_completed ? p.rev_speed : p.rev_speed_burnin, p.rev_std);
-        generate_moves_dir<true>(c, burnin_completed ? p.fwd_speed : p.fwd_speed_burnin, p.fwd_std);
+  if (!all_bound) {
+    PHASE(c, 5, generate_moves_dir<false>(c, burnin_completed ? p.rev_speed : p.rev_speed_burnin, p.rev_std);
+          generate_moves_dir<true>(c, burnin_completed ? p.fwd_speed : p.fwd_speed_burnin, p.fwd_std);
+          wave::sync_mem());
+    PHASE(c, 6, adjust_moves_rev(c, true, true); adjust_moves_fwd(c, true, true));
+    return;
+  }
+  // id-ordered moves live in scratch that is idle until the secondary pass lists its avoided
+  // collisions there
+  u32* mv_rev = c.ws.tmp[5];
+  u32* mv_fwd = c.ws.tmp[6];
+  PHASE(c, 5, generate_moves_by_id(c, burnin_completed ? p.rev_speed : p.rev_speed_burnin, p.rev_std, mv_rev);
+        generate_moves_by_id(c, burnin_completed ? p.fwd_speed : p.fwd_speed_burnin, p.fwd_std, mv_fwd);
         wave::sync_mem());
-  PHASE(c, 6, adjust_moves_rev(c, true, true); adjust_moves_fwd(c, true, true));
+  PHASE(c, 6, adjust_moves_rev(c, true, true, mv_rev); adjust_moves_fwd(c, true, true, mv_fwd));
 }
 
 // =============================================================================================
@@ -3099,7 +3184,14 @@ MODLE_DEV u32 run_test_phases(const Params& p, const Interval& iv, const Workspa
     rank_update<false>(c, true);
     rank_update<true>(c, true);
   }
-  if (mask & PH_GEN_MOVES) phase_generate_moves(c, true);
+  if (mask & PH_GEN_MOVES) {
+    bool unbound = false;
+    for (u32 base = 0; base < n; base += 64) {
+      const u32 k = base + lane;
+      unbound = wave::any(k < n && c.ws.epoch[k] == UNBOUND) || unbound;
+    }
+    phase_generate_moves(c, true, !unbound);
+  }
   if (mask & (PH_ADJUST | PH_CLAMP)) {
     adjust_moves_rev(c, (mask & PH_ADJUST) != 0, (mask & PH_CLAMP) != 0);
     adjust_moves_fwd(c, (mask & PH_ADJUST) != 0, (mask & PH_CLAMP) != 0);
@@ -3170,7 +3262,8 @@ MODLE_DEV u32 run_test_phases(const Params& p, const Interval& iv, const Workspa
 // (test/units/stats/descriptive_test.cpp, test/units/contact_matrix/*_test.cpp,
 // test/units/simulation_cpu/collision_encoding_test.cpp), run by the device code itself.
 // =============================================================================================
-constexpr u32 UNIT_LOOP_STATS = 1, UNIT_MATRIX_INCREMENT = 2, UNIT_COLLISION_WORDS = 3;
+constexpr u32 UNIT_LOOP_STATS = 1, UNIT_MATRIX_INCREMENT = 2, UNIT_COLLISION_WORDS = 3,
+              UNIT_MATH_LOG_EXP = 4, UNIT_MATH_POW_SQRT = 5;
 
 // predicates of one collision word, packed: bit 0 collision_occurred(), bit 1 collision_avoided(),
 // bits 2..5 collision_occurred(CHROM_BOUNDARY / LEF_BAR / LEF_LEF_PRIMARY / LEF_LEF_SECONDARY),
@@ -3226,6 +3319,19 @@ MODLE_DEV u32 run_test_units(const Params& p, const Interval& iv, const Workspac
         const u32 w = cw_make(static_cast<u32>(in[2 * k]), static_cast<u32>(in[2 * k + 1]));
         out[2 * k] = (static_cast<u64>(cw_event(w)) << 56) | cw_index(w);
         out[2 * k + 1] = cw_predicates(w);
+      }
+    }
+  } else if (what == UNIT_MATH_LOG_EXP || what == UNIT_MATH_POW_SQRT) {
+    // pairs (bits of x, bits of y): out = (log x, exp y) or (pow(x, y), sqrt x), as bit images:
+    // the floating-point library the path uses (wave::f_*), evaluated per lane
+    for (u32 base = 0; base < n; base += 64) {
+      const u32 k = base + lane;
+      if (k < n) {
+        const f64 x = __builtin_bit_cast(f64, in[2 * k]), y = __builtin_bit_cast(f64, in[2 * k + 1]);
+        const f64 a = what == UNIT_MATH_LOG_EXP ? wave::f_log(x) : wave::f_pow(x, y);
+        const f64 b = what == UNIT_MATH_LOG_EXP ? wave::f_exp(y) : wave::f_sqrt(x);
+        out[2 * k] = __builtin_bit_cast(u64, a);
+        out[2 * k + 1] = __builtin_bit_cast(u64, b);
       }
     }
   } else {

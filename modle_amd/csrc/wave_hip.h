@@ -9,6 +9,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// software log / exp / pow shared with the CPU oracle (parity by construction, modle_math.h)
+#define MM_FN __device__ inline
+#define MM_TABLE __device__ static const
+#include "modle_math.h"
+
 #define MODLE_DEV __device__ __forceinline__
 // a real call even in the default build (large, rarely changing helpers: keeps the kernel small)
 #define MODLE_DEV_CALL __device__ __noinline__
@@ -176,9 +181,11 @@ MODLE_DEV void atomic_add_u64(uint64_t* p, uint64_t v) {
 }
 MODLE_DEV uint32_t atomic_fetch_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 
-MODLE_DEV double f_log(double x) { return ::log(x); }
-MODLE_DEV double f_exp(double x) { return ::exp(x); }
-MODLE_DEV double f_pow(double x, double y) { return ::pow(x, y); }
+// log / exp / pow are the shared software routines of modle_math.h (the same source the oracle
+// compiles), as real calls: ~15 call sites, most of them in rarely taken branches
+MODLE_DEV_CALL double f_log(double x) { return mm_log(x); }
+MODLE_DEV_CALL double f_exp(double x) { return mm_exp(x); }
+MODLE_DEV_CALL double f_pow(double x, double y) { return mm_pow(x, y); }
 MODLE_DEV double f_sqrt(double x) { return ::sqrt(x); }
 MODLE_DEV double f_floor(double x) { return ::floor(x); }
 MODLE_DEV double f_round(double x) { return ::round(x); }

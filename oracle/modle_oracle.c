@@ -14,6 +14,10 @@
 #include <string.h>
 
 #include "zig_tables.h"
+/* log / exp / pow: the reference calls glibc here.  The oracle and the device code compile the
+ * SAME software routines (modle_amd/csrc/modle_math.h) so that every decision that
+ * depends on them is identical on both sides by construction; sqrt is IEEE-exact everywhere. */
+#include "../modle_amd/csrc/modle_math.h"
 
 /* debugging aid: MO_TRACE=1 prints one line per epoch (epoch, raws drawn, position sums) */
 static int mo_trace_enabled(void) {
@@ -150,7 +154,7 @@ static double unit_exponential(mo_prng_t* g) {
       const double y_above_ubound = (ZIG_EXP_X[i] - ZIG_EXP_X[i + 1]) * y01 - (ZIG_EXP_X[i] - x);
       const double y_above_lbound =
           y - (ZIG_EXP_Y[i + 1] + (ZIG_EXP_X[i + 1] - x) * ZIG_EXP_Y[i + 1]);
-      if (y_above_ubound < 0 && (y_above_lbound < 0 || y < exp(-x))) return x + shift;
+      if (y_above_ubound < 0 && (y_above_lbound < 0 || y < mm_exp(-x))) return x + shift;
     }
   }
 }
@@ -184,7 +188,7 @@ static double unit_normal(mo_prng_t* g) {
       y_above_lbound = chord;
       y_above_ubound = tangent;
     }
-    if (y_above_ubound < 0 && (y_above_lbound < 0 || y < exp(-(x * x / 2)))) return x * sign;
+    if (y_above_ubound < 0 && (y_above_lbound < 0 || y < mm_exp(-(x * x / 2)))) return x * sign;
   }
 }
 
@@ -206,7 +210,7 @@ uint64_t mo_poisson(mo_prng_t* g, double mean) {
                                       10.604602902745251,
                                       12.801827480081469};
   if (mean < 10) {
-    double p = exp(-mean);
+    double p = mm_exp(-mean);
     uint64_t x = 0;
     double u = mo_uniform_01(g);
     while (u > p) {
@@ -241,12 +245,12 @@ uint64_t mo_poisson(mo_prng_t* g, double mean) {
     v = v * inv_alpha / (a / (us * us) + b);
     const double log_sqrt_2pi = 0.91893853320467267;
     if (k >= 10) {
-      if (log(v * smu) <= (k + 0.5) * log(mean / k) - mean - log_sqrt_2pi + k -
+      if (mm_log(v * smu) <= (k + 0.5) * mm_log(mean / k) - mean - log_sqrt_2pi + k -
                               (1 / 12. - (1 / 360. - 1 / (1260. * k * k)) / (k * k)) / k) {
         return (uint64_t)k;
       }
     } else if (k >= 0) {
-      if (log(v) <= k * log(mean) - mean - log_fact[(int)k]) return (uint64_t)k;
+      if (mm_log(v) <= k * mm_log(mean) - mean - log_fact[(int)k]) return (uint64_t)k;
     }
   }
 }
@@ -284,7 +288,7 @@ int64_t mo_binomial(mo_prng_t* g, int64_t t, double p_) {
   const double p = (0.5 < p_) ? (1 - p_) : p_;
   const int64_t m = (int64_t)((double)(t + 1) * p);
   if (m < 11) {
-    const double q_n = pow(1 - p, (double)t);
+    const double q_n = mm_pow(1 - p, (double)t);
     const int64_t x = binom_invert(g, t, p, q_n);
     return (0.5 < p_) ? t - x : x;
   }
@@ -337,17 +341,17 @@ int64_t mo_binomial(mo_prng_t* g, int64_t t, double p_) {
       if (v <= f) break;
       continue;
     }
-    v = log(v);
+    v = mm_log(v);
     const double rho = (km / npq) * (((km / 3. + 0.625) * km + 1. / 6) / npq + 0.5);
     const double tt = -km * km / (2 * npq);
     if (v < tt - rho) break;
     if (v > tt + rho) continue;
     const int64_t nm = t - m + 1;
     const double h =
-        ((double)m + 0.5) * log((double)(m + 1) / (r * (double)nm)) + binom_fc(m) + binom_fc(t - m);
+        ((double)m + 0.5) * mm_log((double)(m + 1) / (r * (double)nm)) + binom_fc(m) + binom_fc(t - m);
     const int64_t nk = t - k + 1;
-    if (v <= h + (double)(t + 1) * log((double)nm / (double)nk) +
-                 ((double)k + 0.5) * log((double)nk * r / (double)(k + 1)) - binom_fc(k) -
+    if (v <= h + (double)(t + 1) * mm_log((double)nm / (double)nk) +
+                 ((double)k + 0.5) * mm_log((double)nk * r / (double)(k + 1)) - binom_fc(k) -
                  binom_fc(t - k)) {
       break;
     }
@@ -357,8 +361,8 @@ int64_t mo_binomial(mo_prng_t* g, int64_t t, double p_) {
 
 /* genextreme_value_distribution<double> (genextreme_value_distribution.hpp:87-105) */
 double mo_genextreme(mo_prng_t* g, double mu, double sigma, double xi) {
-  if (xi == 0.0) return (mu - sigma) * log(-log(mo_canonical(g)));
-  return mu + (sigma * (1.0 - pow(-log(mo_canonical(g)), xi))) / xi;
+  if (xi == 0.0) return (mu - sigma) * mm_log(-mm_log(mo_canonical(g)));
+  return mu + (sigma * (1.0 - mm_pow(-mm_log(mo_canonical(g)), xi))) / xi;
 }
 
 /* ============================================================================================
@@ -566,6 +570,11 @@ double mo_occupancy_from_stp(double stp_active, double stp_inactive) {
   const double tp_a2i = 1.0 - stp_active;
   return clamp01(tp_i2a / (tp_i2a + tp_a2i));
 }
+
+/* the shared software libm, exported for the accuracy / bit-parity tests */
+double mo_math_log(double x) { return mm_log(x); }
+double mo_math_exp(double x) { return mm_exp(x); }
+double mo_math_pow(double x, double y) { return mm_pow(x, y); }
 
 /* ============================================================================================
  * Collision word helpers (collision_encoding_impl.hpp:75-242)

@@ -222,6 +222,10 @@ void mo_generate_moves(const mo_params_t* p, uint64_t start, uint64_t end, size_
 /* ---- whole-cell simulation --------------------------------------------------------------- */
 /* contacts: nrows*ncols+1 uint32 (band layout), accumulated into with atomic adds;
  * missed: updates that fell outside the band; occupancy: ncols uint64 or NULL. */
+/* software log / exp / pow shared with the device code (modle_amd/csrc/modle_math.h) */
+double mo_math_log(double x);
+double mo_math_exp(double x);
+double mo_math_pow(double x, double y);
 /* unit hooks for the reference's stats / contact-matrix / collision-encoding tests */
 void mo_loop_size_stats(size_t n, const uint64_t* rev_pos, const uint64_t* fwd_pos, double* avg,
                         double* ssd, double* var, double* std);

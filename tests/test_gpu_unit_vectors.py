@@ -58,3 +58,30 @@ def test_loop_stats_bit_identical_on_random_loops_gpu(oracle, gpu_backend):
         fwd = rev + rng.integers(0, 3_000_000, size=n).astype(np.uint64)
         a, b = be_o.loop_stats(rev, fwd), gpu_backend.loop_stats(rev, fwd)
         assert a["mean"] == b["mean"] and a["std"] == b["std"], n
+
+
+def test_math_bit_identical_on_gpu(oracle, gpu_backend):
+    """2.4 M arguments shaped like the path's call sites: the GPU's log / exp / pow / sqrt return
+    the oracle's bits (shared software routines; sqrt is IEEE-exact on both sides)."""
+    from test_modle_math import math_lib, oracle_bits, path_arguments
+    from unit_vector_runner import base_config
+
+    L = math_lib(oracle)
+    x, y = path_arguments(np.random.default_rng(5), 20_000)
+    lg, ex, pw = oracle_bits(L, x, y)
+    pairs = np.stack([x.view(np.uint64), y.view(np.uint64)], axis=1)
+    out, _ = gpu_backend._units(base_config(), 4, pairs, 0, 0, None, 0)
+    assert np.array_equal(out[0::2], lg), "log"
+    assert np.array_equal(out[1::2], ex), "exp"
+    out, _ = gpu_backend._units(base_config(), 5, pairs, 0, 0, None, 0)
+    assert np.array_equal(out[0::2], pw), "pow"
+    assert np.array_equal(out[1::2], np.sqrt(x).view(np.uint64)), "sqrt"
+    # a larger sweep of the GEV call: pow(-log(u), xi) and log(u) over canonical draws
+    rng = np.random.default_rng(6)
+    u = rng.random(400_000)
+    u[u == 0] = 0.5
+    xi = np.full_like(u, 0.001)
+    pairs = np.stack([u.view(np.uint64), xi.view(np.uint64)], axis=1)
+    out, _ = gpu_backend._units(base_config(), 4, pairs, 0, 0, None, 0)
+    sample = rng.integers(0, len(u), 5000)
+    assert all(out[2 * i] == np.float64(L.mo_math_log(float(u[i]))).view(np.uint64) for i in sample)

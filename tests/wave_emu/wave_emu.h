@@ -14,6 +14,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "modle_math.h"  // the product's software log / exp / pow
+
 #define MODLE_DEV static inline __attribute__((always_inline))
 #define MODLE_DEV_CALL static __attribute__((noinline))
 #define MODLE_LDS
@@ -201,9 +203,9 @@ MODLE_DEV uint32_t atomic_fetch_add_u32(uint32_t* p, uint32_t v) {
   return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
 }
 
-MODLE_DEV double f_log(double x) { return log(x); }
-MODLE_DEV double f_exp(double x) { return exp(x); }
-MODLE_DEV double f_pow(double x, double y) { return pow(x, y); }
+MODLE_DEV double f_log(double x) { return mm_log(x); }
+MODLE_DEV double f_exp(double x) { return mm_exp(x); }
+MODLE_DEV double f_pow(double x, double y) { return mm_pow(x, y); }
 MODLE_DEV double f_sqrt(double x) { return sqrt(x); }
 MODLE_DEV double f_floor(double x) { return floor(x); }
 MODLE_DEV double f_round(double x) { return round(x); }
