@@ -27,6 +27,11 @@ struct Cell {
   u32 hist_head;  // ring head
   u32 error;      // non-zero when an internal capacity was exceeded (uniform)
   u32 n_hit[2];   // entries of ws.hit_pos / hit_idx (stalling barriers of this epoch; uniform)
+  // LEFs released by release_lefs, in LEF-id order, listed in LDS (lds.sort_lds as REL_CAP
+  // words) for the next epoch's select_and_bind_lefs; rel_valid = the list is complete
+  u32 n_rel;
+  bool rel_valid;
+  u32 n_bound;    // LEFs [0, n_bound) have been bound at least once (the rest were just activated)
 #ifdef MODLE_PHASE_TIMERS
   u64 ph[16];     // profiling build: time spent per phase (wave::clock ticks)
 #endif
@@ -45,6 +50,7 @@ struct Cell {
     __VA_ARGS__;         \
   } while (0)
 #endif
+constexpr u32 REL_CAP = 2 * SORT_LDS_CAP;  // u32 entries in the LDS sort buffer
 constexpr u32 ERR_LIST_OVERFLOW = 1;
 constexpr u32 ERR_TRIAL_OVERFLOW = 2;
 constexpr u32 ERR_INTERNAL = 3;
@@ -150,6 +156,62 @@ MODLE_DEV_NOINLINE void phase_bind(Cell& c, u32 epoch_now) {
     }
     }
   }
+  wave::sync_mem();
+}
+
+// The same from the list release_lefs left in LDS: inside the epoch loop the LEFs to bind are
+// exactly the ones released in the previous epoch (ascending ids) followed by the ones activated
+// since the last bind (ids n_bound .. n_active-1, never ranked: their slots are the identity).
+// No sweep over the LEFs; the ranks of the listed LEFs are the only thing read.
+MODLE_DEV_NOINLINE void phase_bind_listed(Cell& c, u32 epoch_now) {
+  const Interval& iv = *c.iv;
+  Workspace& ws = c.ws;
+  const u32 lane = wave::lane();
+  const u32 n_rel = wave::uniform(c.n_rel);
+  const u32 first_new = wave::uniform(c.n_bound);
+  const u32 total = n_rel + (wave::uniform(c.n_active) - first_new);
+  const u64 range = static_cast<u64>(iv.end) - 1 - iv.start;
+  const u64 bucket = range != 0 ? uniform_int_bucket(range) : 1;
+  const bool fast_div = bucket <= (u64(1) << 62) && bucket >= (u64(1) << 24);
+  const f64 inv_bucket = 1.0 / static_cast<f64>(bucket);
+  const u32* list = reinterpret_cast<const u32*>(c.lds.sort_lds);
+  for (u32 base = 0; base < total; base += 64) {
+    const u32 e = base + lane;
+    const bool act = e < total;
+    const bool listed = e < n_rel;
+    const u32 id = listed ? list[e] : first_new + (e - n_rel);
+    u32 kr = id, kf = id;
+    if (act && listed) {
+      kr = ws.r_rank[id];
+      kf = ws.f_rank[id];
+    }
+    u32 posv = iv.start;
+    if (range != 0) {
+      const u32 cnt = umin(64u, total - base);
+      rng_ensure(c.g, cnt);
+      const u64 raw = rng_peek(c.g, c.g.pos + lane);
+      const u64 r = fast_div ? udiv_by_uniform(raw, bucket, inv_bucket) : raw / bucket;
+      if (wave::any(act && r > range)) {
+        // a draw was rejected (p ~ range / 2^64): replay the batch sequentially
+        for (u32 l = 0; l < cnt; ++l) {
+          const u64 v = uniform_int_exact(c.g, range, bucket);
+          if (lane == l) posv = iv.start + static_cast<u32>(v);
+        }
+      } else {
+        posv = iv.start + static_cast<u32>(r);
+        c.g.pos += cnt;
+      }
+    }
+    if (act) {
+      ws.epoch[id] = epoch_now;
+      ws.r_pos[kr] = posv;
+      ws.r_move[kr] = NEW_MARK;
+      ws.f_pos[kf] = posv;
+      ws.f_move[kf] = NEW_MARK;
+    }
+  }
+  c.n_rel = 0;
+  c.n_bound = c.n_active;
   wave::sync_mem();
 }
 
@@ -2419,8 +2481,11 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
   }
   wave::sync_mem();
   const f64 affinity_soft = 1.0 / p.soft_stall_mult, affinity_hard = 1.0 / p.hard_stall_mult;
+  // Release draws in LEF-id order.  The released LEFs (a few per cent) are listed in LDS; their
+  // units are marked afterwards from the list (the only place their ranks are needed), and the
+  // next epoch's select_and_bind_lefs binds from the same list.
   struct LefRegs {
-    u32 E[UX], H[UX], R[UX], F[UX];
+    u32 E[UX], H[UX];
   };
   const auto load_lefs = [&](u32 group, LefRegs& r) {
 #pragma unroll
@@ -2428,10 +2493,11 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
       const u32 iq = group + 64 * u + lane;
       r.E[u] = iq < n ? ws.epoch[iq] : UNBOUND;
       r.H[u] = iq < n ? ws.stall[iq] : 0;
-      r.R[u] = iq < n ? ws.r_rank[iq] : 0;
-      r.F[u] = iq < n ? ws.f_rank[iq] : 0;
     }
   };
+  u32* list = reinterpret_cast<u32*>(c.lds.sort_lds);
+  u32 n_rel = 0;
+  wave::lockstep();
   LefRegs lcur;
   load_lefs(0, lcur);
   for (u32 group = 0; group < n; group += 64 * UX) {
@@ -2445,8 +2511,6 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
     const bool act = i < n;
     const u32 ep = g.E[u];
     const u32 hard = g.H[u];
-    const u32 kr = g.R[u];
-    const u32 kf = g.F[u];
     const bool bnd = ep != UNBOUND;
     f64 prob = 0.0;
     if (act) {
@@ -2461,11 +2525,31 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
     const u32 k = static_cast<u32>(wave::popc64(dm & lanemask_lt(lane)));
     const bool rel = draws && bernoulli_raw(rng_peek(c.g, c.g.pos + k), prob);
     c.g.pos += cnt;
+    const u64 rm = wave::ballot(rel);
     if (rel) {
       ws.epoch[i] = UNBOUND;
-      ws.r_pos[kr] = UNBOUND;
-      ws.f_pos[kf] = UNBOUND;
+      const u32 j = n_rel + static_cast<u32>(wave::popc64(rm & lanemask_lt(lane)));
+      if (j < REL_CAP) {
+        list[j] = i;
+      } else {
+        // more releases than the list holds (the next bind then sweeps the LEFs instead)
+        ws.r_pos[ws.r_rank[i]] = UNBOUND;
+        ws.f_pos[ws.f_rank[i]] = UNBOUND;
+      }
     }
+    n_rel += static_cast<u32>(wave::popc64(rm));
+    }
+  }
+  wave::sync_lds();
+  c.rel_valid = n_rel <= REL_CAP;
+  c.n_rel = c.rel_valid ? n_rel : 0;
+  const u32 n_listed = umin(n_rel, REL_CAP);
+  for (u32 base = 0; base < n_listed; base += 64) {
+    const u32 e = base + lane;
+    if (e < n_listed) {
+      const u32 id = list[e];
+      ws.r_pos[ws.r_rank[id]] = UNBOUND;
+      ws.f_pos[ws.f_rank[id]] = UNBOUND;
     }
   }
   wave::sync_mem();
@@ -2911,6 +2995,9 @@ MODLE_DEV void init_cell(Cell& c, const Params& p, const Interval& iv, const Wor
   c.error = 0;
   c.n_hit[0] = 0;
   c.n_hit[1] = 0;
+  c.n_rel = 0;
+  c.rel_valid = false;  // the epoch loop turns the list on; the phase-level hooks sweep
+  c.n_bound = 0;
 #ifdef MODLE_PHASE_TIMERS
   for (int i = 0; i < 16; ++i) c.ph[i] = 0;
 #endif
@@ -2926,6 +3013,12 @@ MODLE_DEV void init_cell(Cell& c, const Params& p, const Interval& iv, const Wor
 // a run on the GPU can be compared phase by phase with a run under the CPU lane emulator.
 constexpr u32 TRACE_STAGES = 8;
 constexpr u32 TRACE_WORDS_PER_STAGE = 6;
+// Compiled in only with MODLE_STAGE_TRACE (`make trace`, the emulator build): seven inlined copies
+// of this function are a seventh of the kernel's code, all of it dead weight in the instruction
+// cache of a normal run.
+#ifndef MODLE_STAGE_TRACE
+MODLE_DEV void trace_stage(Cell&, u64, u32) {}
+#else
 MODLE_DEV_NOINLINE void trace_stage(Cell& c, u64 epoch, u32 stage) {
   u64* tr = c.lds.trace;
   if (tr == nullptr || epoch >= c.lds.trace_cap) return;
@@ -2959,6 +3052,7 @@ MODLE_DEV_NOINLINE void trace_stage(Cell& c, u64 epoch, u32 stage) {
     rec[5] = (static_cast<u64>(c.n_active) << 32) | (stage + 1);
   }
 }
+#endif
 
 // Simulates one (interval, cell) task on the calling wave.  Returns 0 or a non-zero status when
 // an internal capacity was exceeded (the host turns that into an error).
@@ -2977,6 +3071,7 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
       static_cast<f64>(task.num_lefs) / static_cast<f64>(p.burnin_target_epochs_for_lef_activation);
 
   barriers_init_states(c);
+  c.rel_valid = true;  // nothing released yet: every LEF to bind is a newly activated one
   if (p.skip_burnin) {
     activate_lefs(c, 0, c.n_lefs);
     burnin_completed = true;
@@ -3010,7 +3105,11 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
         }
       } while (c.n_active == 0);
     }
-    PHASE(c, 1, phase_bind(c, static_cast<u32>(epoch)));
+    PHASE(c, 1, if (c.rel_valid) phase_bind_listed(c, static_cast<u32>(epoch));
+          else {
+            phase_bind(c, static_cast<u32>(epoch));
+            c.n_bound = c.n_active;
+          });
     trace_stage(c, epoch, 0);
     PHASE(c, 2, rank_update<false>(c, false));
     PHASE(c, 3, rank_update<true>(c, false));

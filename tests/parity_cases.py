@@ -59,6 +59,12 @@ CASES = {
                                                  diagonal_width=300_000,
                                                  lef_bar_major_collision_pblock=0.5,
                                                  lef_bar_minor_collision_pblock=0.5)),
+    # more LEFs released in one epoch (~1500 of 2400: processivity of 8 kb against 5 kb moved per
+    # epoch) than the LDS list of released LEFs holds (1024): the overflow path of release_lefs
+    # and the sweeping form of select_and_bind_lefs
+    "mass_release": dict(size=120_000_000, barriers=True,
+                         cfg=dict(num_cells=4, skip_burnin=1, avg_lef_processivity=8000,
+                                  target_contact_density=0.0004)),
     # a 4 Mb window that ends 10 Mb below the 32-bit position limit of the device layout, on a
     # chromosome longer than any real one: positions above 2^31 (the 64-bit scans of the move
     # adjustment, saturating key arithmetic in LEF-BAR detection)
