@@ -710,7 +710,10 @@ MODLE_DEV_NOINLINE void generate_moves_dir(Cell& c, f64 speed, f64 std) {
 // moves are a function of the stream alone.  They are stored in LEF-id order with coalesced
 // stores -- no per-LEF state is read -- and the move adjustment, which walks the units in rank
 // order, fetches each unit's move through its LEF id from this freshly written, compact array
-// (instead of this pass scattering 4-byte stores over the rank-ordered array).
+// (instead of this pass scattering 4-byte stores over the rank-ordered array).  Measured on one
+// box against the scattering form: 23 % fewer bytes written to the fabric and a kernel 0.7 %
+// faster -- the adjustment pass itself takes twice as long (dependent gathers), every other pass
+// gains from the lighter write traffic.
 MODLE_DEV_NOINLINE void generate_moves_by_id(Cell& c, f64 speed, f64 std, u32* mv_by_id) {
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
