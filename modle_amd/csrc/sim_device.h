@@ -296,8 +296,8 @@ MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 aq = group + 64 * u + lane;
-      r.P[u] = aq < n_old ? old_pos[aq] : UNBOUND;
-      r.I[u] = aq < n_old ? old_id[aq] : 0;
+      r.P[u] = aq < n_old ? wave::ld_stream(&old_pos[aq]) : UNBOUND;
+      r.I[u] = aq < n_old ? wave::ld_stream(&old_id[aq]) : 0;
     }
   };
   KeptRegs cur;
@@ -356,8 +356,8 @@ MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_
           tie = lo < n_new && static_cast<u32>(keys[lo] >> 32) == pp;
         }
       }
-      out_pos[a + lo] = pp;
-      out_id[a + lo] = oid;
+      wave::st_stream(&out_pos[a + lo], pp);
+      wave::st_stream(&out_id[a + lo], oid);
       where_new[oid] = a + lo;
     }
     const u32 prev_in = wave::shfl_up1(pp);
@@ -387,8 +387,8 @@ MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_
         }
       }
       const u32 nid = new_id[static_cast<u32>(key)];
-      out_pos[bq + lo] = pp;
-      out_id[bq + lo] = nid;
+      wave::st_stream(&out_pos[bq + lo], pp);
+      wave::st_stream(&out_id[bq + lo], nid);
       where_new[nid] = bq + lo;
       tie = bq + 1 < n_new && static_cast<u32>(keys[bq + 1] >> 32) == pp;
     }
@@ -429,9 +429,9 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 kq = group + 64 * u + lane;
-      r.P[u] = kq < n ? pos[kq] : 0;
-      r.I[u] = kq < n ? ids[kq] : 0;
-      r.K[u] = kq < n ? marks[kq] : 0;
+      r.P[u] = kq < n ? wave::ld_stream(&pos[kq]) : 0;
+      r.I[u] = kq < n ? wave::ld_stream(&ids[kq]) : 0;
+      r.K[u] = kq < n ? wave::ld_stream(&marks[kq]) : 0;
     }
   };
   UnitRegs cur;
@@ -469,8 +469,8 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
     }
     if (is_old) {
       const u32 j = n_old + static_cast<u32>(wave::popc64(mo & lanemask_lt(lane)));
-      old_id[j] = id;
-      old_pos[j] = P;
+      wave::st_stream(&old_id[j], id);
+      wave::st_stream(&old_pos[j], P);
     }
     n_new += static_cast<u32>(wave::popc64(mn));
     n_old += static_cast<u32>(wave::popc64(mo));
@@ -830,7 +830,7 @@ MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp,
     u32 Mnew = M;
     if (okself) Mnew = P - static_cast<u32>(val + static_cast<i64>(k));
     const bool cross = okself && static_cast<u64>(P) <= start + Mnew;
-    if (act) mv_out[k] = (bnd && do_clamp) ? umin(Mnew, P - static_cast<u32>(start)) : Mnew;
+    if (act) wave::st_stream(&mv_out[k], (bnd && do_clamp) ? umin(Mnew, P - static_cast<u32>(start)) : Mnew);
     const bool cross_next_in = wave::shfl_up1(cross);
     const bool cross_next = lane > 0 ? cross_next_in : carry_cross;
     const u64 vm = wave::ballot(link && cross_next);
@@ -939,7 +939,7 @@ MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp,
     u32 Mnew = M;
     if (okself) Mnew = static_cast<u32>(val + static_cast<i64>(k) - static_cast<i64>(P));
     const bool cross = okself && static_cast<u64>(P) + Mnew > last;
-    if (act) mv_out[k] = (bnd && do_clamp) ? umin(Mnew, static_cast<u32>(last - P)) : Mnew;
+    if (act) wave::st_stream(&mv_out[k], (bnd && do_clamp) ? umin(Mnew, static_cast<u32>(last - P)) : Mnew);
     const bool cross_prev_in = wave::shfl_up1(cross);
     const bool cross_prev = lane > 0 ? cross_prev_in : carry_cross;
     const u64 vm = wave::ballot(link && cross_prev);
@@ -2471,8 +2471,8 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
     for (u32 u = 0; u < UX; ++u) {
       const u32 k = base + 64 * u + lane;
       if (k < n) {
-        if (g.rP[u] != UNBOUND) ws.r_pos[k] = g.rP[u] - g.rM[u];
-        if (g.fP[u] != UNBOUND) ws.f_pos[k] = g.fP[u] + g.fM[u];
+        if (g.rP[u] != UNBOUND) wave::st_stream(&ws.r_pos[k], g.rP[u] - g.rM[u]);
+        if (g.fP[u] != UNBOUND) wave::st_stream(&ws.f_pos[k], g.fP[u] + g.fM[u]);
         if (g.rc[u] != 0) ws.r_coll[k] = 0;
         if (g.fc[u] != 0) ws.f_coll[k] = 0;
         if (g.rP[u] != UNBOUND && cw_occurred_as(g.rc[u], EV_LEF_BAR) && (g.rc[u] & CW_HARD))

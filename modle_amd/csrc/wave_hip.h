@@ -171,6 +171,20 @@ MODLE_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // constant-rate (100 MHz) timestamp, for the profiling build
 MODLE_DEV uint64_t clock() { return wall_clock64(); }
 
+// Streaming accesses of the rank-ordered sweeps (read once / written once per pass): with
+// MODLE_NT they carry the non-temporal hint, so that they do not push the lines the scattered
+// 4-byte stores keep coming back to out of L2.
+#ifdef MODLE_NT
+template <class T>
+MODLE_DEV T ld_stream(const T* p) { return __builtin_nontemporal_load(p); }
+template <class T>
+MODLE_DEV void st_stream(T* p, T v) { __builtin_nontemporal_store(v, p); }
+#else
+template <class T>
+MODLE_DEV T ld_stream(const T* p) { return *p; }
+template <class T>
+MODLE_DEV void st_stream(T* p, T v) { *p = v; }
+#endif
 // word written by another agent (the host) while the kernel runs: bypasses this CU's L1
 MODLE_DEV uint32_t load_agent_u32(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

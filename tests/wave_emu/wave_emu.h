@@ -194,6 +194,10 @@ MODLE_DEV LdsRow lds_load_row(const uint64_t* table, uint32_t v) {
 }
 MODLE_DEV void sched_fence() {}
 
+template <class T>
+MODLE_DEV T ld_stream(const T* p) { return *p; }
+template <class T>
+MODLE_DEV void st_stream(T* p, T v) { *p = v; }
 MODLE_DEV uint32_t load_agent_u32(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
 MODLE_DEV void atomic_inc_u32(uint32_t* p) { __atomic_fetch_add(p, 1u, __ATOMIC_RELAXED); }
 MODLE_DEV void atomic_add_u64(uint64_t* p, uint64_t v) {
