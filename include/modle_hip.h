@@ -186,6 +186,12 @@ int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen);
  * registered before the stop stay in the matrices.  May be called from another host thread than
  * the one that waits.  No-op when nothing is in flight. */
 int modle_hip_cancel(modle_hip_handle* h, char* err, size_t errlen);
+/* Non-blocking: 1 when every task the launch in flight holds for `interval_id` has finished (its
+ * matrix and occupancy track are complete and may be read by other streams, e.g. reduced with
+ * RCCL while the kernel simulates the remaining intervals), 0 when not yet; 1 when nothing is in
+ * flight.  Tasks are started largest interval first, so intervals complete roughly in that order.
+ * The counters live in host-mapped memory: the call touches no stream. */
+int modle_hip_interval_done(modle_hip_handle* h, int interval_id);
 /* Duration of the last simulation kernel, measured with HIP events on the launch stream. */
 int modle_hip_last_kernel_ms(modle_hip_handle* h, float* ms);
 /* Results of the tasks submitted for `interval_id`, in submission order. */

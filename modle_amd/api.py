@@ -180,6 +180,13 @@ class Simulator:
         err = _errbuf()
         _check(self._L.modle_hip_wait(self._h, err, len(err)), err)
 
+    def interval_done(self, interval_id):
+        """True when the launch in flight has finished every task of this interval."""
+        rc = self._L.modle_hip_interval_done(self._h, interval_id)
+        if rc < 0:
+            raise ModleHipError(f"modle_hip_interval_done failed: {rc}")
+        return rc == 1
+
     def cancel(self):
         err = _errbuf()
         _check(self._L.modle_hip_cancel(self._h, err, len(err)), err)

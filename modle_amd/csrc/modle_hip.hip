@@ -54,6 +54,7 @@ struct SimArgs {
   u32* status;        // one word per task
   u32* task_counter;
   const u32* abort_flag;  // raised by modle_hip_cancel while the kernel runs
+  u32* interval_remaining;  // host-visible: tasks of every interval still to finish in this launch
   u64* trace;  // diagnostic per-epoch trace of task 0 (MODLE_HIP_TRACE) or nullptr
   u32 trace_cap;
   u32 pad2_;
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs
   const Workspace ws = device_carve(a.workspace + static_cast<u64>(slot) * a.workspace_stride,
                                     a.max_lefs, a.max_barriers, a.params.hist_len);
   if (static_cast<u32>(wave_in_block) >= a.active_waves) return;
+  u32 finished_interval = 0xFFFFFFFFu;  // interval of the task this wave has just completed
   for (;;) {
     // Pop one task.  Only lane 0 touches the counter, so this block branches on the lane id; the
     // wave barrier (a convergent operation the optimizer may not duplicate) and the laundered
@@ -161,7 +163,15 @@ __global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs
     u32 leader = wave::lane();
     asm volatile("" : "+v"(leader));
     u32 t = 0;
-    if (leader == 0) t = atomicAdd(wave::as_global(a.task_counter), 1u);
+    if (leader == 0) {
+      // the previous task's outputs are complete (release fence at the end of the iteration):
+      // tell the host, which may start reducing that interval's matrix once the count is zero
+      if (finished_interval != 0xFFFFFFFFu)
+        __hip_atomic_fetch_sub(a.interval_remaining + finished_interval, 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+      t = atomicAdd(wave::as_global(a.task_counter), 1u);
+    }
+    finished_interval = 0xFFFFFFFFu;
     t = wave::bcast(t, 0);  // scalar from here on: the queue loop is a scalar loop
     if (t >= a.n_tasks) break;  // every wave leaves once the queue is empty
     if (wave::uniform(wave::load_agent_u32(wave::as_global(a.abort_flag))) != 0) {
@@ -170,6 +180,8 @@ __global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs
       __builtin_memset(&none, 0, sizeof(none));
       wave::as_global(a.results)[t] = none;
       wave::as_global(a.status)[t] = ERR_CANCELLED;
+      finished_interval = wave::as_global(a.tasks)[t].interval;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       continue;
     }
     const Task task = wave::as_global(a.tasks)[t];
@@ -185,6 +197,10 @@ __global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs
     // all lanes store the same words (no lane-dependent branch at the end of the loop body)
     wave::as_global(a.results)[t] = res;
     wave::as_global(a.status)[t] = st;
+    finished_interval = task.interval;
+    // contact increments (memory-side atomics) and the result words are performed before the
+    // completion count of the interval drops
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   }
 }
 
@@ -317,6 +333,9 @@ struct modle_hip_handle {
   DevBuf<u32> d_status;
   DevBuf<u32> d_counter;
   DevBuf<u32> d_abort;
+  u32* h_remaining = nullptr;  // host-mapped per-interval completion counters of the launch
+  u32* d_remaining = nullptr;
+  size_t remaining_cap = 0;
   hipStream_t cancel_stream = nullptr;  // non-blocking: raises the abort word beside the kernel
   bool cancelled = false;
   void* trace_host = nullptr;           // MODLE_HIP_TRACE_SHM mapping, registered once per handle
@@ -396,6 +415,7 @@ void modle_hip_destroy(modle_hip_handle* h) {
   if (h->ev_start != nullptr) (void)hipEventDestroy(h->ev_start);
   if (h->ev_stop != nullptr) (void)hipEventDestroy(h->ev_stop);
   if (h->cancel_stream != nullptr) (void)hipStreamDestroy(h->cancel_stream);
+  if (h->h_remaining != nullptr) (void)hipHostFree(h->h_remaining);
   if (h->trace_host != nullptr) {
     (void)hipHostUnregister(h->trace_host);
     ::munmap(h->trace_host, h->trace_bytes);
@@ -604,6 +624,20 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
   HIP_TRY(h->d_results.ensure(sorted.size()));
   HIP_TRY(h->d_status.ensure(sorted.size()));
   HIP_TRY(h->d_workspace.ensure(layout.total_bytes * n_slots));
+  if (h->remaining_cap < ivs.size()) {
+    if (h->h_remaining != nullptr) (void)hipHostFree(h->h_remaining);
+    h->h_remaining = nullptr;
+    h->remaining_cap = 0;
+    void* hp = nullptr;
+    HIP_TRY(hipHostMalloc(&hp, std::max<size_t>(ivs.size(), 64) * 4, hipHostMallocMapped));
+    void* dp = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
+    h->h_remaining = static_cast<u32*>(hp);
+    h->d_remaining = static_cast<u32*>(dp);
+    h->remaining_cap = std::max<size_t>(ivs.size(), 64);
+  }
+  for (size_t iv = 0; iv < ivs.size(); ++iv) h->h_remaining[iv] = 0;
+  for (const Task& t : sorted) h->h_remaining[t.interval] += 1;
   HIP_TRY(hipMemcpyAsync(h->d_intervals.p, ivs.data(), ivs.size() * sizeof(Interval),
                          hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_tasks.p, sorted.data(), sorted.size() * sizeof(Task),
@@ -625,6 +659,7 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
   a.status = h->d_status.p;
   a.task_counter = h->d_counter.p;
   a.abort_flag = h->d_abort.p;
+  a.interval_remaining = h->d_remaining;
   a.trace = nullptr;
   a.trace_cap = 0;
   a.pad2_ = 0;
@@ -745,6 +780,15 @@ int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen) {
     }
   }
   return rc;
+}
+
+int modle_hip_interval_done(modle_hip_handle* h, int interval_id) {
+  if (h == nullptr || interval_id < 0 || static_cast<size_t>(interval_id) >= h->intervals.size())
+    return MODLE_HIP_ERR_ARG;
+  if (!h->in_flight) return 1;
+  if (h->h_remaining == nullptr || static_cast<size_t>(interval_id) >= h->remaining_cap) return 0;
+  const volatile u32* p = h->h_remaining + interval_id;
+  return *p == 0 ? 1 : 0;
 }
 
 int modle_hip_last_kernel_ms(modle_hip_handle* h, float* ms) {

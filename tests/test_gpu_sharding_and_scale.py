@@ -120,3 +120,59 @@ def test_chr1_scale_matches_oracle(oracle, skip_burnin, ncells, extra):
         sim.close()
     assert_same_results(ores, gres, "chr1")
     assert_same_outputs((oc, om, oo), (gc, gm, go), "chr1")
+
+
+def test_interval_completion_counters():
+    """modle_hip_interval_done: false for an interval whose cells are still running, true once
+    they have all finished (and for every interval after wait)."""
+    import time
+
+    from modle_amd import api, driver, synthetic
+
+    genome = [synthetic.synthetic_chromosome("chrBig", 60_000_000, seed=1),
+              synthetic.synthetic_chromosome("chrSmall", 1_000_000, seed=2)]
+    cfg = api.make_config(num_cells=4096, seed=3)
+    plan = driver.plan_genome(cfg, genome)
+    for e in plan:  # many long cells on the big interval, a few short ones on the small one
+        e["tasks"] = api.slice_tasks(e["tasks"], 0, 3000 if e["interval"]["name"] == "chrBig" else 8)
+    sim = api.Simulator(cfg, 0)
+    try:
+        ids = driver.enqueue_plan(sim, cfg, plan)
+        assert all(sim.interval_done(i) for i in ids)  # nothing in flight
+        sim.launch()
+        seen_small_first = False
+        t0 = time.time()
+        while not sim.interval_done(ids[0]) and time.time() - t0 < 120:
+            if sim.interval_done(ids[1]):
+                seen_small_first = True
+            time.sleep(0.001)
+        sim.wait()
+        assert all(sim.interval_done(i) for i in ids)
+        # the 8 small cells finish long before the 3000 big ones (two rounds over 2048 waves)
+        assert seen_small_first
+        c_small = sim.copy_outputs(ids[1])[0]
+        assert int(c_small.sum()) == sum(r.num_contacts for r in sim.results(ids[1]))
+    finally:
+        sim.close()
+
+
+def test_bench_runs_under_torch_distributed_run_with_one_rank(tmp_path):
+    """bench.py's own N > 1 code path (RCCL process group, per-interval reduce on a side stream as
+    intervals complete, self-check) with one rank under torch.distributed.run."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+         "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"),
+         "--gpus", "1", "--steps", "2", "--warmup", "1", "--cells", "16", "--no-cpu-baseline"],
+        capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["checked"] is True and d["n_gpus"] == 1 and d["value"] > 0
+    assert d["check"]["tasks"] == 24 * 16 and "side stream" in d["config"]["parallelism"]
