@@ -13,6 +13,9 @@ from ._lib import lib
 from .params import CellResult, Config, Task
 
 
+Config = Config  # re-exported: `api.Config` is the ctypes mirror of modle_hip_config
+
+
 class ModleHipError(RuntimeError):
     pass
 

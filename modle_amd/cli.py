@@ -1,0 +1,222 @@
+"""`modle simulate`-shaped front end over the C ABI.
+
+    python -m modle_amd simulate -c hg38.chrom.sizes -b barriers.bed.xz -o out/prefix [options]
+
+Option names, defaults and the derivation of the dependent parameters follow the reference's
+`modle simulate` (reference: src/modle/cli.cpp:53-602 options, :886-1016 transform_args); the
+task derivation is `run_simulate`'s (src/libmodle/cpu/scheduler_simulate.cpp:43-170) and the
+outputs are the reference's: `<prefix>.cool` and, with the 1-D LEF position track on,
+`<prefix>_lef_1d_occupancy.bw` (cli.cpp:867-882).  Everything heavy is native: parsing and
+task generation in libmodle_hip.so (host), the simulation on the MI355X (one process per GPU;
+under torch.distributed.run the cells are sharded over the ranks and the matrices are summed
+with RCCL), the writers in libmodle_cooler.so.  `-t/--threads` is accepted and ignored."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import api, driver, genome
+from .params import CS_LOOP, CS_NOISIFY, CS_TAD
+
+STRATEGIES = {  # cli.hpp:63-72
+    "tad-only": CS_TAD, "loop-only": CS_LOOP, "tad-plus-loop": CS_TAD | CS_LOOP,
+    "tad-only-with-noise": CS_TAD | CS_NOISIFY, "loop-only-with-noise": CS_LOOP | CS_NOISIFY,
+    "tad-plus-loop-with-noise": CS_TAD | CS_LOOP | CS_NOISIFY,
+}
+
+
+def build_parser():
+    ap = argparse.ArgumentParser(prog="modle_amd", description=__doc__,
+                                 formatter_class=argparse.RawDescriptionHelpFormatter)
+    sub = ap.add_subparsers(dest="command", required=True)
+    p = sub.add_parser("simulate", aliases=["sim"], help="simulate loop extrusion and write a .cool")
+    io = p.add_argument_group("input / output")
+    io.add_argument("-c", "--chrom-sizes", required=True)
+    io.add_argument("-b", "--extrusion-barrier-file", required=True)
+    io.add_argument("-g", "--genomic-intervals", "--chrom-subranges", default=None)
+    io.add_argument("-f", "--force", action="store_true")
+    io.add_argument("-o", "--output-prefix", required=True)
+    io.add_argument("--assembly-name", default="unknown")
+    io.add_argument("-q", "--quiet", action="store_true")
+    io.add_argument("--skip-output", action="store_true")
+    io.add_argument("--simulate-chromosomes-wo-barriers", dest="wo_barriers", action="store_true")
+    io.add_argument("--skip-chromosomes-wo-barriers", dest="wo_barriers", action="store_false")
+    io.add_argument("-t", "--threads", type=int, default=None, help="ignored (the GPU does the work)")
+    io.add_argument("--device", type=int, default=None, help="HIP device (default: LOCAL_RANK or 0)")
+    g = p.add_argument_group("model parameters (reference names; omitted => reference default)")
+    for flags, dest, typ in [
+        (("--lef-density", "--lefs-per-mbp"), "number_of_lefs_per_mbp", float),
+        (("--avg-lef-processivity",), "avg_lef_processivity", int),
+        (("--probability-of-lef-bypass",), "probability_of_extrusion_unit_bypass", float),
+        (("--extrusion-barrier-occupancy",), "extrusion_barrier_occupancy", float),
+        (("--hard-stall-lef-stability-multiplier",), "hard_stall_lef_stability_multiplier", float),
+        (("--soft-stall-lef-stability-multiplier",), "soft_stall_lef_stability_multiplier", float),
+        (("--fwd-extrusion-speed",), "fwd_extrusion_speed", int),
+        (("--rev-extrusion-speed",), "rev_extrusion_speed", int),
+        (("--fwd-extrusion-speed-std",), "fwd_extrusion_speed_std", float),
+        (("--rev-extrusion-speed-std",), "rev_extrusion_speed_std", float),
+        (("--lef-bar-major-collision-prob",), "lef_bar_major_collision_pblock", float),
+        (("--lef-bar-minor-collision-prob",), "lef_bar_minor_collision_pblock", float),
+        (("--extrusion-barrier-bound-stp",), "barrier_occupied_stp", float),
+        (("--extrusion-barrier-not-bound-stp",), "barrier_not_occupied_stp", float),
+        (("--contact-sampling-interval",), "contact_sampling_interval", int),
+        (("-r", "--resolution"), "bin_size", int),
+        (("-w", "--diagonal-width"), "diagonal_width", int),
+        (("--tad-to-loop-contact-ratio",), "tad_to_loop_contact_ratio", float),
+        (("--mu", "--genextr-location"), "genextreme_mu", float),
+        (("--sigma", "--genextr-scale"), "genextreme_sigma", float),
+        (("--xi", "--genextr-shape"), "genextreme_xi", float),
+        (("--target-number-of-epochs",), "target_simulation_epochs", int),
+        (("--target-contact-density",), "target_contact_density", float),
+        (("--ncells",), "num_cells", int),
+        (("--seed",), "seed", int),
+        (("--burnin-target-epochs-for-lef-activation",), "burnin_target_epochs_for_lef_activation", int),
+        (("--burnin-history-length",), "burnin_history_length", int),
+        (("--burnin-smoothing-window-size",), "burnin_smoothing_window_size", int),
+        (("--min-burnin-epochs",), "min_burnin_epochs", int),
+        (("--max-burnin-epochs",), "max_burnin_epochs", int),
+        (("--burnin-extr-speed-coefficient",), "burnin_speed_coefficient", float),
+        (("--probability-normalization-factor",), "probability_normalization_factor", int),
+    ]:
+        g.add_argument(*flags, dest=dest, type=typ, default=None)
+    g.add_argument("--contact-sampling-strategy", choices=sorted(STRATEGIES), default=None)
+    g.add_argument("-s", "--stopping-criterion", choices=["contact-density", "simulation-epochs"],
+                   default="contact-density")
+    g.add_argument("--track-1d-lef-position", dest="track_1d", action="store_true", default=None)
+    g.add_argument("--no-track-1d-lef-position", dest="track_1d", action="store_false")
+    g.add_argument("--skip-burnin", action="store_true")
+    g.add_argument("--interpret-extrusion-barrier-name-as-not-bound-stp", dest="name_as_stp",
+                   action="store_true")
+    g.add_argument("--normalize-probabilities", dest="normalize", action="store_true", default=None)
+    g.add_argument("--no-normalize-probabilities", dest="normalize", action="store_false")
+    p.set_defaults(wo_barriers=False)
+    return ap
+
+
+def config_from_args(a):
+    """reference defaults, the options given on the command line, then Cli::transform_args"""
+    over = {}
+    for k, v in vars(a).items():
+        if v is not None and hasattr(api.Config, k):
+            over[k] = v
+    if a.fwd_extrusion_speed is not None:
+        over["fwd_extrusion_speed_set"] = 1
+    if a.rev_extrusion_speed is not None:
+        over["rev_extrusion_speed_set"] = 1
+    if a.extrusion_barrier_occupancy is not None:
+        if a.barrier_occupied_stp is not None:
+            raise SystemExit("--extrusion-barrier-occupancy excludes --extrusion-barrier-bound-stp")
+        over["extrusion_barrier_occupancy_set"] = 1
+    if a.name_as_stp and a.barrier_not_occupied_stp is not None:
+        raise SystemExit("--interpret-extrusion-barrier-name-as-not-bound-stp excludes "
+                         "--extrusion-barrier-not-bound-stp")
+    if a.contact_sampling_strategy is not None:
+        over["contact_sampling_strategy"] = STRATEGIES[a.contact_sampling_strategy]
+    if a.track_1d is not None:
+        over["track_1d_lef_position"] = int(a.track_1d)
+    if a.normalize is not None:
+        over["normalize_probabilities"] = int(a.normalize)
+    over["skip_burnin"] = int(a.skip_burnin)
+    over["simulate_chromosomes_wo_barriers"] = int(a.wo_barriers)
+    if a.stopping_criterion == "simulation-epochs":
+        # cli.cpp:783-797 + simulation.cpp:1058-1074: epochs mode switches the density target off
+        if a.target_simulation_epochs is None:
+            raise SystemExit("--stopping-criterion=simulation-epochs requires --target-number-of-epochs")
+        if a.target_contact_density is not None:
+            raise SystemExit("--target-contact-density excludes --target-number-of-epochs")
+        over["target_contact_density"] = -1.0
+    elif a.target_simulation_epochs is not None:
+        raise SystemExit("--stopping-criterion=contact-density excludes --target-number-of-epochs")
+    mn, mx = over.get("min_burnin_epochs"), over.get("max_burnin_epochs")
+    if mn is not None and mx is not None and mn > mx:
+        raise SystemExit(f"--min-burnin-epochs={mn} cannot be greater than --max-burnin-epochs={mx}.")
+    return api.make_config(**over)
+
+
+def output_paths(prefix):
+    return prefix + ".cool", prefix + "_lef_1d_occupancy.bw"
+
+
+def simulate(a, log=print):
+    cfg = config_from_args(a)
+    cool_path, bw_path = output_paths(a.output_prefix)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    device = a.device if a.device is not None else int(os.environ.get("LOCAL_RANK", "0"))
+    if not a.skip_output and rank == 0:
+        os.makedirs(os.path.dirname(os.path.abspath(cool_path)), exist_ok=True)
+        for p in (cool_path, bw_path if cfg.track_1d_lef_position else None):
+            if p and os.path.exists(p) and not a.force:
+                raise SystemExit(f"refusing to overwrite {p}: pass --force to overwrite")
+    t0 = time.time()
+    chroms, intervals, stats = genome.import_genome(cfg, a.chrom_sizes, a.extrusion_barrier_file,
+                                                    a.genomic_intervals, a.name_as_stp)
+    log(f"imported {len(chroms)} chromosomes, {len(intervals)} intervals, "
+        f"{stats['barriers_imported']} barriers ({stats['barriers_without_strand']} without strand dropped)")
+    plan = driver.plan_genome(cfg, intervals, rank, world)
+    use_dist = world > 1
+    if use_dist:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(device)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+    sim = api.Simulator(cfg, device)
+    try:
+        ids = driver.enqueue_plan(sim, cfg, plan)
+        n_tasks = sum(len(e["tasks"]) for e in plan if not e["skipped"])
+        log(f"simulating {n_tasks} (interval, cell) tasks on device {device} (rank {rank} of {world})")
+        sim.launch()
+        sim.wait()
+        log(f"simulation kernel: {sim.kernel_ms() / 1e3:.2f} s")
+        matrices, occupancies = [], []
+        for entry, iid in zip(plan, ids):
+            if iid is None:
+                matrices.append(None)
+                occupancies.append(None)
+                continue
+            c, missed, occ = sim.copy_outputs(iid)
+            if use_dist:
+                import torch
+
+                dev = torch.device("cuda", device)
+                tc = torch.from_numpy(c.view(np.int32)).to(dev)
+                to = torch.from_numpy(occ.view(np.int64)).to(dev) if occ is not None else None
+                dist.reduce(tc, dst=0, op=dist.ReduceOp.SUM)
+                if to is not None:
+                    dist.reduce(to, dst=0, op=dist.ReduceOp.SUM)
+                c = tc.cpu().numpy().view(np.uint32)
+                occ = to.cpu().numpy().view(np.uint64) if to is not None else None
+            total = int(c[:entry["nrows"] * entry["ncols"]].astype(np.int64).sum())
+            if rank == 0 and total + missed > 0 and missed / (total + missed) >= 0.01:
+                log(f"warning: {100.0 * missed / (total + missed):.2f}% missing interactions for "
+                    f"{entry['interval']['name']}")  # simulation.cpp:153-157
+            matrices.append(c)
+            occupancies.append(occ)
+    finally:
+        sim.close()
+    if rank == 0 and not a.skip_output:
+        meta = json.dumps({k: v for k, v in vars(a).items() if v is not None and k != "command"},
+                          sort_keys=True)
+        driver.write_cooler(cool_path, cfg, plan, matrices, assembly=a.assembly_name,
+                            generated_by="modle_amd (MI355X)", metadata_json=meta,
+                            force_overwrite=a.force)
+        log(f"written {cool_path}")
+        if cfg.track_1d_lef_position:
+            driver.write_bigwig(bw_path, cfg, plan, occupancies, chroms, force_overwrite=a.force)
+            log(f"written {bw_path}")
+    if use_dist:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+    log(f"done in {time.time() - t0:.1f} s")
+    return 0
+
+
+def main(argv=None):
+    a = build_parser().parse_args(argv)
+    log = (lambda *x: None) if a.quiet else (lambda *x: print(*x, file=sys.stderr, flush=True))
+    return simulate(a, log)

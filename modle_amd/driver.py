@@ -42,6 +42,14 @@ def plan_genome(cfg, genome, rank=0, world=1):
     return plan
 
 
+def interval_stps(cfg, iv):
+    """self-transition probabilities of an interval's barriers: as imported (genome.py), or
+    derived from BED-score-like occupancies (synthetic.py)"""
+    if "bar_stp_active" in iv:
+        return iv["bar_stp_active"], iv["bar_stp_inactive"]
+    return api.barrier_stps(cfg, iv["bar_occupancy"])
+
+
 def enqueue_plan(sim, cfg, plan, device_buffers=None):
     """Registers intervals + tasks of a plan with `sim`.  `device_buffers`: optional list of
     (contacts_ptr, occupancy_ptr) device pointers per plan entry (e.g. torch tensors)."""
@@ -51,7 +59,7 @@ def enqueue_plan(sim, cfg, plan, device_buffers=None):
             ids.append(None)
             continue
         iv = entry["interval"]
-        stp_active, stp_inactive = api.barrier_stps(cfg, iv["bar_occupancy"])
+        stp_active, stp_inactive = interval_stps(cfg, iv)
         dc, do = (None, None) if device_buffers is None else device_buffers[k]
         iid = sim.add_interval(iv["start"], iv["end"], iv["bar_pos"], iv["bar_dir"], stp_active,
                                stp_inactive, dc, do)
@@ -142,3 +150,24 @@ def write_cooler(path, cfg, plan, matrices, assembly="unknown", generated_by="mo
                 continue
             iv = entry["interval"]
             w.append(iv["name"], m, entry["nrows"], entry["ncols"], offset_bp=int(iv["start"]))
+
+
+def write_bigwig(path, cfg, plan, occupancies, chroms=None, force_overwrite=False):
+    """Writes the 1-D LEF occupancy of every simulated interval the way the reference's IO thread
+    does (simulation.cpp:130-141, 170-197): every chromosome of the genome in the header, one
+    range per interval in genome order with values = counts / max(counts) as float32, span = step =
+    bin size.  `occupancies[k]`: uint64 counts of plan entry k (ncols words) or None."""
+    from . import bigwig
+
+    if chroms is None:
+        chroms = []
+        for entry in plan:
+            iv = entry["interval"]
+            if not chroms or chroms[-1][0] != iv["name"]:
+                chroms.append((iv["name"], int(iv["size"])))
+    with bigwig.BigWigWriter(path, chroms, force_overwrite=force_overwrite) as w:
+        for entry, occ in zip(plan, occupancies):
+            if entry["skipped"] or occ is None or entry["ncols"] == 0:
+                continue
+            iv = entry["interval"]
+            w.write_occupancy(iv["name"], occ[:entry["ncols"]], int(cfg.bin_size), int(iv["start"]))
