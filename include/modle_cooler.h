@@ -52,6 +52,14 @@ int modle_cool_append_matrix(modle_cool_file* f, size_t chrom_id, uint64_t offse
  * freed also when an error is returned. */
 int modle_cool_close(modle_cool_file* f, char* err, size_t errlen);
 
+/* Reads the cis contacts of one chromosome back into the band layout (for the evaluator; the
+ * counterpart of hictk's File::fetch in the reference's modle_tools evaluate).  `nrows`: band
+ * width in bins; the band holds min(nrows, ncols) * ncols words.  Pass band = NULL to query the
+ * shape (*ncols_out, *bin_size_out) only.  Contacts beyond the band are summed in *missed_out. */
+int modle_cool_read_band(const char* path, const char* chrom, uint64_t nrows, uint32_t* band,
+                         uint64_t band_words, uint64_t* ncols_out, uint32_t* bin_size_out,
+                         uint64_t* missed_out, char* err, size_t errlen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,15 @@ def build_parser():
     g.add_argument("--normalize-probabilities", dest="normalize", action="store_true", default=None)
     g.add_argument("--no-normalize-probabilities", dest="normalize", action="store_false")
     p.set_defaults(wo_barriers=False)
+    e = sub.add_parser("evaluate", aliases=["eval"],
+                       help="compare two .cool files stripe by stripe (modle_tools evaluate)")
+    e.add_argument("-i", "--input-cooler", required=True, help="the matrix under test")
+    e.add_argument("-r", "--reference-cooler", required=True)
+    e.add_argument("-c", "--chrom-sizes", required=True, help="chromosomes to compare")
+    e.add_argument("-w", "--diagonal-width", type=int, default=3_000_000)
+    e.add_argument("-m", "--metric", choices=["pearson", "spearman", "rmse", "eucl_dist"],
+                   default="pearson")
+    e.add_argument("--exclude-zero-pixels", action="store_true")
     return ap
 
 
@@ -216,7 +225,21 @@ def simulate(a, log=print):
     return 0
 
 
+def evaluate_cmd(a):
+    """prints one JSON object: {chromosome: {vertical: summary, horizontal: summary}}"""
+    from . import evaluate as ev
+
+    cfg = api.make_config()
+    chroms, _, _ = genome.import_genome_text(cfg, genome.read_text(a.chrom_sizes), b"")
+    res = ev.compare_coolers(a.reference_cooler, a.input_cooler, [n for n, _ in chroms],
+                             a.diagonal_width, a.metric, a.exclude_zero_pixels)
+    print(json.dumps({"metric": a.metric, "chromosomes": res}, indent=1))
+    return 0
+
+
 def main(argv=None):
     a = build_parser().parse_args(argv)
+    if a.command in ("evaluate", "eval"):
+        return evaluate_cmd(a)
     log = (lambda *x: None) if a.quiet else (lambda *x: print(*x, file=sys.stderr, flush=True))
     return simulate(a, log)

@@ -293,3 +293,140 @@ extern "C" int modle_cool_close(modle_cool_file* f, char* err, size_t errlen) {
   }
   return MODLE_COOL_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Reading a chromosome's cis contacts back into the band layout (for the evaluator,
+// modle_amd/evaluate.py: the counterpart of what modle_tools evaluate does with
+// hictk::cooler::File::fetch, reference: src/modle_tools/eval.cpp).  Pixels are located through
+// the file's own indexes (chrom_offset -> bin1_offset).
+// ---------------------------------------------------------------------------------------------
+namespace {
+template <class T>
+bool read_all(hid_t file, const char* name, hid_t memtype, std::vector<T>& out) {
+  const hid_t d = H5Dopen2(file, name, H5P_DEFAULT);
+  if (d < 0) return false;
+  const hid_t sp = H5Dget_space(d);
+  const hssize_t n = H5Sget_simple_extent_npoints(sp);
+  out.resize(static_cast<size_t>(n > 0 ? n : 0));
+  const bool ok = n <= 0 || H5Dread(d, memtype, H5S_ALL, H5S_ALL, H5P_DEFAULT, out.data()) >= 0;
+  H5Sclose(sp);
+  H5Dclose(d);
+  return ok;
+}
+template <class T>
+bool read_slice(hid_t file, const char* name, hid_t memtype, hsize_t first, hsize_t count, std::vector<T>& out) {
+  out.resize(count);
+  if (count == 0) return true;
+  const hid_t d = H5Dopen2(file, name, H5P_DEFAULT);
+  if (d < 0) return false;
+  const hid_t fs = H5Dget_space(d);
+  H5Sselect_hyperslab(fs, H5S_SELECT_SET, &first, nullptr, &count, nullptr);
+  const hid_t ms = H5Screate_simple(1, &count, nullptr);
+  const bool ok = H5Dread(d, memtype, ms, fs, H5P_DEFAULT, out.data()) >= 0;
+  H5Sclose(ms);
+  H5Sclose(fs);
+  H5Dclose(d);
+  return ok;
+}
+}  // namespace
+
+extern "C" int modle_cool_read_band(const char* path, const char* chrom, uint64_t nrows,
+                                    uint32_t* band, uint64_t band_words, uint64_t* ncols_out,
+                                    uint32_t* bin_size_out, uint64_t* missed_out, char* err,
+                                    size_t errlen) {
+  if (path == nullptr || chrom == nullptr || nrows == 0) {
+    set_err(err, errlen, "modle_cool_read_band: invalid argument");
+    return MODLE_COOL_ERR_ARG;
+  }
+  const hid_t file = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
+  if (file < 0) {
+    set_err(err, errlen, std::string("unable to open \"") + path + "\"");
+    return MODLE_COOL_ERR_IO;
+  }
+  int rc = MODLE_COOL_OK;
+  do {
+    // chromosome names: fixed-length strings
+    const hid_t d = H5Dopen2(file, "chroms/name", H5P_DEFAULT);
+    if (d < 0) {
+      rc = MODLE_COOL_ERR_IO;
+      break;
+    }
+    const hid_t ft = H5Dget_type(d);
+    const size_t len = H5Tget_size(ft);
+    const hid_t sp = H5Dget_space(d);
+    const hssize_t n = H5Sget_simple_extent_npoints(sp);
+    const size_t mlen = len + 1;  // room for the terminator of the (null-terminated) memory type
+    std::vector<char> names(static_cast<size_t>(n) * mlen + 1, 0);
+    const hid_t mt = H5Tcopy(H5T_C_S1);
+    H5Tset_size(mt, mlen);
+    const bool ok = H5Dread(d, mt, H5S_ALL, H5S_ALL, H5P_DEFAULT, names.data()) >= 0;
+    H5Tclose(mt);
+    H5Sclose(sp);
+    H5Tclose(ft);
+    H5Dclose(d);
+    if (!ok) {
+      rc = MODLE_COOL_ERR_IO;
+      break;
+    }
+    int64_t cid = -1;
+    for (hssize_t i = 0; i < n; ++i) {
+      const std::string nm(names.data() + static_cast<size_t>(i) * mlen, strnlen(names.data() + static_cast<size_t>(i) * mlen, mlen));
+      if (nm == chrom) cid = i;
+    }
+    if (cid < 0) {
+      set_err(err, errlen, std::string("chromosome \"") + chrom + "\" is not in the file");
+      rc = MODLE_COOL_ERR_ARG;
+      break;
+    }
+    std::vector<int64_t> chrom_offset, bin1_offset;
+    if (!read_all(file, "indexes/chrom_offset", H5T_NATIVE_INT64, chrom_offset) ||
+        !read_all(file, "indexes/bin1_offset", H5T_NATIVE_INT64, bin1_offset)) {
+      rc = MODLE_COOL_ERR_IO;
+      break;
+    }
+    const int64_t b0 = chrom_offset[static_cast<size_t>(cid)], b1 = chrom_offset[static_cast<size_t>(cid) + 1];
+    const uint64_t ncols = static_cast<uint64_t>(b1 - b0);
+    if (ncols_out) *ncols_out = ncols;
+    if (bin_size_out) {
+      const hid_t a = H5Aopen(file, "bin-size", H5P_DEFAULT);
+      uint32_t bs = 0;
+      if (a >= 0) {
+        H5Aread(a, H5T_NATIVE_UINT32, &bs);
+        H5Aclose(a);
+      }
+      *bin_size_out = bs;
+    }
+    if (band == nullptr) break;  // shape query
+    const uint64_t rows = std::min<uint64_t>(nrows, ncols);
+    if (band_words < rows * ncols) {
+      set_err(err, errlen, "modle_cool_read_band: band buffer too small");
+      rc = MODLE_COOL_ERR_ARG;
+      break;
+    }
+    std::fill(band, band + rows * ncols, 0u);
+    const hsize_t p0 = static_cast<hsize_t>(bin1_offset[static_cast<size_t>(b0)]);
+    const hsize_t p1 = static_cast<hsize_t>(bin1_offset[static_cast<size_t>(b1)]);
+    std::vector<int64_t> x1, x2;
+    std::vector<int32_t> cn;
+    if (!read_slice(file, "pixels/bin1_id", H5T_NATIVE_INT64, p0, p1 - p0, x1) ||
+        !read_slice(file, "pixels/bin2_id", H5T_NATIVE_INT64, p0, p1 - p0, x2) ||
+        !read_slice(file, "pixels/count", H5T_NATIVE_INT32, p0, p1 - p0, cn)) {
+      rc = MODLE_COOL_ERR_IO;
+      break;
+    }
+    uint64_t missed = 0;
+    for (size_t k = 0; k < cn.size(); ++k) {
+      if (x2[k] >= b1) continue;  // trans pixel
+      const uint64_t i = static_cast<uint64_t>(x2[k] - x1[k]), j = static_cast<uint64_t>(x2[k] - b0);
+      if (i >= rows) {
+        missed += static_cast<uint64_t>(cn[k]);
+        continue;
+      }
+      band[j * rows + i] = static_cast<uint32_t>(cn[k]);
+    }
+    if (missed_out) *missed_out = missed;
+  } while (false);
+  H5Fclose(file);
+  if (rc == MODLE_COOL_ERR_IO) set_err(err, errlen, std::string("HDF5 error while reading \"") + path + "\"");
+  return rc;
+}
