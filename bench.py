@@ -61,6 +61,10 @@ def parse_args():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--total-cells", type=int, default=None,
                     help="cells of the whole job with --scaling strong (default 2048 / 512)")
+    ap.add_argument("--rng", choices=["exact", "philox"], default="exact",
+                    help="exact: the reference's xoshiro256++ stream (default, every parity claim); "
+                         "philox: the counter-based generator policy, a separate line that is not "
+                         "bit-comparable with the reference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=None)
     return ap.parse_args()
@@ -108,7 +112,7 @@ def cpu_baseline(cfg, genome, unit, sample_cells):
         n = min(sample, len(tasks))
         stp_a, stp_i = api.barrier_stps(cfg, iv["bar_occupancy"])
         jobs.append((iv, api.slice_tasks(tasks, 0, n), stp_a, stp_i))
-    oracle.lib()
+    oracle.lib().mo_set_rng_policy(1 if os.environ.get("MODLE_HIP_LIB") == "libmodle_hip_philox.so" else 0)
     t0 = time.perf_counter()
     epochs = 0
     for iv, tasks, stp_a, stp_i in jobs:
@@ -130,6 +134,9 @@ def cpu_baseline(cfg, genome, unit, sample_cells):
 
 def main():
     args = parse_args()
+    if args.rng == "philox":
+        # the policy is a separate build of the library, chosen when modle_amd is imported
+        os.environ["MODLE_HIP_LIB"] = "libmodle_hip_philox.so"
     # stdout carries exactly one line, the JSON result: everything libraries print there while
     # the job runs (RCCL's version banner, for one) goes to stderr instead
     sys.stdout.flush()
@@ -320,7 +327,10 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "simulated cells/sec (whole node), GRCh38 default barriers",
+            "metric": "simulated cells/sec (whole node), GRCh38 default barriers"
+                      + (" [PHILOX generator policy: statistically equivalent output, not the "
+                         "reference's stream]" if args.rng == "philox" else ""),
+            "rng": args.rng,
             "value": total_cells * args.steps / dt,
             "unit": unit,
             "n_gpus": world,

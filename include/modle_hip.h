@@ -259,7 +259,7 @@ int modle_hip_test_phases(modle_hip_handle* h, uint32_t phase_mask, uint64_t sta
  *                     simulation.cpp:795-819; reference vectors: test/units/stats/descriptive_test.cpp)
  *   MATRIX_INCREMENT  in = (row, col) per ContactMatrixDense::increment call; `contacts`
  *                     (uint32[nrows * ncols + 1], band layout) and `missed_updates` are updated in
- *                     place (reference vectors: test/units/contact_matrix/*_test.cpp)
+ *                     place (reference vectors: the contact_matrix unit tests under test/units)
  *   COLLISION_WORDS   in = (index, event); out = (Collision<> word, predicate bits: 0 occurred,
  *                     1 avoided, 2..5 occurred(CHROM_BOUNDARY, LEF_BAR, LEF_LEF_PRIMARY,
  *                     LEF_LEF_SECONDARY), 6..9 avoided(the same)) (reference vectors:

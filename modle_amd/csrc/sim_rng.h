@@ -216,6 +216,7 @@ MODLE_DEV_CALL void rng_gen_block_call(MODLE_LDS u64* ring, const MODLE_LDS u64*
   state[3 * 64 + lane] = j3;
 }
 
+#ifndef MODLE_RNG_PHILOX
 MODLE_DEV void rng_gen_block(Rng& g) {
   wave::lockstep();  // other lanes may still be reading the block that is about to be replaced
   rng_gen_block_call((MODLE_LDS u64*)g.ring, (const MODLE_LDS u64*)g.jump, (MODLE_LDS u64*)g.state,
@@ -240,12 +241,96 @@ MODLE_DEV void rng_init(Rng& g, const u64 state[4]) {
   g.pos = 0;
   wave::sync_lds();
 }
+#else
+// ---------------------------------------------------------------------------------------------
+// PHILOX generator policy (compile-time, -DMODLE_RNG_PHILOX; SURVEY.md H1's second back-end).
+// The cell's stream is counter based: output p of the stream is one half of
+// Philox4x32-10(counter = (p >> 1, c2, c3), key = (k0, k1)), the 128 bits (k0, k1, c2, c3) taken
+// from the task's PRNG state words (so cells keep distinct streams through the same per-cell
+// jump() as in the exact mode).  Every lane computes its outputs directly -- no state, no GF(2)
+// jump table -- and everything downstream (the ring, the draw order, speculate / verify /
+// replay) is unchanged.  Results are NOT comparable bit for bit with the reference's xoshiro
+// stream: this mode is validated statistically (modle_amd/evaluate.py) and bit for bit only
+// against the oracle running the same policy.  Round function and constants: Salmon et al.,
+// "Parallel random numbers: as easy as 1, 2, 3" (SC'11), as implemented by rocRAND's
+// philox4x32_10.
+// ---------------------------------------------------------------------------------------------
+MODLE_DEV void philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1, u32 out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const u64 p0 = static_cast<u64>(0xD2511F53u) * c0;
+    const u64 p1 = static_cast<u64>(0xCD9E8D57u) * c2;
+    const u32 n0 = static_cast<u32>(p1 >> 32) ^ c1 ^ k0;
+    const u32 n1 = static_cast<u32>(p1);
+    const u32 n2 = static_cast<u32>(p0 >> 32) ^ c3 ^ k1;
+    const u32 n3 = static_cast<u32>(p0);
+    c0 = n0;
+    c1 = n1;
+    c2 = n2;
+    c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0;
+  out[1] = c1;
+  out[2] = c2;
+  out[3] = c3;
+}
+
+// one block of the stream; a real call like the xoshiro block generator (it is reached from every
+// phase that draws)
+MODLE_DEV_CALL void rng_philox_block_call(MODLE_LDS u64* ring, u64 key, u64 hi, u64 block_start,
+                                          u32 ring_base) {
+  const u32 lane = wave::lane();
+  const u32 base = ring_base + RNG_CHUNK * lane;
+  const u64 q0 = (block_start + RNG_CHUNK * lane) >> 1;
+#pragma unroll
+  for (u32 t = 0; t < RNG_CHUNK / 2; ++t) {
+    const u64 q = q0 + t;
+    u32 x[4];
+    philox4x32_10(static_cast<u32>(q), static_cast<u32>(q >> 32), static_cast<u32>(hi),
+                  static_cast<u32>(hi >> 32), static_cast<u32>(key), static_cast<u32>(key >> 32), x);
+    ring[base + ((2 * t) ^ (lane & (RNG_CHUNK - 1)))] = (static_cast<u64>(x[1]) << 32) | x[0];
+    ring[base + ((2 * t + 1) ^ (lane & (RNG_CHUNK - 1)))] = (static_cast<u64>(x[3]) << 32) | x[2];
+  }
+}
+
+MODLE_DEV void rng_gen_block(Rng& g) {
+  wave::lockstep();  // other lanes may still be reading the block that is about to be replaced
+  // the stream's identity lives in g.snap[4..5] (LDS): key and the upper counter words
+  const u64 key = wave::uniform(g.snap[4]), hi = wave::uniform(g.snap[5]);
+  rng_philox_block_call((MODLE_LDS u64*)g.ring, key, hi, g.gen_end,
+                        ((static_cast<u32>(g.gen_end) / RNG_BLOCK) & 1u) * RNG_BLOCK);
+  g.gen_end += RNG_BLOCK;
+  wave::sync_lds();
+}
+
+MODLE_DEV void rng_init(Rng& g, const u64 state[4]) {
+  wave::lockstep();
+  if (wave::lane() == 0) {
+    g.snap[0] = state[0];
+    g.snap[1] = state[1];
+    g.snap[2] = state[2];
+    g.snap[3] = state[3];
+    g.snap[4] = state[0] ^ state[2];
+    g.snap[5] = state[1] ^ state[3];
+  }
+  g.gen_end = 0;
+  g.pos = 0;
+  wave::sync_lds();
+}
+#endif
 
 // State of the sequential engine after g.pos outputs (what the reference's PRNG object holds when
 // the cell returns).  The block that contains g.pos is one of the two in the ring (g.pos >
 // g.gen_end - RNG_RING: a block is only generated when a consumer needs outputs beyond
 // gen_end), or the one that has not been generated yet.  Once per cell; uniform.
 MODLE_DEV void rng_final_state(const Rng& g, u64 out[4]) {
+#ifdef MODLE_RNG_PHILOX
+  // counter based: the engine state is the task's seed state, the position is raws_consumed
+  for (int w = 0; w < 4; ++w) out[w] = wave::uniform(g.snap[w]);
+  return;
+#endif
   const u64 q = g.pos / RNG_BLOCK;
   u64 s0, s1, s2, s3;
   if (q * RNG_BLOCK == g.gen_end) {

@@ -43,6 +43,9 @@ def lib():
     L.mo_prng_next.argtypes = [P(Prng)]
     L.mo_prng_next.restype = C.c_uint64
     L.mo_prng_jump.argtypes = [P(Prng)]
+    L.mo_set_rng_policy.argtypes = [C.c_int]
+    L.mo_set_rng_policy.restype = None
+    L.mo_get_rng_policy.restype = C.c_int
     L.mo_bernoulli.argtypes = [P(Prng), C.c_double]
     L.mo_bernoulli.restype = C.c_int
     for name in ("mo_canonical", "mo_uniform_01"):
@@ -155,3 +158,18 @@ def simulate_interval(cfg, start, end, bar_pos, bar_dir, stp_active, stp_inactiv
     if rc != 0:
         raise RuntimeError(f"oracle failed with code {rc}")
     return contacts, missed.value, occ, results
+
+
+class rng_policy:
+    """context manager: run the oracle with the PHILOX generator policy (see modle_oracle.c)"""
+
+    def __init__(self, philox=True):
+        self.philox = philox
+
+    def __enter__(self):
+        self.prev = lib().mo_get_rng_policy()
+        lib().mo_set_rng_policy(1 if self.philox else 0)
+
+    def __exit__(self, *exc):
+        lib().mo_set_rng_policy(self.prev)
+        return False

@@ -46,8 +46,48 @@ void mo_prng_seed(mo_prng_t* g, uint64_t seed) {
   g->count = 0;
 }
 
+/* Generator policy of the in-cell stream (test infrastructure switch, process wide):
+ * 0 = the reference's xoshiro256++ stream (every parity claim), 1 = the counter-based PHILOX
+ * policy of the device code (modle_amd/csrc/sim_rng.h, MODLE_RNG_PHILOX): output p of a cell's
+ * stream is one half of Philox4x32-10(counter = (p >> 1, s1 ^ s3), key = s0 ^ s2).  Seeding and
+ * the per-cell jump() are the same in both policies. */
+static uint64_t xoshiro_step_impl(uint64_t* s);
+static inline uint64_t xoshiro_step(uint64_t* s) { return xoshiro_step_impl(s); }
+static int g_rng_policy = 0;
+void mo_set_rng_policy(int philox) { g_rng_policy = philox; }
+int mo_get_rng_policy(void) { return g_rng_policy; }
+
+static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0;
+    c[1] = n1;
+    c[2] = n2;
+    c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
 uint64_t mo_prng_next(mo_prng_t* g) {
   uint64_t* s = g->s;
+  if (g_rng_policy == 1) {
+    const uint64_t p = g->count++;
+    const uint64_t q = p >> 1, key = s[0] ^ s[2], hi = s[1] ^ s[3];
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+    philox4x32_10(c, (uint32_t)key, (uint32_t)(key >> 32));
+    return (p & 1) ? (((uint64_t)c[3] << 32) | c[2]) : (((uint64_t)c[1] << 32) | c[0]);
+  }
+  ++g->count;
+  return xoshiro_step(s);
+}
+
+static uint64_t xoshiro_step_impl(uint64_t* s) {
   const uint64_t result = rotl64(s[0] + s[3], 23) + s[0];
   const uint64_t t = s[1] << 17;
   s[2] ^= s[0];
@@ -56,7 +96,6 @@ uint64_t mo_prng_next(mo_prng_t* g) {
   s[0] ^= s[3];
   s[2] ^= t;
   s[3] = rotl64(s[3], 45);
-  ++g->count;
   return result;
 }
 
@@ -74,7 +113,7 @@ void mo_prng_jump(mo_prng_t* g) {
         s2 ^= g->s[2];
         s3 ^= g->s[3];
       }
-      (void)mo_prng_next(g);
+      (void)xoshiro_step(g->s); /* the jump is a property of the seed sequence: always xoshiro */
     }
   }
   g->s[0] = s0;

@@ -6,7 +6,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include "modle_bigwig.h"
 #include "modle_cooler.h"
+#include "modle_genome.h"
 #include "modle_hip.h"
 
 int main(int argc, char** argv) {
@@ -41,6 +43,27 @@ int main(int argc, char** argv) {
   modle_hip_handle* h = modle_hip_create(&cfg, 0, err, sizeof(err));
   printf("create %s\n", h != NULL ? "ok" : "refused");
   if (h != NULL) modle_hip_destroy(h);
+  {
+    /* genome import: one chromosome, one barrier */
+    const char* cs = "chrC\t50000\n";
+    const char* bed = "chrC\t100\t120\tb\t0.9\t+\n";
+    modle_genome* g = NULL;
+    if (modle_genome_import(cs, strlen(cs), bed, strlen(bed), NULL, 0, &cfg, 0, &g, err,
+                            sizeof(err)) != MODLE_GENOME_OK) {
+      fprintf(stderr, "genome: %s\n", err);
+      return 6;
+    }
+    modle_genome_interval info;
+    uint64_t bpos = 0;
+    uint8_t bdir = 0;
+    double bsa = 0, bsi = 0;
+    if (modle_genome_interval_info(g, 0, &info) != MODLE_GENOME_OK ||
+        modle_genome_interval_barriers(g, 0, &bpos, &bdir, &bsa, &bsi) != MODLE_GENOME_OK)
+      return 7;
+    printf("genome %zu %" PRIu64 " %" PRIu64 " %u\n", modle_genome_num_chromosomes(g), info.end,
+           bpos, (unsigned)bdir);
+    modle_genome_free(g);
+  }
   if (argc > 1) {
     const char* names[1] = {"chrC"};
     const uint32_t sizes[1] = {50000};
@@ -57,6 +80,14 @@ int main(int argc, char** argv) {
     if (modle_cool_append_matrix(f, 0, 0, band, 2, 5, err, sizeof(err)) != MODLE_COOL_OK) return 4;
     if (modle_cool_close(f, err, sizeof(err)) != MODLE_COOL_OK) return 5;
     printf("cooler ok\n");
+    if (argc > 2) {
+      modle_bw_file* bw = NULL;
+      const uint64_t occ[5] = {1, 4, 0, 2, 4};
+      if (modle_bw_create(argv[2], 1, names, sizes, 1, &bw, err, sizeof(err)) != MODLE_BW_OK) return 8;
+      if (modle_bw_write_occupancy(bw, 0, occ, 5, 10000, 0, err, sizeof(err)) != MODLE_BW_OK) return 9;
+      if (modle_bw_close(bw, err, sizeof(err)) != MODLE_BW_OK) return 10;
+      printf("bigwig ok\n");
+    }
   }
   return 0;
 }

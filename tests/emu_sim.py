@@ -14,8 +14,8 @@ u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
 
 
 def simulate_interval(cfg, start, end, bar_pos, bar_dir, stp_active, stp_inactive, tasks, nrows,
-                      ncols, track_occupancy=True):
-    L = emu_lib()
+                      ncols, track_occupancy=True, variant=None):
+    L = emu_lib(variant)
     L.emu_simulate_interval.argtypes = [C.POINTER(Config), C.c_uint64, C.c_uint64, u64p, u8p,
                                         f64p, f64p, C.c_size_t, C.POINTER(Task), C.c_size_t,
                                         u32p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64),

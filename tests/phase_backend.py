@@ -111,10 +111,18 @@ def _advance(state, n):
 
 
 _emu = None
+_emu_variants = {}
 
 
-def emu_lib():
+def emu_lib(variant=None):
+    """the lane emulator build of the device code; variant "philox" = PHILOX generator policy"""
     global _emu
+    if variant is not None:
+        if variant not in _emu_variants:
+            so = f"libmodle_emu_{variant}.so"
+            subprocess.run(["make", "-C", _EMU_DIR, so], check=True, capture_output=True)
+            _emu_variants[variant] = C.CDLL(os.path.join(_EMU_DIR, so))
+        return _emu_variants[variant]
     if _emu is None:
         subprocess.run(["make", "-C", _EMU_DIR], check=True, capture_output=True)
         L = C.CDLL(os.path.join(_EMU_DIR, "libmodle_emu.so"))

@@ -158,8 +158,8 @@ def test_c11_consumer_compiles_and_agrees_with_the_python_view(tmp_path):
                     "-lmodle_hip", "-lmodle_cooler", "-Wl,-rpath," + libdir,
                     "-Wl,-rpath,/opt/rocm/lib"],
                    check=True, capture_output=True, text=True)
-    cool = str(tmp_path / "c.cool")
-    out = subprocess.run([exe, cool], check=True, capture_output=True, text=True).stdout.split("\n")
+    cool, bw = str(tmp_path / "c.cool"), str(tmp_path / "c.bw")
+    out = subprocess.run([exe, cool, bw], check=True, capture_output=True, text=True).stdout.split("\n")
     cfg = api.make_config(num_cells=4)
     size = 5_000_000
     tasks = api.make_tasks(cfg, "chrC", size, 0, size)
@@ -172,7 +172,9 @@ def test_c11_consumer_compiles_and_agrees_with_the_python_view(tmp_path):
     assert out[7] == "sorted 100 500 900 2 0.8 0.1"
     assert float(out[8].split()[1]) == api.stp_active_from_occupancy(cfg.barrier_not_occupied_stp, 0.85)
     assert out[9] in ("create ok", "create refused")
-    assert out[10] == "cooler ok" and os.path.getsize(cool) > 0
+    assert out[10] == "genome 1 50000 110 2"  # midpoint (100 + 120 + 1) / 2, strand '+' => DIR_REV
+    assert out[11] == "cooler ok" and os.path.getsize(cool) > 0
+    assert out[12] == "bigwig ok" and os.path.getsize(bw) > 0
 
 
 def test_sort_barriers_is_stable_and_matches_the_oracle(oracle):
