@@ -1,5 +1,11 @@
+# One gpurun call that produces everything committed under profiles/<tag>/ for a round:
+#   bench.json                 python bench.py (default workload, with the CPU baseline)
+#   kernel_stats.csv           rocprofv3 --kernel-trace --stats of the same command (+ its bench line)
+#   pmc_*                      separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / L2 hits / SQ)
+#   phase_breakdown.txt        profiling build (per-phase wave time)
+#   bench_chr1_512.json (+ kernel stats)   BASELINE config 1
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${PROFILE_TAG:-r01g}; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${PROFILE_TAG:-r02}; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err; cat $O/bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof.err
 echo trace done
@@ -8,4 +14,9 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES 
   rocprofv3 --pmc $set --output-format csv -d $O/pmc_$tag -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_$tag.json 2> $O/pmc_$tag.err
   echo pmc $tag done
 done
-ls -R $O | head -50
+MODLE_HIP_LIB=libmodle_hip_prof.so python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/bench_prof.json 2> $O/phase_breakdown.txt
+grep -v amdgpu $O/phase_breakdown.txt
+python3 $R/bench.py --workload chr1 --cells 512 > $O/bench_chr1_512.json 2> $O/bench_chr1_512.err; cat $O/bench_chr1_512.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_chr1 -- python3 $R/bench.py --workload chr1 --cells 512 --no-cpu-baseline > $O/bench_chr1_512_under_rocprof.json 2> $O/rocprof_chr1.err
+python3 $R/bench.py --rng philox --no-cpu-baseline > $O/bench_philox.json 2> $O/bench_philox.err; cat $O/bench_philox.json
+ls -R $O | head -60
