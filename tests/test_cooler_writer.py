@@ -235,7 +235,11 @@ def test_cooler_writer_errors(tmp_path):
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(os.path.dirname(__file__), "..", "include", "modle_cooler.h")).read()
     names = set(re.findall(r"\b(modle_cool_[a-z_]+)\s*\(", header))
-    assert names == {"modle_cool_create", "modle_cool_append_matrix", "modle_cool_close"}
+    assert names == {"modle_cool_create", "modle_cool_append_matrix", "modle_cool_close",
+                     "modle_cool_read_band"}
+    bw = open(os.path.join(os.path.dirname(__file__), "..", "include", "modle_bigwig.h")).read()
+    names |= set(re.findall(r"\b(modle_bw_[a-z_]+)\s*\(", bw))
+    assert {"modle_bw_create", "modle_bw_write_range", "modle_bw_write_occupancy", "modle_bw_close"} <= names
     lb = cooler.lib()
     for n in names:
         assert hasattr(lb, n)
