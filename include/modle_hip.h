@@ -186,6 +186,22 @@ int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen);
  * registered before the stop stay in the matrices.  May be called from another host thread than
  * the one that waits.  No-op when nothing is in flight. */
 int modle_hip_cancel(modle_hip_handle* h, char* err, size_t errlen);
+/* --log-model-internal-state (reference: Simulation::dump_stats, simulation.cpp:995-1056, one
+ * record per task and epoch after extrude and before release_lefs).  Only the diagnostic build
+ * libmodle_hip_statelog.so records (the default build returns MODLE_HIP_ERR_UNSUPPORTED for a
+ * non-zero capacity: the recording code stays out of the production kernel).  A record is
+ * MODLE_HIP_STATE_LOG_WORDS words: epoch | burn-in << 63, barriers occupied, active LEFs, units
+ * stalled rev, units stalled fwd, LEFs stalled at both ends, LEF-BAR collisions, primary LEF-LEF
+ * collisions, secondary LEF-LEF collisions, sum of the loop sizes.  Epochs beyond the capacity
+ * are not recorded. */
+#define MODLE_HIP_STATE_LOG_WORDS 10
+int modle_hip_enable_state_log(modle_hip_handle* h, uint32_t max_epochs_per_task, char* err,
+                               size_t errlen);
+/* records of task `task_index` (submission order within the last launch) of `interval_id`, in
+ * epoch order; `records` holds max_epochs * MODLE_HIP_STATE_LOG_WORDS words (NULL to count) */
+int modle_hip_get_state_log(modle_hip_handle* h, int interval_id, size_t task_index,
+                            uint64_t* records, size_t max_epochs, size_t* n_epochs, char* err,
+                            size_t errlen);
 /* Non-blocking: 1 when every task the launch in flight holds for `interval_id` has finished (its
  * matrix and occupancy track are complete and may be read by other streams, e.g. reduced with
  * RCCL while the kernel simulates the remaining intervals), 0 when not yet; 1 when nothing is in

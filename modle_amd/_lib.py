@@ -24,6 +24,7 @@ EXPORTS = [
     "modle_hip_interval_outputs", "modle_hip_copy_outputs", "modle_hip_reset",
     "modle_hip_simulate_interval", "modle_hip_test_phases", "modle_hip_sort_barriers",
     "modle_hip_cancel", "modle_hip_test_units", "modle_hip_interval_done",
+    "modle_hip_enable_state_log", "modle_hip_get_state_log",
 ]
 
 u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
@@ -71,6 +72,9 @@ def lib():
     L.modle_hip_sort_barriers.restype = None
     L.modle_hip_cancel.argtypes = [C.c_void_p] + err
     L.modle_hip_interval_done.argtypes = [C.c_void_p, C.c_int]
+    L.modle_hip_enable_state_log.argtypes = [C.c_void_p, C.c_uint32] + err
+    L.modle_hip_get_state_log.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t,
+                                          P(C.c_size_t)] + err
     L.modle_hip_create.argtypes = [P(Config), C.c_int] + err
     L.modle_hip_create.restype = C.c_void_p
     L.modle_hip_destroy.argtypes = [C.c_void_p]

@@ -183,6 +183,24 @@ class Simulator:
         err = _errbuf()
         _check(self._L.modle_hip_wait(self._h, err, len(err)), err)
 
+    def enable_state_log(self, max_epochs_per_task):
+        """--log-model-internal-state: needs the diagnostic build (MODLE_HIP_LIB=
+        libmodle_hip_statelog.so); the default build refuses"""
+        err = _errbuf()
+        _check(self._L.modle_hip_enable_state_log(self._h, int(max_epochs_per_task), err, len(err)), err)
+        self._state_log_cap = int(max_epochs_per_task)
+
+    def state_log(self, interval_id, task_index):
+        """records of one task of the last launch: uint64 array (n_epochs, 10), see
+        MODLE_HIP_STATE_LOG_WORDS in include/modle_hip.h"""
+        cap = getattr(self, "_state_log_cap", 0)
+        rec = np.zeros((cap, 10), dtype=np.uint64)
+        n = C.c_size_t(0)
+        err = _errbuf()
+        _check(self._L.modle_hip_get_state_log(self._h, interval_id, task_index, rec.ctypes.data, cap,
+                                               C.byref(n), err, len(err)), err)
+        return rec[:n.value]
+
     def interval_done(self, interval_id):
         """True when the launch in flight has finished every task of this interval."""
         rc = self._L.modle_hip_interval_done(self._h, interval_id)

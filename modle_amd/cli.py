@@ -42,6 +42,11 @@ def build_parser():
     io.add_argument("--assembly-name", default="unknown")
     io.add_argument("-q", "--quiet", action="store_true")
     io.add_argument("--skip-output", action="store_true")
+    io.add_argument("--log-model-internal-state", action="store_true",
+                    help="write <prefix>_internal_state.log.gz: one line of statistics per task and "
+                         "epoch (uses the diagnostic build libmodle_hip_statelog.so)")
+    io.add_argument("--internal-state-max-epochs", type=int, default=4096,
+                    help="epochs recorded per task with --log-model-internal-state")
     io.add_argument("--simulate-chromosomes-wo-barriers", dest="wo_barriers", action="store_true")
     io.add_argument("--skip-chromosomes-wo-barriers", dest="wo_barriers", action="store_false")
     io.add_argument("-t", "--threads", type=int, default=None, help="ignored (the GPU does the work)")
@@ -149,6 +154,10 @@ def output_paths(prefix):
     return prefix + ".cool", prefix + "_lef_1d_occupancy.bw"
 
 
+def state_log_path(prefix):
+    return prefix + "_internal_state.log.gz"  # cli.cpp:871-875
+
+
 def simulate(a, log=print):
     cfg = config_from_args(a)
     cool_path, bw_path = output_paths(a.output_prefix)
@@ -175,12 +184,29 @@ def simulate(a, log=print):
         dist.init_process_group("nccl", device_id=torch.device("cuda", device))
     sim = api.Simulator(cfg, device)
     try:
+        if a.log_model_internal_state:
+            sim.enable_state_log(a.internal_state_max_epochs)
         ids = driver.enqueue_plan(sim, cfg, plan)
         n_tasks = sum(len(e["tasks"]) for e in plan if not e["skipped"])
         log(f"simulating {n_tasks} (interval, cell) tasks on device {device} (rank {rank} of {world})")
         sim.launch()
         sim.wait()
         log(f"simulation kernel: {sim.kernel_ms() / 1e3:.2f} s")
+        if a.log_model_internal_state and not a.skip_output:
+            import gzip
+
+            path = state_log_path(a.output_prefix) if world == 1 else \
+                f"{a.output_prefix}_internal_state.rank{rank}.log.gz"
+            with gzip.open(path, "wt") as fh:
+                fh.write(driver.STATE_LOG_HEADER)
+                for entry, iid in zip(plan, ids):
+                    if iid is None:
+                        continue
+                    iv = entry["interval"]
+                    for k, task in enumerate(entry["tasks"]):
+                        fh.writelines(driver.format_state_log(task, iv, len(iv["bar_pos"]),
+                                                              sim.state_log(iid, k)))
+            log(f"written {path}")
         matrices, occupancies = [], []
         for entry, iid in zip(plan, ids):
             if iid is None:
@@ -241,5 +267,14 @@ def main(argv=None):
     a = build_parser().parse_args(argv)
     if a.command in ("evaluate", "eval"):
         return evaluate_cmd(a)
+    if a.log_model_internal_state and not a.skip_output:
+        # the recording code lives in a diagnostic build of the library, chosen at import time
+        from . import _lib
+
+        if _lib._lib is not None and "statelog" not in _lib.SO_PATH:
+            raise SystemExit("--log-model-internal-state needs MODLE_HIP_LIB=libmodle_hip_statelog.so "
+                             "to be set before modle_amd is imported")
+        if _lib._lib is None:
+            _lib.SO_PATH = os.path.join(os.path.dirname(_lib.SO_PATH), "libmodle_hip_statelog.so")
     log = (lambda *x: None) if a.quiet else (lambda *x: print(*x, file=sys.stderr, flush=True))
     return simulate(a, log)

@@ -59,6 +59,9 @@ struct SimArgs {
   u32 trace_cap;
   u32 pad2_;
   u64* phase_ticks;  // profiling build only
+  u64* state_log;    // MODLE_STATE_LOG build: n_tasks x state_log_cap records, or nullptr
+  u32 state_log_cap;
+  u32 pad3_;
   char* workspace;
   u64 workspace_stride;
   u32 n_tasks;
@@ -131,6 +134,8 @@ __device__ __forceinline__ WaveLds make_wave_lds(BlockLds& s, int wave_in_block)
   l.sort_lds = s.sort_keys[wave_in_block];
   l.stage = s.stage[wave_in_block];
   l.phase_ticks = nullptr;
+  l.state_log = nullptr;
+  l.state_log_cap = 0;
   l.trace = nullptr;
   l.trace_cap = 0;
   return l;
@@ -189,6 +194,10 @@ __global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs
     WaveLds lds_t = lds;
     lds_t.phase_ticks = wave::as_global(a.phase_ticks);
     lds_t.abort_flag = wave::as_global(a.abort_flag);
+    if (a.state_log != nullptr) {
+      lds_t.state_log = wave::as_global(a.state_log) + static_cast<u64>(t) * a.state_log_cap * STATE_LOG_WORDS;
+      lds_t.state_log_cap = a.state_log_cap;
+    }
     if (t == 0 && a.trace != nullptr) {
       lds_t.trace = a.trace;
       lds_t.trace_cap = a.trace_cap;
@@ -345,6 +354,8 @@ struct modle_hip_handle {
   DevBuf<u64> d_phase_out;
   DevBuf<u64> d_trace;
   DevBuf<u64> d_phase_ticks;
+  DevBuf<u64> d_state_log;
+  u32 state_log_cap = 0;  // epochs logged per task (0 = off)
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   hipStream_t stream = nullptr;
   bool in_flight = false;
@@ -691,6 +702,16 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
       a.trace_cap = kTraceEpochs;
     }
   }
+  a.state_log = nullptr;
+  a.state_log_cap = 0;
+  a.pad3_ = 0;
+  if (h->state_log_cap != 0) {
+    const size_t words = sorted.size() * static_cast<size_t>(h->state_log_cap) * STATE_LOG_WORDS;
+    HIP_TRY(h->d_state_log.ensure(words));
+    HIP_TRY(hipMemsetAsync(h->d_state_log.p, 0xFF, words * 8, h->stream));
+    a.state_log = h->d_state_log.p;
+    a.state_log_cap = h->state_log_cap;
+  }
   a.phase_ticks = nullptr;
 #ifdef MODLE_PHASE_TIMERS
   HIP_TRY(h->d_phase_ticks.ensure(16));
@@ -780,6 +801,63 @@ int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen) {
     }
   }
   return rc;
+}
+
+int modle_hip_enable_state_log(modle_hip_handle* h, uint32_t max_epochs_per_task, char* err,
+                                size_t errlen) {
+  if (h == nullptr) return MODLE_HIP_ERR_ARG;
+#ifndef MODLE_STATE_LOG
+  if (max_epochs_per_task != 0) {
+    set_err(err, errlen,
+            "this build of the library does not log the model's internal state: load "
+            "libmodle_hip_statelog.so (make -C modle_amd/csrc statelog)");
+    return MODLE_HIP_ERR_UNSUPPORTED;
+  }
+#endif
+  if (h->in_flight) return MODLE_HIP_ERR_STATE;
+  h->state_log_cap = max_epochs_per_task;
+  return MODLE_HIP_OK;
+}
+
+int modle_hip_get_state_log(modle_hip_handle* h, int interval_id, size_t task_index,
+                            uint64_t* records, size_t max_epochs, size_t* n_epochs, char* err,
+                            size_t errlen) {
+  if (h == nullptr || interval_id < 0 || static_cast<size_t>(interval_id) >= h->intervals.size() ||
+      n_epochs == nullptr) {
+    set_err(err, errlen, "invalid arguments");
+    return MODLE_HIP_ERR_ARG;
+  }
+  if (h->in_flight || h->state_log_cap == 0 || h->d_state_log.p == nullptr) {
+    set_err(err, errlen, "no state log available (enable it before the launch, wait for the launch)");
+    return MODLE_HIP_ERR_STATE;
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  // the record block of the task: tasks of the LAST launch, found through the launch map
+  // (launch slot -> (interval, submission index)); `task_index` counts this interval's tasks of
+  // that launch in submission order
+  std::vector<std::pair<size_t, size_t>> mine;  // (submission index, launch slot)
+  for (size_t i = 0; i < h->launch_map.size(); ++i)
+    if (h->launch_map[i].first == interval_id) mine.emplace_back(h->launch_map[i].second, i);
+  std::sort(mine.begin(), mine.end());
+  if (task_index >= mine.size()) {
+    set_err(err, errlen, "task index out of range");
+    return MODLE_HIP_ERR_ARG;
+  }
+  const size_t slot = mine[task_index].second;
+  const size_t block = static_cast<size_t>(h->state_log_cap) * STATE_LOG_WORDS;
+  std::vector<uint64_t> all(block);
+  HIP_TRY(hipMemcpy(all.data(), h->d_state_log.p + slot * block, block * 8, hipMemcpyDeviceToHost));
+  // a record sits at its epoch's index; epochs whose move / collision phase did not run (the
+  // epoch in which the contact target is reached) have none
+  size_t out = 0;
+  for (size_t e = 0; e < h->state_log_cap && out < max_epochs; ++e) {
+    if (all[e * STATE_LOG_WORDS] == ~uint64_t(0)) continue;
+    if (records != nullptr)
+      std::memcpy(records + out * STATE_LOG_WORDS, all.data() + e * STATE_LOG_WORDS, STATE_LOG_WORDS * 8);
+    ++out;
+  }
+  *n_epochs = out;
+  return MODLE_HIP_OK;
 }
 
 int modle_hip_interval_done(modle_hip_handle* h, int interval_id) {

@@ -3057,6 +3057,78 @@ MODLE_DEV_NOINLINE void trace_stage(Cell& c, u64 epoch, u32 stage) {
 }
 #endif
 
+// Model-internal-state record of one epoch (Simulation::dump_stats, reference:
+// simulation.cpp:995-1056; logged after extrude and before release_lefs, :969-975).  Compiled in
+// only with MODLE_STATE_LOG (`make statelog`): the front end loads that build when
+// --log-model-internal-state is given.  Runs BEFORE the fused extrusion / release pass (which
+// consumes the collision words), on positions + moves = the positions after extrusion.
+#ifdef MODLE_STATE_LOG
+MODLE_DEV_NOINLINE void log_internal_state(Cell& c, u64 epoch, bool burnin) {
+  u64* log = c.lds.state_log;
+  if (log == nullptr || epoch >= c.lds.state_log_cap) return;
+  Workspace& ws = c.ws;
+  const u32 n = wave::uniform(c.n_active);
+  const u32 lane = wave::lane();
+  u32* flag = ws.tmp[2];  // per LEF: its rev unit is stalled
+  u32 st_rev = 0, st_fwd = 0, st_both = 0, n_bar = 0, n_prim = 0, n_sec = 0;
+  u64 part = 0;
+  for (u32 base = 0; base < n; base += 64) {
+    const u32 k = base + lane;
+    const bool act = k < n;
+    const u32 rc = act ? ws.r_coll[k] : 0;
+    const u32 P = act ? ws.r_pos[k] : UNBOUND;
+    if (act) flag[ws.r_id[k]] = cw_occurred(rc) ? 1u : 0u;
+    st_rev += static_cast<u32>(wave::popc64(wave::ballot(act && cw_occurred(rc))));
+    n_bar += static_cast<u32>(wave::popc64(wave::ballot(act && cw_occurred_as(rc, EV_LEF_BAR))));
+    n_prim += static_cast<u32>(wave::popc64(wave::ballot(act && cw_occurred_as(rc, EV_LEF_LEF_PRIMARY))));
+    n_sec += static_cast<u32>(wave::popc64(wave::ballot(act && cw_occurred_as(rc, EV_LEF_LEF_SECONDARY))));
+    if (act && P != UNBOUND) part -= static_cast<u64>(P - ws.r_move[k]);
+  }
+  wave::sync_mem();
+  for (u32 base = 0; base < n; base += 64) {
+    const u32 k = base + lane;
+    const bool act = k < n;
+    const u32 fc = act ? ws.f_coll[k] : 0;
+    const u32 P = act ? ws.f_pos[k] : UNBOUND;
+    const bool both = act && cw_occurred(fc) && flag[ws.f_id[k]] != 0;
+    st_fwd += static_cast<u32>(wave::popc64(wave::ballot(act && cw_occurred(fc))));
+    st_both += static_cast<u32>(wave::popc64(wave::ballot(both)));
+    n_bar += static_cast<u32>(wave::popc64(wave::ballot(act && cw_occurred_as(fc, EV_LEF_BAR))));
+    n_prim += static_cast<u32>(wave::popc64(wave::ballot(act && cw_occurred_as(fc, EV_LEF_LEF_PRIMARY))));
+    n_sec += static_cast<u32>(wave::popc64(wave::ballot(act && cw_occurred_as(fc, EV_LEF_LEF_SECONDARY))));
+    if (act && P != UNBOUND) part += static_cast<u64>(P + ws.f_move[k]);
+  }
+#pragma unroll
+  for (u32 sft = 1; sft < 64; sft <<= 1) {
+    const u64 o = wave::shfl_down(part, sft);
+    if (lane + sft < 64) part += o;
+  }
+  const u64 loop_sum = wave::bcast(part, 0);
+  u32 n_occ = 0;
+  const u32 nb = wave::uniform(c.iv->n_barriers);
+  for (u32 base = 0; base < nb; base += 64) {
+    const u32 i = base + lane;
+    n_occ += static_cast<u32>(wave::popc64(wave::ballot(i < nb && ws.bar_active[i] != 0)));
+  }
+  if (lane == 0) {
+    u64* rec = log + epoch * STATE_LOG_WORDS;
+    rec[0] = epoch | (burnin ? (u64(1) << 63) : 0);
+    rec[1] = n_occ;
+    rec[2] = n;
+    rec[3] = st_rev;
+    rec[4] = st_fwd;
+    rec[5] = st_both;
+    rec[6] = n_bar;
+    rec[7] = n_prim;
+    rec[8] = n_sec;
+    rec[9] = loop_sum;
+  }
+  wave::sync_mem();
+}
+#else
+MODLE_DEV void log_internal_state(Cell&, u64, bool) {}
+#endif
+
 // Simulates one (interval, cell) task on the calling wave.  Returns 0 or a non-zero status when
 // an internal capacity was exceeded (the host turns that into an error).
 MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& task,
@@ -3152,6 +3224,7 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
       }
     }
 #endif
+    log_internal_state(c, epoch, !burnin_completed);
     PHASE(c, 13, phase_extrude_and_release(c, burnin_completed));
     trace_stage(c, epoch, 4);
 #ifdef MODLE_TRACE

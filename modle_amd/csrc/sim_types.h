@@ -150,7 +150,14 @@ struct WaveLds {
   u64* trace;             // optional per-epoch trace (4 words per epoch) or nullptr
   u32 trace_cap;          // epochs the trace buffer holds
   u64* phase_ticks;       // profiling build: 16 per-phase tick counters (device memory) or nullptr
+  u64* state_log;         // --log-model-internal-state build: STATE_LOG_WORDS per epoch, or nullptr
+  u32 state_log_cap;      // epochs the log of this task holds
 };
+// words of one record of the model-internal-state log (Simulation::dump_stats,
+// reference: simulation.cpp:995-1056): epoch | burn-in flag << 63, barriers occupied, active LEFs,
+// units stalled rev / fwd, LEFs stalled at both ends, LEF-BAR / primary / secondary collisions,
+// sum of the loop sizes
+constexpr u32 STATE_LOG_WORDS = 10;
 constexpr u32 SORT_LDS_CAP = MODLE_WAVES_PER_CU > 8 ? 256 : 512;
 constexpr u32 STAGE_CAP = 256;
 

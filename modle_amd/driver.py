@@ -171,3 +171,27 @@ def write_bigwig(path, cfg, plan, occupancies, chroms=None, force_overwrite=Fals
                 continue
             iv = entry["interval"]
             w.write_occupancy(iv["name"], occ[:entry["ncols"]], int(cfg.bin_size), int(iv["start"]))
+
+
+STATE_LOG_HEADER = ("task_id\tepoch\tcell_id\tchrom\tstart\tend\tburnin\tbarrier_occupancy\t"
+                    "num_active_lefs\tnum_stalls_rev\tnum_stalls_fwd\tnum_stalls_both\t"
+                    "num_lef_bar_collisions\tnum_primary_lef_lef_collisions\t"
+                    "num_secondary_lef_lef_collisions\tavg_loop_size\n")
+
+
+def format_state_log(task, interval, n_barriers, records):
+    """lines of the model-internal-state log for one task, in the column order of
+    Simulation::dump_stats (simulation.cpp:1040-1054): ids, interval, burn-in flag, effective
+    barrier occupancy (occupied / all), active LEFs, units stalled rev / fwd, LEFs stalled at both
+    ends, LEF-BAR / primary / secondary collisions, mean loop size"""
+    out = []
+    for rec in records:
+        epoch = int(rec[0]) & ((1 << 63) - 1)
+        burnin = bool(int(rec[0]) >> 63)
+        n = int(rec[2])
+        occ = (int(rec[1]) / n_barriers) if n_barriers else float("nan")
+        avg = int(rec[9]) / n if n else float("nan")
+        out.append(f"{task.id}\t{epoch}\t{task.cell_id}\t{interval['name']}\t{interval['start']}\t"
+                   f"{interval['end']}\t{'True' if burnin else 'False'}\t{occ!r}\t{n}\t{int(rec[3])}\t"
+                   f"{int(rec[4])}\t{int(rec[5])}\t{int(rec[6])}\t{int(rec[7])}\t{int(rec[8])}\t{avg!r}\n")
+    return out

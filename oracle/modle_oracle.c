@@ -1490,6 +1490,59 @@ static int simulate_cell_sorted(const mo_params_t* p, uint64_t start, uint64_t e
                                 uint64_t ncols, uint64_t* missed, uint64_t* occupancy,
                                 mo_cell_result_t* res);
 
+/* Model-internal-state log (Simulation::dump_stats, simulation.cpp:995-1056; called after
+ * extrude and before release_lefs, :969-975): the sink of the calling thread, 10 words per
+ * record in the layout of MODLE_HIP_STATE_LOG_WORDS (include/modle_hip.h). */
+static __thread uint64_t* tl_state_log = NULL;
+static __thread size_t tl_state_log_cap = 0, tl_state_log_n = 0;
+
+static void dump_stats(uint64_t epoch, int burnin, size_t n, const uint64_t* rev_pos,
+                       const uint64_t* fwd_pos, const uint64_t* epochs, const uint64_t* rev_coll,
+                       const uint64_t* fwd_coll, size_t nb, const uint8_t* bar_active) {
+  if (tl_state_log == NULL || tl_state_log_n >= tl_state_log_cap) return;
+  uint64_t occ = 0, st_rev = 0, st_fwd = 0, st_both = 0, n_bar = 0, n_prim = 0, n_sec = 0, loops = 0;
+  for (size_t i = 0; i < nb; ++i) occ += bar_active[i] != 0;
+  for (size_t i = 0; i < n; ++i) {
+    const int r = coll_occurred(rev_coll[i]), f = coll_occurred(fwd_coll[i]);
+    st_rev += (uint64_t)r;
+    st_fwd += (uint64_t)f;
+    st_both += (uint64_t)(r && f);
+    n_bar += (uint64_t)coll_occurred_as(rev_coll[i], MO_EV_LEF_BAR) + (uint64_t)coll_occurred_as(fwd_coll[i], MO_EV_LEF_BAR);
+    n_prim += (uint64_t)coll_occurred_as(rev_coll[i], MO_EV_LEF_LEF_PRIMARY) +
+              (uint64_t)coll_occurred_as(fwd_coll[i], MO_EV_LEF_LEF_PRIMARY);
+    n_sec += (uint64_t)coll_occurred_as(rev_coll[i], MO_EV_LEF_LEF_SECONDARY) +
+             (uint64_t)coll_occurred_as(fwd_coll[i], MO_EV_LEF_LEF_SECONDARY);
+    if (bound(epochs, i)) loops += fwd_pos[i] - rev_pos[i];
+  }
+  uint64_t* rec = tl_state_log + 10 * tl_state_log_n++;
+  rec[0] = epoch | (burnin ? (UINT64_C(1) << 63) : 0);
+  rec[1] = occ;
+  rec[2] = n;
+  rec[3] = st_rev;
+  rec[4] = st_fwd;
+  rec[5] = st_both;
+  rec[6] = n_bar;
+  rec[7] = n_prim;
+  rec[8] = n_sec;
+  rec[9] = loops;
+}
+
+/* one cell with its internal-state log: `log` holds cap records; returns the number written */
+size_t mo_simulate_cell_with_state_log(const mo_params_t* p, uint64_t start, uint64_t end, size_t nb,
+                                       const uint64_t* bar_pos, const uint8_t* bar_dir,
+                                       const double* bar_stp_active, const double* bar_stp_inactive,
+                                       const mo_task_t* task, uint32_t* contacts, uint64_t nrows,
+                                       uint64_t ncols, uint64_t* missed, uint64_t* occupancy,
+                                       mo_cell_result_t* res, uint64_t* log, size_t cap) {
+  tl_state_log = log;
+  tl_state_log_cap = cap;
+  tl_state_log_n = 0;
+  (void)mo_simulate_cell(p, start, end, nb, bar_pos, bar_dir, bar_stp_active, bar_stp_inactive, task,
+                         contacts, nrows, ncols, missed, occupancy, res);
+  tl_state_log = NULL;
+  return tl_state_log_n;
+}
+
 /* State::operator=(const Task&) copies the interval's barriers and sorts them for every task
  * (simulation.cpp:741-761); the copy is only made here when the input is not sorted already. */
 int mo_simulate_cell(const mo_params_t* p, uint64_t start, uint64_t end, size_t nb,
@@ -1662,6 +1715,8 @@ static int simulate_cell_sorted(const mo_params_t* p, uint64_t start, uint64_t e
       s.rev_pos[i] -= s.rev_moves[i];
       s.fwd_pos[i] += s.fwd_moves[i];
     }
+    dump_stats(epoch, !burnin_completed, n, s.rev_pos, s.fwd_pos, s.epoch, s.rev_coll, s.fwd_coll, nb,
+               s.bar_active);
     release_lefs(&s, burnin_completed);
     if (mo_trace_enabled()) {
       uint64_t sr = 0, sf = 0;

@@ -241,6 +241,14 @@ void mo_select_and_bind_lefs(uint64_t start, uint64_t end, size_t n, uint64_t* r
                              uint64_t* fwd_pos, uint64_t* epoch, uint64_t* rev_rank,
                              uint64_t* fwd_rank, uint64_t epoch_now, mo_prng_t* g,
                              uint64_t* scratch);
+/* one cell with its model-internal-state log (Simulation::dump_stats): 10 words per record in
+ * the layout of MODLE_HIP_STATE_LOG_WORDS; returns the number of records written */
+size_t mo_simulate_cell_with_state_log(const mo_params_t* p, uint64_t start, uint64_t end, size_t nb,
+                                       const uint64_t* bar_pos, const uint8_t* bar_dir,
+                                       const double* bar_stp_active, const double* bar_stp_inactive,
+                                       const mo_task_t* task, uint32_t* contacts, uint64_t nrows,
+                                       uint64_t ncols, uint64_t* missed, uint64_t* occupancy,
+                                       mo_cell_result_t* res, uint64_t* log, size_t cap);
 /* ExtrusionBarriers::sort (extrusion_barriers.cpp:237-257), in place */
 void mo_sort_barriers(size_t nb, uint64_t* pos, uint8_t* dir, double* stp_active,
                       double* stp_inactive);

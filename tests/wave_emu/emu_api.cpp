@@ -51,6 +51,8 @@ struct LdsImage {
     l.stage = stage.data();
     l.trace = nullptr;
     l.phase_ticks = nullptr;
+    l.state_log = nullptr;
+    l.state_log_cap = 0;
     l.trace_cap = 0;
     return l;
   }
