@@ -40,8 +40,8 @@ for seed in range(first, first + count):
     sim.close()
     ok = np.array_equal(oc, gc) and om == gm and (not track or np.array_equal(oo, go))
     for a, b in zip(ores, gres):
-        ok = ok and (a.epochs, a.burnin_epochs, a.num_contacts, a.raws_consumed) == (
-            b.epochs, b.burnin_epochs, b.num_contacts, b.raws_consumed)
+        ok = ok and (a.epochs, a.burnin_epochs, a.num_contacts, a.raws_consumed, list(a.prng_final)) == (
+            b.epochs, b.burnin_epochs, b.num_contacts, b.raws_consumed, list(b.prng_final))
     if (seed - first) % 25 == 24:
         print(f"  .. seed {seed}, {time.time() - t0:.0f} s", flush=True)
     if not ok:
