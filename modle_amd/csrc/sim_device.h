@@ -100,20 +100,21 @@ MODLE_DEV_NOINLINE void phase_bind(Cell& c, u32 epoch_now) {
   struct LefRegs {
     u32 E[UX], R[UX], F[UX];
   };
-  const auto load_lefs = [&](u32 group, LefRegs& r) {
+  const auto load_lefs = [&](auto op, u32 group, LefRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 iq = group + 64 * u + lane;
-      r.E[u] = iq < n ? ws.epoch[iq] : 0;
-      r.R[u] = iq < n ? ws.r_rank[iq] : 0;
-      r.F[u] = iq < n ? ws.f_rank[iq] : 0;
+      r.E[u] = op(ws.epoch, iq, iq < n, 0, r.E[u]);
+      r.R[u] = op(ws.r_rank, iq, iq < n, 0, r.R[u]);
+      r.F[u] = op(ws.f_rank, iq, iq < n, 0, r.F[u]);
     }
   };
   LefRegs cur;
-  load_lefs(0, cur);
+  load_lefs(wave::LdRaw{}, 0, cur);
   for (u32 group = 0; group < n; group += 64 * UX) {
-    const LefRegs g = cur;
-    if (group + 64 * UX < n) load_lefs(group + 64 * UX, cur);
+    LefRegs g = cur;
+    load_lefs(wave::LdMask{}, group, g);  // (defaults of the lanes outside the range)
+    if (group + 64 * UX < n) load_lefs(wave::LdRaw{}, group + 64 * UX, cur);
     const u32* Eq = g.E;
     const u32* Rq = g.R;
     const u32* Fq = g.F;
@@ -143,7 +144,7 @@ MODLE_DEV_NOINLINE void phase_bind(Cell& c, u32 epoch_now) {
         }
       } else {
         posv = iv.start + static_cast<u32>(r);
-        c.g.pos += cnt;
+        rng_advance(c.g, cnt);
       }
     }
     if (unb) {
@@ -199,7 +200,7 @@ MODLE_DEV_NOINLINE void phase_bind_listed(Cell& c, u32 epoch_now) {
         }
       } else {
         posv = iv.start + static_cast<u32>(r);
-        c.g.pos += cnt;
+        rng_advance(c.g, cnt);
       }
     }
     if (act) {
@@ -292,19 +293,20 @@ MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_
   struct KeptRegs {
     u32 P[UX], I[UX];
   };
-  const auto load_kept = [&](u32 group, KeptRegs& r) {
+  const auto load_kept = [&](auto op, u32 group, KeptRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 aq = group + 64 * u + lane;
-      r.P[u] = aq < n_old ? wave::ld_stream(&old_pos[aq]) : UNBOUND;
-      r.I[u] = aq < n_old ? wave::ld_stream(&old_id[aq]) : 0;
+      r.P[u] = op(old_pos, aq, aq < n_old, UNBOUND, r.P[u]);
+      r.I[u] = op(old_id, aq, aq < n_old, 0, r.I[u]);
     }
   };
   KeptRegs cur;
-  load_kept(0, cur);
+  load_kept(wave::LdRaw{}, 0, cur);
   for (u32 group = 0; group < n_old; group += 64 * UX) {
-    const KeptRegs g = cur;
-    if (group + 64 * UX < n_old) load_kept(group + 64 * UX, cur);
+    KeptRegs g = cur;
+    load_kept(wave::LdMask{}, group, g);  // (defaults of the lanes outside the range)
+    if (group + 64 * UX < n_old) load_kept(wave::LdRaw{}, group + 64 * UX, cur);
     const u32* Pq = g.P;
     const u32* Iq = g.I;
 #pragma unroll
@@ -325,7 +327,10 @@ MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_
       const u64 thr = FWD ? ((static_cast<u64>(pp) + 1) << 32) : (static_cast<u64>(pp) << 32);
 #pragma unroll
       for (u32 sft = 8; sft >= 1; sft >>= 1) {
-        if (lo + sft <= n_new && keys[lo + sft - 1] < thr) lo += sft;
+        const u32 j = lo + sft;
+        const bool in = j <= n_new;
+        const u64 kv = keys[in ? j - 1 : 0];  // (no branch around the read)
+        if (in & (kv < thr)) lo = j;
       }
       if (lo == carry_lo + 15 && lo < n_new) {
         u32 hi = n_new;
@@ -425,20 +430,21 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
   struct UnitRegs {
     u32 P[UX], I[UX], K[UX];
   };
-  const auto load_units = [&](u32 group, UnitRegs& r) {
+  const auto load_units = [&](auto op, u32 group, UnitRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 kq = group + 64 * u + lane;
-      r.P[u] = kq < n ? wave::ld_stream(&pos[kq]) : 0;
-      r.I[u] = kq < n ? wave::ld_stream(&ids[kq]) : 0;
-      r.K[u] = kq < n ? wave::ld_stream(&marks[kq]) : 0;
+      r.P[u] = op(pos, kq, kq < n, 0, r.P[u]);
+      r.I[u] = op(ids, kq, kq < n, 0, r.I[u]);
+      r.K[u] = op(marks, kq, kq < n, 0, r.K[u]);
     }
   };
   UnitRegs cur;
-  load_units(0, cur);
+  load_units(wave::LdRaw{}, 0, cur);
   for (u32 group = 0; group < n; group += 64 * UX) {
-    const UnitRegs g = cur;
-    if (group + 64 * UX < n) load_units(group + 64 * UX, cur);
+    UnitRegs g = cur;
+    load_units(wave::LdMask{}, group, g);  // (defaults of the lanes outside the range)
+    if (group + 64 * UX < n) load_units(wave::LdRaw{}, group + 64 * UX, cur);
     const u32* Pq = g.P;
     const u32* Iq = g.I;
     const u32* Kq = g.K;
@@ -628,9 +634,9 @@ MODLE_DEV u32 draw_moves_step(Cell& c, f64 speed, f64 std, u32 tail) {
   }
   tail += static_cast<u32>(wave::popc64(acc));
   if (stop == 64) {
-    g.pos += 64 + static_cast<u32>(dbl >> 63);
+    rng_advance(g, 64 + static_cast<u32>(dbl >> 63));
   } else {
-    g.pos += stop;
+    rng_advance(g, stop);
     const f64 exact = unit_normal_exact(g, c.lds);
     if (lane == 0) {
       q_move[tail % MOVQ_CAP] = move_from_normal(exact, speed, std);
@@ -667,19 +673,20 @@ MODLE_DEV_NOINLINE void generate_moves_dir(Cell& c, f64 speed, f64 std) {
   struct LefRegs {
     u32 E[UX], S[UX];
   };
-  const auto load_lefs = [&](u32 group, LefRegs& r) {
+  const auto load_lefs = [&](auto op, u32 group, LefRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 i = group + 64 * u + lane;
-      r.E[u] = i < n ? ws.epoch[i] : UNBOUND;
-      r.S[u] = i < n ? rank[i] : 0;
+      r.E[u] = op(ws.epoch, i, i < n, UNBOUND, r.E[u]);
+      r.S[u] = op(rank, i, i < n, 0, r.S[u]);
     }
   };
   LefRegs cur;
-  load_lefs(0, cur);
+  load_lefs(wave::LdRaw{}, 0, cur);
   for (u32 group = 0; group < n; group += 64 * UX) {
-    const LefRegs g = cur;
-    if (group + 64 * UX < n) load_lefs(group + 64 * UX, cur);
+    LefRegs g = cur;
+    load_lefs(wave::LdMask{}, group, g);  // (defaults of the lanes outside the range)
+    if (group + 64 * UX < n) load_lefs(wave::LdRaw{}, group + 64 * UX, cur);
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
     const u32 base = group + 64 * u;
@@ -701,7 +708,7 @@ MODLE_DEV_NOINLINE void generate_moves_dir(Cell& c, f64 speed, f64 std) {
     // the stream ends right after the draw of the last bound LEF: hand back what the last step
     // evaluated beyond it (queued draws, and rejected attempts that no draw followed)
     const u32 end_low = wave::uniform(q_end[(head - 1) % MOVQ_CAP]);
-    c.g.pos -= static_cast<u32>(static_cast<u32>(c.g.pos) - end_low);
+    c.g.pos = wave::known_uniform(c.g.pos - static_cast<u32>(static_cast<u32>(c.g.pos) - end_low));
   }
 }
 
@@ -737,7 +744,7 @@ MODLE_DEV_NOINLINE void generate_moves_by_id(Cell& c, f64 speed, f64 std, u32* m
   if (head != 0) {
     // hand back what the last step evaluated beyond the draw of the last LEF
     const u32 end_low = wave::uniform(q_end[(head - 1) % MOVQ_CAP]);
-    c.g.pos -= static_cast<u32>(static_cast<u32>(c.g.pos) - end_low);
+    c.g.pos = wave::known_uniform(c.g.pos - static_cast<u32>(static_cast<u32>(c.g.pos) - end_low));
   }
 }
 
@@ -784,27 +791,28 @@ MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp,
     for (u32 u = 0; u < UX; ++u) {
       const bool in = bg + u < nbatch;
       const u32 kq = (nbatch - 1 - (bg + u)) * 64 + (63 - lane);
-      r.I[u] = by_id && in && kq < n ? ws.r_id[kq] : 0;
+      r.I[u] = wave::ld_sel(ws.r_id, kq, by_id && in && kq < n, 0);
     }
   };
-  const auto load_units = [&](u32 bg, const IdRegs& ids, UnitRegs& r) {
+  const auto load_units = [&](auto op, u32 bg, const IdRegs& ids, UnitRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const bool in = bg + u < nbatch;
       const u32 kq = (nbatch - 1 - (bg + u)) * 64 + (63 - lane);
-      r.P[u] = in && kq < n ? ws.r_pos[kq] : UNBOUND;
-      r.M[u] = in && kq < n ? (by_id ? mv_by_id[ids.I[u]] : mv_in[kq]) : 0;
+      r.P[u] = op(ws.r_pos, kq, in && kq < n, UNBOUND, r.P[u]);
+      r.M[u] = op(by_id ? mv_by_id : mv_in, by_id ? ids.I[u] : kq, in && kq < n, 0, r.M[u]);
     }
   };
   IdRegs ids;
   UnitRegs cur;
   load_ids(0, ids);
-  load_units(0, ids, cur);
+  load_units(wave::LdRaw{}, 0, ids, cur);
   if (UX < nbatch) load_ids(UX, ids);
   for (u32 bg = 0; bg < nbatch; bg += UX) {
-    const UnitRegs g = cur;
+    UnitRegs g = cur;
+    load_units(wave::LdMask{}, bg, ids, g);  // (defaults of the lanes outside the range)
     if (bg + UX < nbatch) {
-      load_units(bg + UX, ids, cur);
+      load_units(wave::LdRaw{}, bg + UX, ids, cur);
       if (bg + 2 * UX < nbatch) load_ids(bg + 2 * UX, ids);
     }
     const u32* Pq = g.P;
@@ -894,26 +902,27 @@ MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp,
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 kq = (bg + u) * 64 + lane;
-      r.I[u] = by_id && kq < n ? ws.f_id[kq] : 0;
+      r.I[u] = wave::ld_sel(ws.f_id, kq, by_id && kq < n, 0);
     }
   };
-  const auto load_units = [&](u32 bg, const IdRegs& ids, UnitRegs& r) {
+  const auto load_units = [&](auto op, u32 bg, const IdRegs& ids, UnitRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 kq = (bg + u) * 64 + lane;
-      r.P[u] = kq < n ? ws.f_pos[kq] : UNBOUND;
-      r.M[u] = kq < n ? (by_id ? mv_by_id[ids.I[u]] : mv_in[kq]) : 0;
+      r.P[u] = op(ws.f_pos, kq, kq < n, UNBOUND, r.P[u]);
+      r.M[u] = op(by_id ? mv_by_id : mv_in, by_id ? ids.I[u] : kq, kq < n, 0, r.M[u]);
     }
   };
   IdRegs ids;
   UnitRegs cur;
   load_ids(0, ids);
-  load_units(0, ids, cur);
+  load_units(wave::LdRaw{}, 0, ids, cur);
   if (UX < nbatch) load_ids(UX, ids);
   for (u32 bg = 0; bg < nbatch; bg += UX) {
-    const UnitRegs g = cur;
+    UnitRegs g = cur;
+    load_units(wave::LdMask{}, bg, ids, g);  // (defaults of the lanes outside the range)
     if (bg + UX < nbatch) {
-      load_units(bg + UX, ids, cur);
+      load_units(wave::LdRaw{}, bg + UX, ids, cur);
       if (bg + 2 * UX < nbatch) load_ids(bg + 2 * UX, ids);
     }
     const u32* Pq = g.P;
@@ -1007,7 +1016,7 @@ MODLE_DEV_NOINLINE void barriers_init_states(Cell& c) {
   for (u32 base = 0; base < nb; base += 64) {
     const u32 i = base + lane;
     const bool act = i < nb;
-    const f64 occ = act ? iv.bar_occupancy[i] : 0.0;
+    const f64 occ = wave::ld_sel(iv.bar_occupancy, i, act, 0.0);
     const bool draws = act && occ != 0.0;  // bernoulli(0) consumes nothing
     const u64 dm = wave::ballot(draws);
     const u32 cnt = static_cast<u32>(wave::popc64(dm));
@@ -1015,7 +1024,7 @@ MODLE_DEV_NOINLINE void barriers_init_states(Cell& c) {
     const u32 k = static_cast<u32>(wave::popc64(dm & lanemask_lt(lane)));
     const bool on = draws && bernoulli_raw(rng_peek(c.g, c.g.pos + k), occ);
     if (act) c.ws.bar_active[i] = on ? 1 : 0;
-    c.g.pos += cnt;
+    rng_advance(c.g, cnt);
   }
   wave::sync_mem();
 }
@@ -1078,22 +1087,23 @@ MODLE_DEV_NOINLINE void barriers_next_state(Cell& c) {
     u32 P[UX];
     f64 I[UX], A[UX];
   };
-  const auto load_bars = [&](u32 group, BarRegs& r) {
+  const auto load_bars = [&](auto op, u32 group, BarRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 iq = group + 64 * u + lane;
-      r.S[u] = iq < nb ? c.ws.bar_active[iq] : u8(0);
-      r.I[u] = iq < nb ? iv.bar_stp_inactive[iq] : 0.0;
-      r.A[u] = iq < nb ? iv.bar_stp_active[iq] : 0.0;
-      r.D[u] = lists && iq < nb ? iv.bar_dir[iq] : u8(0);
-      r.P[u] = lists && iq < nb ? iv.bar_pos[iq] : 0;
+      r.S[u] = op(c.ws.bar_active, iq, iq < nb, u8(0), r.S[u]);
+      r.I[u] = op(iv.bar_stp_inactive, iq, iq < nb, 0.0, r.I[u]);
+      r.A[u] = op(iv.bar_stp_active, iq, iq < nb, 0.0, r.A[u]);
+      r.D[u] = op(iv.bar_dir, iq, lists && iq < nb, u8(0), r.D[u]);
+      r.P[u] = op(iv.bar_pos, iq, lists && iq < nb, 0, r.P[u]);
     }
   };
-  BarRegs cur;
-  load_bars(0, cur);
+  BarRegs cur{};
+  if (nb != 0) load_bars(wave::LdRaw{}, 0, cur);
   for (u32 group = 0; group < nb; group += 64 * UX) {
-    const BarRegs g = cur;
-    if (group + 64 * UX < nb) load_bars(group + 64 * UX, cur);
+    BarRegs g = cur;
+    load_bars(wave::LdMask{}, group, g);  // (defaults of the lanes outside the range)
+    if (group + 64 * UX < nb) load_bars(wave::LdRaw{}, group + 64 * UX, cur);
     const u8* Sq = g.S;
     const f64* Iq = g.I;
     const f64* Aq = g.A;
@@ -1115,7 +1125,7 @@ MODLE_DEV_NOINLINE void barriers_next_state(Cell& c) {
           c.ws.bar_active[i] = 0;
         }
       }
-      c.g.pos += cnt;
+      rng_advance(c.g, cnt);
       if (lists) stalling_lists_append(c, i, i < nb, st != 0, g.P[u], g.D[u]);
     }
   }
@@ -1141,7 +1151,7 @@ MODLE_DEV_NOINLINE BoundaryCounts detect_boundaries(Cell& c) {
   for (u32 top = n; top > 0;) {
     const u32 cnt = umin(64u, top);
     const bool act = lane < cnt;
-    const u32 P = act ? ws.r_pos[top - 1 - lane] : UNBOUND;  // descending ranks
+    const u32 P = wave::ld_sel(ws.r_pos, top - 1 - lane, act, UNBOUND);  // descending ranks
     const u64 m = wave::ballot(act && P != UNBOUND);
     if (m != 0) {
       last_rev_pos = wave::bcast(P, static_cast<u32>(wave::ctz64(m)));
@@ -1155,8 +1165,8 @@ MODLE_DEV_NOINLINE BoundaryCounts detect_boundaries(Cell& c) {
   for (u32 base = 0; base < n; base += 64) {
     const u32 k = base + lane;
     const bool act = k < n;
-    const u32 P = act ? ws.r_pos[k] : 0;
-    const u32 M = act ? ws.r_move[k] : 0;
+    const u32 P = wave::ld_sel(ws.r_pos, k, act, 0);
+    const u32 M = wave::ld_sel(ws.r_move, k, act, 0);
     const bool at = act && P == start;
     const bool brk_b = act && !at && P > first_fwd_pos;
     const bool brk_c = act && !at && !brk_b && P - M == start;
@@ -1172,8 +1182,8 @@ MODLE_DEV_NOINLINE BoundaryCounts detect_boundaries(Cell& c) {
     const u32 cnt = umin(64u, top - 1);
     const u32 k = top - 1 - lane;
     const bool act = lane < cnt;
-    const u32 P = act ? ws.f_pos[k] : 0;
-    const u32 M = act ? ws.f_move[k] : 0;
+    const u32 P = wave::ld_sel(ws.f_pos, k, act, 0);
+    const u32 M = wave::ld_sel(ws.f_move, k, act, 0);
     const bool bnd = act && P != UNBOUND;
     const bool unb = act && !bnd;
     const bool at = bnd && P == last;
@@ -1416,22 +1426,23 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
   struct UnitRegs {
     u32 P[UX], M[UX];
   };
-  const auto load_units = [&](u32 bg, UnitRegs& r) {
+  const auto load_units = [&](auto op, u32 bg, UnitRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       // (ranks stay far below 2^31: 32-bit index arithmetic)
       const i32 kk = FWD ? static_cast<i32>(j_fwd0) - static_cast<i32>((bg + u) * 64 + lane)
                          : static_cast<i32>(j_rev0 + (bg + u) * 64 + lane);
       const bool act = kk >= 0 && static_cast<u32>(kk) < n;
-      r.P[u] = act ? pos[static_cast<u32>(kk)] : 0;
-      r.M[u] = act ? moves[static_cast<u32>(kk)] : 0;
+      r.P[u] = op(pos, static_cast<u32>(kk), act, 0, r.P[u]);
+      r.M[u] = op(moves, static_cast<u32>(kk), act, 0, r.M[u]);
     }
   };
   UnitRegs cur;
-  load_units(0, cur);
+  load_units(wave::LdRaw{}, 0, cur);
   for (u32 bg = 0; bg < nbatch; bg += UX) {
-    const UnitRegs g = cur;
-    if (bg + UX < nbatch) load_units(bg + UX, cur);
+    UnitRegs g = cur;
+    load_units(wave::LdMask{}, bg, g);  // (defaults of the lanes outside the range)
+    if (bg + UX < nbatch) load_units(wave::LdRaw{}, bg + UX, cur);
     const u32* Pq = g.P;
     const u32* Mq = g.M;
 #pragma unroll
@@ -1484,7 +1495,8 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
 #pragma unroll
             for (u32 t = 0; t < BAR_WIN / 64; ++t) {
               const u32 e = lane + 64 * t;
-              below += static_cast<u32>(wave::popc64(wave::ballot(e < cnt && cp[e] < key)));
+              const u32 ce = cp[e];  // (e < BAR_WIN: inside the window whatever cnt is)
+              below += static_cast<u32>(wave::popc64(wave::ballot((e < cnt) & (ce < key))));
             }
             if (!FWD) {
               g0 += below;
@@ -1527,7 +1539,10 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
           if (bnd) {
 #pragma unroll
             for (u32 sft = 64; sft >= 1; sft >>= 1) {
-              if (q + sft <= cnt && cp[c0 + q + sft - 1] < hi_key) q += sft;
+              const u32 j = q + sft;
+              const bool in = j <= cnt;
+              const u32 kv = cp[c0 + (in ? j - 1 : 0)];  // (no branch around the read)
+              if (in & (kv < hi_key)) q = j;
             }
             if (q == anchor + HITBAR_NEAR && q < cnt) {
               u32 hi = cnt;
@@ -1551,7 +1566,9 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
           if (bnd) {
 #pragma unroll
             for (u32 sft = 64; sft >= 1; sft >>= 1) {
-              if (q >= sft && cp[c0 + q - sft] >= lo_key) q -= sft;
+              const bool in = q >= sft;
+              const u32 kv = cp[c0 + (in ? q - sft : 0)];  // (no branch around the read)
+              if (in & (kv >= lo_key)) q -= sft;
             }
             if (q + HITBAR_NEAR == anchor && q > 0) {
               u32 lo = 0;
@@ -1643,8 +1660,8 @@ MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
       const i64 kk = FWD ? static_cast<i64>(j_fwd0) - static_cast<i64>(bg + u) * 64 - lane
                          : static_cast<i64>(j_rev0) + static_cast<i64>(bg + u) * 64 + lane;
       const bool act = kk >= 0 && kk < static_cast<i64>(n);
-      Pq[u] = act ? pos[static_cast<u32>(kk)] : 0;
-      Mq[u] = act ? moves[static_cast<u32>(kk)] : 0;
+      Pq[u] = wave::ld_sel(pos, static_cast<u32>(kk), act, 0);
+      Mq[u] = wave::ld_sel(moves, static_cast<u32>(kk), act, 0);
     }
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
@@ -1739,7 +1756,7 @@ MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
         if (total != 0) rng_ensure(c.g, total);
         winner = staged_only ? lef_bar_pick<FWD, true>(v, p, c.g, b_lo, b_hi, off, hard, bpos)
                              : lef_bar_pick<FWD, false>(v, p, c.g, b_lo, b_hi, off, hard, bpos);
-        c.g.pos += total;
+        rng_advance(c.g, total);
       } else {
         // More Bernoulli trials in this batch than one block of the PRNG ring serves (dense
         // barrier annotations with a fractional blocking probability): the lanes are resolved in
@@ -1800,7 +1817,7 @@ MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
                            ? lef_bar_pick<FWD, true>(v, p, c.g, b_lo, b_hi, off - base_tr, hard, bpos)
                            : lef_bar_pick<FWD, false>(v, p, c.g, b_lo, b_hi, off - base_tr, hard, bpos);
             }
-            c.g.pos += cnt;
+            rng_advance(c.g, cnt);
             base_tr += cnt;
             pend &= ~fm;
           }
@@ -1865,31 +1882,32 @@ struct PrimaryBatch {
   u32 sp[STAGE_CAP / 64];
   u32 sm[PRIMARY_NEAR / 64], sc[PRIMARY_NEAR / 64], si[PRIMARY_NEAR / 64], sb[PRIMARY_NEAR / 64];
 };
-MODLE_DEV void primary_load_batch(const Workspace& ws, u32 n, u32 base, u32 w0, u32 lane,
+template <class Op>
+MODLE_DEV void primary_load_batch(Op op, const Workspace& ws, u32 n, u32 base, u32 w0, u32 lane,
                                   PrimaryBatch& b) {
   const u32 k = base + lane;
   const bool act = k < n;
-  b.R = act ? ws.r_pos[k] : UNBOUND;
-  b.rev_move = act ? ws.r_move[k] : 0;
-  b.rev_id = act ? ws.r_id[k] : 0;
-  b.rc = act ? ws.r_coll[k] : 0;
+  b.R = op(ws.r_pos, k, act, UNBOUND, b.R);
+  b.rev_move = op(ws.r_move, k, act, 0, b.rev_move);
+  b.rev_id = op(ws.r_id, k, act, 0, b.rev_id);
+  b.rc = op(ws.r_coll, k, act, 0, b.rc);
   // position of the barrier that stalls the unit (meaningful where the word says LEF-BAR):
   // having it here keeps a dependent load, and with it a wait for everything in flight, out of
   // the batch's work
-  b.rbp = act ? stalling_barrier_positions<false>(ws)[k] : 0;
+  b.rbp = op(stalling_barrier_positions<false>(ws), k, act, 0, b.rbp);
 #pragma unroll
   for (u32 q = 0; q < STAGE_CAP / 64; ++q) {
     const u32 t = lane + 64 * q;
-    b.sp[q] = w0 + t < n ? ws.f_pos[w0 + t] : UNBOUND;
+    b.sp[q] = op(ws.f_pos, w0 + t, w0 + t < n, UNBOUND, b.sp[q]);
   }
 #pragma unroll
   for (u32 q = 0; q < PRIMARY_NEAR / 64; ++q) {
     const u32 t = lane + 64 * q;
     const bool in = w0 + t < n;
-    b.sm[q] = in ? ws.f_move[w0 + t] : 0;
-    b.sc[q] = in ? ws.f_coll[w0 + t] : 0;
-    b.si[q] = in ? ws.f_id[w0 + t] : 0;
-    b.sb[q] = in ? stalling_barrier_positions<true>(ws)[w0 + t] : 0;
+    b.sm[q] = op(ws.f_move, w0 + t, in, 0, b.sm[q]);
+    b.sc[q] = op(ws.f_coll, w0 + t, in, 0, b.sc[q]);
+    b.si[q] = op(ws.f_id, w0 + t, in, 0, b.si[q]);
+    b.sb[q] = op(stalling_barrier_positions<true>(ws), w0 + t, in, 0, b.sb[q]);
   }
 }
 
@@ -1928,11 +1946,12 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
   // unit: it lies upstream of this batch's last rev unit, which is then the "first rev unit
   // downstream of it".
   PrimaryBatch cur;
-  primary_load_batch(ws, n, bc.n5, 0, lane, cur);
+  primary_load_batch(wave::LdRaw{}, ws, n, bc.n5, 0, lane, cur);
   for (u32 base = bc.n5; base < n; base += 64) {
     const u32 k = base + lane;
     const bool act = k < n;
     const u32 w0 = carry_pf > 0 ? carry_pf - 1 : 0;
+    primary_load_batch(wave::LdMask{}, ws, n, base, w0, lane, cur);  // (defaults outside the range)
     const u32 R = cur.R;
     const u32 rev_move_k = cur.rev_move;
     const u32 rev_id_k = cur.rev_id;
@@ -1972,7 +1991,7 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
     // last active lane's pf (inactive lanes hold 0)
     const u64 am = wave::ballot(act);
     const u32 next_pf = wave::bcast(pf, static_cast<u32>(63 - wave::clz64(am)));
-    if (base + 64 < n) primary_load_batch(ws, n, base + 64, next_pf > 0 ? next_pf - 1 : 0, lane, cur);
+    if (base + 64 < n) primary_load_batch(wave::LdRaw{}, ws, n, base + 64, next_pf > 0 ? next_pf - 1 : 0, lane, cur);
     bool cand = false;
     u32 F = 0, rev_move = 0, fwd_move = 0, fwd_id_s = 0, fc_s = 0, fbp_s = 0;
     if (act && pf >= 1 && pf < i2) {
@@ -1998,7 +2017,7 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
       rng_ensure(c.g, cnt);
       const u32 t = static_cast<u32>(wave::popc64(cm & lanemask_lt(lane)));
       hit = cand && bernoulli_raw(rng_peek(c.g, c.g.pos + t), p_collide);
-      c.g.pos += cnt;
+      rng_advance(c.g, cnt);
     }
     if (hit) {
       const u32 kf = pf - 1;
@@ -2127,7 +2146,7 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
   struct UnitRegs {
     u32 P[UX], I[UX], M[UX], C[UX], B[UX];
   };
-  const auto load_units = [&](u32 bg, UnitRegs& r) {
+  const auto load_units = [&](auto op, u32 bg, UnitRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 bi = bg + u;
@@ -2136,18 +2155,19 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
                          : static_cast<i32>(bi * 64 + lane);
       const bool act = kk >= 0 && static_cast<u32>(kk) < n;
       const u32 k = act ? static_cast<u32>(kk) : 0;
-      r.P[u] = act ? pos[k] : 0;
-      r.I[u] = act ? ids[k] : 0;
-      r.M[u] = act ? moves[k] : 0;
-      r.C[u] = act ? coll[k] : 0;
-      r.B[u] = act ? barpos[k] : 0;
+      r.P[u] = op(pos, k, act, 0, r.P[u]);
+      r.I[u] = op(ids, k, act, 0, r.I[u]);
+      r.M[u] = op(moves, k, act, 0, r.M[u]);
+      r.C[u] = op(coll, k, act, 0, r.C[u]);
+      r.B[u] = op(barpos, k, act, 0, r.B[u]);
     }
   };
   UnitRegs cur;
-  load_units(0, cur);
+  load_units(wave::LdRaw{}, 0, cur);
   for (u32 bg = 0; bg < nbatch; bg += UX) {
-    const UnitRegs g = cur;
-    if (bg + UX < nbatch) load_units(bg + UX, cur);
+    UnitRegs g = cur;
+    load_units(wave::LdMask{}, bg, g);  // (defaults of the lanes outside the range)
+    if (bg + UX < nbatch) load_units(wave::LdRaw{}, bg + UX, cur);
     const u32* Pq = g.P;
     const u32* Iq = g.I;
     const u32* Mq = g.M;
@@ -2213,7 +2233,7 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
           rng_ensure(c.g, cnt);
           const u32 t = static_cast<u32>(wave::popc64(dm & lanemask_lt(lane)));
           collide = draws && bernoulli_raw(rng_peek(c.g, c.g.pos + t), p_collide);
-          c.g.pos += cnt;
+          rng_advance(c.g, cnt);
         }
         const bool avoided = draws && !collide;
         if (collide) {
@@ -2447,26 +2467,27 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
   struct UnitRegs {
     u32 rP[UX], rM[UX], rc[UX], fP[UX], fM[UX], fc[UX], rI[UX], fI[UX];
   };
-  const auto load_units = [&](u32 base, UnitRegs& r) {
+  const auto load_units = [&](auto op, u32 base, UnitRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 k = base + 64 * u + lane;
       const bool act = k < n;
-      r.rP[u] = act ? ws.r_pos[k] : UNBOUND;
-      r.rM[u] = act ? ws.r_move[k] : 0;
-      r.rc[u] = act ? ws.r_coll[k] : 0;
-      r.rI[u] = act ? ws.r_id[k] : 0;
-      r.fP[u] = act ? ws.f_pos[k] : UNBOUND;
-      r.fM[u] = act ? ws.f_move[k] : 0;
-      r.fc[u] = act ? ws.f_coll[k] : 0;
-      r.fI[u] = act ? ws.f_id[k] : 0;
+      r.rP[u] = op(ws.r_pos, k, act, UNBOUND, r.rP[u]);
+      r.rM[u] = op(ws.r_move, k, act, 0, r.rM[u]);
+      r.rc[u] = op(ws.r_coll, k, act, 0, r.rc[u]);
+      r.rI[u] = op(ws.r_id, k, act, 0, r.rI[u]);
+      r.fP[u] = op(ws.f_pos, k, act, UNBOUND, r.fP[u]);
+      r.fM[u] = op(ws.f_move, k, act, 0, r.fM[u]);
+      r.fc[u] = op(ws.f_coll, k, act, 0, r.fc[u]);
+      r.fI[u] = op(ws.f_id, k, act, 0, r.fI[u]);
     }
   };
   UnitRegs cur;
-  load_units(0, cur);
+  load_units(wave::LdRaw{}, 0, cur);
   for (u32 base = 0; base < n; base += 64 * UX) {
-    const UnitRegs g = cur;
-    if (base + 64 * UX < n) load_units(base + 64 * UX, cur);
+    UnitRegs g = cur;
+    load_units(wave::LdMask{}, base, g);  // (defaults of the lanes outside the range)
+    if (base + 64 * UX < n) load_units(wave::LdRaw{}, base + 64 * UX, cur);
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 k = base + 64 * u + lane;
@@ -2490,22 +2511,23 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
   struct LefRegs {
     u32 E[UX], H[UX];
   };
-  const auto load_lefs = [&](u32 group, LefRegs& r) {
+  const auto load_lefs = [&](auto op, u32 group, LefRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 iq = group + 64 * u + lane;
-      r.E[u] = iq < n ? ws.epoch[iq] : UNBOUND;
-      r.H[u] = iq < n ? ws.stall[iq] : 0;
+      r.E[u] = op(ws.epoch, iq, iq < n, UNBOUND, r.E[u]);
+      r.H[u] = op(ws.stall, iq, iq < n, 0, r.H[u]);
     }
   };
   u32* list = reinterpret_cast<u32*>(c.lds.sort_lds);
   u32 n_rel = 0;
   wave::lockstep();
   LefRegs lcur;
-  load_lefs(0, lcur);
+  load_lefs(wave::LdRaw{}, 0, lcur);
   for (u32 group = 0; group < n; group += 64 * UX) {
-    const LefRegs g = lcur;
-    if (group + 64 * UX < n) load_lefs(group + 64 * UX, lcur);
+    LefRegs g = lcur;
+    load_lefs(wave::LdMask{}, group, g);  // (defaults of the lanes outside the range)
+    if (group + 64 * UX < n) load_lefs(wave::LdRaw{}, group + 64 * UX, lcur);
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
     const u32 base = group + 64 * u;
@@ -2527,7 +2549,7 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
     rng_ensure(c.g, cnt);
     const u32 k = static_cast<u32>(wave::popc64(dm & lanemask_lt(lane)));
     const bool rel = draws && bernoulli_raw(rng_peek(c.g, c.g.pos + k), prob);
-    c.g.pos += cnt;
+    rng_advance(c.g, cnt);
     const u64 rm = wave::ballot(rel);
     if (rel) {
       ws.epoch[i] = UNBOUND;
@@ -2734,19 +2756,19 @@ MODLE_DEV_NOINLINE u64 run_events(Cell& c, u64 n_events) {
     if (irregular == 0) {
       if (act && e.ok) commit_event<KIND>(c, e);
       registered += static_cast<u64>(wave::popc64(wave::ballot(act && e.ok)));
-      c.g.pos += static_cast<u64>(cntb) * stride;
+      rng_advance(c.g, static_cast<u64>(cntb) * stride);
       remaining -= cntb;
     } else {
       const u32 f = static_cast<u32>(wave::ctz64(irregular));
       const bool commit = act && e.ok && lane < f;
       if (commit) commit_event<KIND>(c, e);
       registered += static_cast<u64>(wave::popc64(wave::ballot(commit)));
-      c.g.pos += static_cast<u64>(f) * stride;
+      rng_advance(c.g, static_cast<u64>(f) * stride);
       const bool needx = wave::bcast(e.need_exact, f);
       if (!needx) {
         if (lane == f && e.ok) commit_event<KIND>(c, e);
         registered += wave::bcast(e.ok, f) ? 1 : 0;
-        c.g.pos += wave::bcast(e.consumed, f);
+        rng_advance(c.g, wave::bcast(e.consumed, f));
       } else {
         const EventEval x = eval_event_exact<KIND>(c, lef_range, lef_bucket, noisify);
         if (x.ok && lane == 0) commit_event<KIND>(c, x);
@@ -2806,22 +2828,23 @@ MODLE_DEV LoopStats loop_size_stats(Cell& c) {
   struct UnitRegs {
     u32 fP[UX], fI[UX], rP[UX], rI[UX];
   };
-  const auto load_units = [&](u32 group, UnitRegs& r) {
+  const auto load_units = [&](auto op, u32 group, UnitRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 k = group + 64 * u + lane;
       const bool act = k < n;
-      r.fP[u] = act ? ws.f_pos[k] : 0;
-      r.fI[u] = act ? ws.f_id[k] : 0;
-      r.rP[u] = act ? ws.r_pos[k] : 0;
-      r.rI[u] = act ? ws.r_id[k] : 0;
+      r.fP[u] = op(ws.f_pos, k, act, 0, r.fP[u]);
+      r.fI[u] = op(ws.f_id, k, act, 0, r.fI[u]);
+      r.rP[u] = op(ws.r_pos, k, act, 0, r.rP[u]);
+      r.rI[u] = op(ws.r_id, k, act, 0, r.rI[u]);
     }
   };
   UnitRegs cur;
-  load_units(0, cur);
+  load_units(wave::LdRaw{}, 0, cur);
   for (u32 group = 0; group < n; group += 64 * UX) {
-    const UnitRegs g = cur;
-    if (group + 64 * UX < n) load_units(group + 64 * UX, cur);
+    UnitRegs g = cur;
+    load_units(wave::LdMask{}, group, g);  // (defaults of the lanes outside the range)
+    if (group + 64 * UX < n) load_units(wave::LdRaw{}, group + 64 * UX, cur);
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 k = group + 64 * u + lane;
@@ -3075,8 +3098,8 @@ MODLE_DEV_NOINLINE void log_internal_state(Cell& c, u64 epoch, bool burnin) {
   for (u32 base = 0; base < n; base += 64) {
     const u32 k = base + lane;
     const bool act = k < n;
-    const u32 rc = act ? ws.r_coll[k] : 0;
-    const u32 P = act ? ws.r_pos[k] : UNBOUND;
+    const u32 rc = wave::ld_sel(ws.r_coll, k, act, 0);
+    const u32 P = wave::ld_sel(ws.r_pos, k, act, UNBOUND);
     if (act) flag[ws.r_id[k]] = cw_occurred(rc) ? 1u : 0u;
     st_rev += static_cast<u32>(wave::popc64(wave::ballot(act && cw_occurred(rc))));
     n_bar += static_cast<u32>(wave::popc64(wave::ballot(act && cw_occurred_as(rc, EV_LEF_BAR))));
@@ -3088,8 +3111,8 @@ MODLE_DEV_NOINLINE void log_internal_state(Cell& c, u64 epoch, bool burnin) {
   for (u32 base = 0; base < n; base += 64) {
     const u32 k = base + lane;
     const bool act = k < n;
-    const u32 fc = act ? ws.f_coll[k] : 0;
-    const u32 P = act ? ws.f_pos[k] : UNBOUND;
+    const u32 fc = wave::ld_sel(ws.f_coll, k, act, 0);
+    const u32 P = wave::ld_sel(ws.f_pos, k, act, UNBOUND);
     const bool both = act && cw_occurred(fc) && flag[ws.f_id[k]] != 0;
     st_fwd += static_cast<u32>(wave::popc64(wave::ballot(act && cw_occurred(fc))));
     st_both += static_cast<u32>(wave::popc64(wave::ballot(both)));

@@ -356,8 +356,14 @@ MODLE_DEV void rng_final_state(const Rng& g, u64 out[4]) {
 
 // makes raws [pos, pos + k) readable (k <= RNG_BLOCK); uniform
 MODLE_DEV void rng_ensure(Rng& g, u32 k) {
+  // (both are the same in every lane; saying so keeps them in scalar registers and the loop a
+  // scalar branch)
+  g.pos = wave::known_uniform(g.pos);
+  g.gen_end = wave::known_uniform(g.gen_end);
   while (g.gen_end < g.pos + k) rng_gen_block(g);
 }
+// consumes n raws (uniform)
+MODLE_DEV void rng_advance(Rng& g, u64 n) { g.pos = wave::known_uniform(g.pos + n); }
 MODLE_DEV u64 rng_peek(const Rng& g, u64 p) { return g.ring[ring_index(p)]; }
 // uniform: next raw of the stream
 MODLE_DEV u64 rng_next(Rng& g) {

@@ -185,6 +185,34 @@ MODLE_DEV T ld_stream(const T* p) { return *p; }
 template <class T>
 MODLE_DEV void st_stream(T* p, T v) { *p = v; }
 #endif
+// a value that is the same in every lane by construction, where the compiler cannot see it: keeps
+// it in scalar registers and branches on it scalar (no exchange in the emulator)
+template <class T>
+MODLE_DEV T known_uniform(T v) { return uniform(v); }
+// p[k] where `ok`, `dflt` elsewhere, without a divergent branch around the load: lanes that are
+// not `ok` read p[0] (p must point at one readable element at least) and drop it.  The compiler keeps
+// an `ok ? p[k] : dflt` as s_and_saveexec / s_cbranch_execz around every single load.
+// The two halves of ld_sel for loads that are requested one group ahead of their use: LdRaw at
+// the request (no select, hence no wait, behind the load), LdMask where the values are consumed.
+// A loader written as `r.x = op(p, k, ok, dflt, r.x)` serves both.
+struct LdRaw {
+  template <class T, class D>
+  MODLE_DEV T operator()(const T* p, uint32_t k, bool ok, D dflt, T) const {
+    (void)dflt;
+    return ld_stream(p + (ok ? k : 0u));
+  }
+};
+struct LdMask {
+  template <class T, class D>
+  MODLE_DEV T operator()(const T*, uint32_t, bool ok, D dflt, T cur) const {
+    return ok ? cur : static_cast<T>(dflt);
+  }
+};
+template <class T, class D>
+MODLE_DEV T ld_sel(const T* p, uint32_t k, bool ok, D dflt) {
+  const T v = ld_stream(p + (ok ? k : 0u));
+  return ok ? v : static_cast<T>(dflt);
+}
 // word written by another agent (the host) while the kernel runs: bypasses this CU's L1
 MODLE_DEV uint32_t load_agent_u32(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

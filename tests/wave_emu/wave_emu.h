@@ -198,6 +198,28 @@ template <class T>
 MODLE_DEV T ld_stream(const T* p) { return *p; }
 template <class T>
 MODLE_DEV void st_stream(T* p, T v) { *p = v; }
+template <class T>
+MODLE_DEV T known_uniform(T v) { return v; }
+// The two halves of ld_sel for loads that are requested one group ahead of their use: LdRaw at
+// the request (no select, hence no wait, behind the load), LdMask where the values are consumed.
+// A loader written as `r.x = op(p, k, ok, dflt, r.x)` serves both.
+struct LdRaw {
+  template <class T, class D>
+  T operator()(const T* p, uint32_t k, bool ok, D dflt, T) const {
+    (void)dflt;
+    return ok ? p[k] : static_cast<T>(dflt);
+  }
+};
+struct LdMask {
+  template <class T, class D>
+  T operator()(const T*, uint32_t, bool ok, D dflt, T cur) const {
+    return ok ? cur : static_cast<T>(dflt);
+  }
+};
+template <class T, class D>
+MODLE_DEV T ld_sel(const T* p, uint32_t k, bool ok, D dflt) {
+  return ok ? p[k] : static_cast<T>(dflt);
+}
 MODLE_DEV uint32_t load_agent_u32(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
 MODLE_DEV void atomic_inc_u32(uint32_t* p) { __atomic_fetch_add(p, 1u, __ATOMIC_RELAXED); }
 MODLE_DEV void atomic_add_u64(uint64_t* p, uint64_t v) {
