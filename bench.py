@@ -296,6 +296,7 @@ def main():
     n_tasks = 0
     step_bytes = 0
     epochs = 0
+    longest = 0  # epochs of the longest cell: a launch with fewer tasks than wave slots lasts as long as it does
     for entry, iid in zip(plan, ids):
         if iid is None:
             continue
@@ -305,6 +306,7 @@ def main():
         step_bytes += driver.algorithmic_bytes(last, len(entry["interval"]["bar_pos"]),
                                                bool(cfg.track_1d_lef_position))
         epochs += sum(r.epochs for r in last)
+        longest = max(longest, max((r.epochs for r in last), default=0))
         n_tasks += k
     avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3 if kernel_ms else float("nan")
     achieved = step_bytes / avg_kernel_s / 1e9
@@ -349,7 +351,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "cells_per_gpu": cells_per_gpu,
                        "total_cells": total_cells, "tasks_per_gpu": n_tasks,
-                       "cell_epochs_per_gpu_step": epochs, "seed": 0,
+                       "cell_epochs_per_gpu_step": epochs,
+                       "longest_cell_epochs": longest, "mean_cell_epochs": epochs / max(n_tasks, 1), "seed": 0,
                        "parallelism": f"cells sharded over {world} GPU(s); per-interval RCCL sum-reduce "
                                       "issued on a side stream as intervals complete"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
