@@ -179,6 +179,13 @@ template <class T>
 MODLE_DEV T ld_stream(const T* p) { return __builtin_nontemporal_load(p); }
 template <class T>
 MODLE_DEV void st_stream(T* p, T v) { __builtin_nontemporal_store(v, p); }
+#elif defined(MODLE_L1_BYPASS)
+// experiment: the loads of the sweeps go to L2 directly (agent scope: the vector L1 does not look
+// them up, hence cannot stall on a line that is still on its way)
+template <class T>
+MODLE_DEV T ld_stream(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T>
+MODLE_DEV void st_stream(T* p, T v) { *p = v; }
 #else
 template <class T>
 MODLE_DEV T ld_stream(const T* p) { return *p; }
