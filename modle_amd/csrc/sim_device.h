@@ -759,6 +759,137 @@ MODLE_DEV_NOINLINE void generate_moves_by_id(Cell& c, f64 speed, f64 std, u32* m
 // update changes the answer are replayed sequentially from the first affected rank.
 // `do_adjust` / `do_clamp` exist for the phase-level test entry point.
 // =============================================================================================
+// The same two sweeps with FOUR consecutive ranks per lane (blocks of 256 ranks; used whenever the
+// 32-bit scan applies, i.e. on every real chromosome): one 128-bit load per array and lane, the
+// scan runs over the four units of a lane in registers, ONE cross-lane scan joins the 64 lanes,
+// and the carries, the loop control and the violation test are paid once per 256 units instead
+// of once per 64.  rev: lane 0 holds the highest ranks of a block and a lane walks its four units
+// downwards, so that the suffix scan over ranks is again a prefix scan over (lane, unit).
+// Returns the rank the sequential replay has to start from (adjust_moves_rev / _fwd), or -1.
+template <bool FWD>
+MODLE_DEV_NOINLINE i64 adjust_moves_x4(Cell& c, bool do_adjust, bool do_clamp, const u32* mv_by_id) {
+  Workspace& ws = c.ws;
+  const u32 n = wave::uniform(c.n_active);
+  const u32 lane = wave::lane();
+  const u32 start = c.iv->start;
+  const u32 last = c.iv->end - 1;
+  const u32* pos = FWD ? ws.f_pos : ws.r_pos;
+  const u32* uid = FWD ? ws.f_id : ws.r_id;
+  const u32* mv_in = FWD ? ws.f_move : ws.r_move;
+  u32* mv_out = ws.tmp[0];
+  const bool by_id = mv_by_id != nullptr;
+  const u32 nblk = (n + 255) / 256;
+  i32 carry_d = 0;
+  bool carry_ok = false, carry_cross = false;
+  i64 viol_rank = -1;
+  // first rank of this lane in block t of the sweep (t = 0 is the block the sweep starts with)
+  const auto word0 = [&](u32 t) { return (FWD ? t : nblk - 1 - t) * 256 + 4 * (FWD ? lane : 63 - lane); };
+  struct Blk {
+    wave::U32x4 P, M;
+  };
+  // the ids of a block are requested one block ahead of its positions and (gathered) moves
+  const auto load_ids = [&](u32 t, wave::U32x4& I) {
+    const u32 w = word0(t);
+    I = wave::ld4(uid, (by_id && t < nblk && w < n) ? w : 0u);
+  };
+  const auto load_blk = [&](u32 t, const wave::U32x4& I, Blk& r) {
+    const u32 w = word0(t);
+    const bool in = t < nblk && w < n;
+    r.P = wave::ld4(pos, in ? w : 0u);
+    if (by_id) {
+#pragma unroll
+      for (u32 q = 0; q < 4; ++q) r.M.v[q] = wave::LdRaw{}(mv_by_id, I.v[q], in && w + q < n, 0, 0u);
+    } else {
+      r.M = wave::ld4(mv_in, in ? w : 0u);
+    }
+  };
+  wave::U32x4 ids;
+  Blk cur;
+  load_ids(0, ids);
+  load_blk(0, ids, cur);
+  if (1 < nblk) load_ids(1, ids);
+  for (u32 t = 0; t < nblk; ++t) {
+    const Blk g = cur;
+    if (t + 1 < nblk) {
+      load_blk(t + 1, ids, cur);
+      if (t + 2 < nblk) load_ids(t + 2, ids);
+    }
+    const u32 w = word0(t);
+    u32 P[4], M[4], k[4];
+    bool bnd[4], ok[4];
+    i32 d[4];
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j) {  // j: position in sweep order inside the lane
+      const u32 q = FWD ? j : 3 - j;
+      k[j] = w + q;
+      const bool act = k[j] < n;
+      P[j] = g.P.v[q];
+      M[j] = g.M.v[q];
+      bnd[j] = act && P[j] != UNBOUND;
+      if (FWD) {
+        ok[j] = do_adjust && bnd[j] && static_cast<u64>(P[j]) + M[j] <= last;
+        d[j] = ok[j] ? static_cast<i32>(P[j] + M[j] - k[j]) : 0;
+      } else {
+        ok[j] = do_adjust && bnd[j] && static_cast<u64>(P[j]) > static_cast<u64>(start) + M[j];
+        d[j] = ok[j] ? static_cast<i32>(P[j] - M[j] - k[j]) : 0;
+      }
+    }
+    const auto pick = [](i32 a, i32 b) { return FWD ? (a > b ? a : b) : (a < b ? a : b); };
+    const bool ok_in = wave::shfl_up1(ok[3]);
+    bool link[4], open[4];  // link: to the unit before; open: the chain reaches the start of the lane
+    i32 v[4];
+    link[0] = ok[0] && (lane > 0 ? ok_in : carry_ok);
+    open[0] = link[0];
+    v[0] = d[0];
+#pragma unroll
+    for (u32 j = 1; j < 4; ++j) {
+      link[j] = ok[j] && ok[j - 1];
+      v[j] = link[j] ? pick(d[j], v[j - 1]) : d[j];
+      open[j] = link[j] && open[j - 1];
+    }
+    const SegScan inc = wave_prefix_segscan32<FWD>(v[3], open[3]);
+    const i32 inc_val = static_cast<i32>(inc.val);
+    const i32 whole = inc.cont ? pick(inc_val, carry_d) : inc_val;  // scan value of the lane's last unit
+    const i32 whole_in = static_cast<i32>(wave::shfl_up1(static_cast<u32>(whole)));
+    const i32 before = lane > 0 ? whole_in : carry_d;
+    bool cross[4];
+    wave::U32x4 O;
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j) {
+      const i32 val = open[j] ? pick(v[j], before) : v[j];
+      u32 Mnew = M[j];
+      if (ok[j]) Mnew = FWD ? static_cast<u32>(val) + k[j] - P[j] : P[j] - (static_cast<u32>(val) + k[j]);
+      cross[j] = ok[j] && (FWD ? static_cast<u64>(P[j]) + Mnew > last
+                               : static_cast<u64>(P[j]) <= static_cast<u64>(start) + Mnew);
+      O.v[FWD ? j : 3 - j] = (bnd[j] && do_clamp) ? umin(Mnew, FWD ? last - P[j] : P[j] - start) : Mnew;
+    }
+    if (w + 3 < n) {
+      wave::st4(mv_out, w, O);
+    } else {
+#pragma unroll
+      for (u32 q = 0; q < 4; ++q) {
+        if (w + q < n) mv_out[w + q] = O.v[q];
+      }
+    }
+    // first unit in sweep order whose link leads to a unit that crosses the end with its updated move
+    const bool cross_in = wave::shfl_up1(cross[3]);
+    const bool viol0 = link[0] && (lane > 0 ? cross_in : carry_cross);
+    const bool viol1 = link[1] && cross[0], viol2 = link[2] && cross[1], viol3 = link[3] && cross[2];
+    const u64 vm = wave::ballot(viol0 || viol1 || viol2 || viol3);
+    if (vm != 0 && viol_rank < 0) {
+      const u32 fl = static_cast<u32>(wave::ctz64(vm));
+      const u32 jf = wave::bcast(viol0 ? 0u : viol1 ? 1u : viol2 ? 2u : 3u, fl);
+      const u32 s = 4 * fl + jf;
+      const u32 b = FWD ? t : nblk - 1 - t;
+      viol_rank = FWD ? static_cast<i64>(b) * 256 + s - 1 : static_cast<i64>(b) * 256 + (255 - s) + 1;
+    }
+    carry_d = wave::bcast(whole, 63);
+    carry_ok = wave::bcast(ok[3], 63);
+    carry_cross = wave::bcast(cross[3], 63);
+  }
+  return viol_rank;
+}
+
 // `mv_by_id`: moves in LEF-id order (generate_moves_by_id) or nullptr when they already sit in
 // r_move in rank order (phase-level test entry point).
 MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp,
@@ -778,6 +909,9 @@ MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp,
   i64 viol_rank = -1;
   // lanes hold the ranks of a batch in DESCENDING order (lane 0 = highest rank), so that the
   // suffix scan over ranks is a prefix scan over lanes
+  if (narrow) {
+    viol_rank = adjust_moves_x4<false>(c, do_adjust, do_clamp, mv_by_id);
+  } else {
   constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
   struct UnitRegs {
     u32 P[UX], M[UX];
@@ -849,6 +983,7 @@ MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp,
     carry_cross = wave::bcast(cross, 63);
     }
   }
+  }
   wave::sync_mem();
   if (viol_rank >= 0) {
     // sequential replay (reference loop) from the first rank whose decision the scan got wrong.
@@ -891,6 +1026,9 @@ MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp,
   i64 carry_d = 0;
   bool carry_ok = false, carry_cross = false;
   i64 viol_rank = -1;
+  if (narrow) {
+    viol_rank = adjust_moves_x4<true>(c, do_adjust, do_clamp, mv_by_id);
+  } else {
   constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
   struct UnitRegs {
     u32 P[UX], M[UX];
@@ -958,6 +1096,7 @@ MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp,
     carry_ok = wave::bcast(okself, 63);
     carry_cross = wave::bcast(cross, 63);
     }
+  }
   }
   wave::sync_mem();
   if (viol_rank >= 0) {

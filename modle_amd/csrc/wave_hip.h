@@ -199,6 +199,13 @@ MODLE_DEV T known_uniform(T v) { return uniform(v); }
 // p[k] where `ok`, `dflt` elsewhere, without a divergent branch around the load: lanes that are
 // not `ok` read p[0] (p must point at one readable element at least) and drop it.  The compiler keeps
 // an `ok ? p[k] : dflt` as s_and_saveexec / s_cbranch_execz around every single load.
+// four consecutive words as one 128-bit access: p + k must be 16-byte aligned (k a multiple of 4
+// in an array that starts on a 16-byte boundary)
+struct alignas(16) U32x4 {
+  uint32_t v[4];
+};
+MODLE_DEV U32x4 ld4(const uint32_t* p, uint32_t k) { return *reinterpret_cast<const U32x4*>(p + k); }
+MODLE_DEV void st4(uint32_t* p, uint32_t k, const U32x4& x) { *reinterpret_cast<U32x4*>(p + k) = x; }
 // The two halves of ld_sel for loads that are requested one group ahead of their use: LdRaw at
 // the request (no select, hence no wait, behind the load), LdMask where the values are consumed.
 // A loader written as `r.x = op(p, k, ok, dflt, r.x)` serves both.

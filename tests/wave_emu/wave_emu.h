@@ -200,6 +200,19 @@ template <class T>
 MODLE_DEV void st_stream(T* p, T v) { *p = v; }
 template <class T>
 MODLE_DEV T known_uniform(T v) { return v; }
+// four consecutive words as one 128-bit access: p + k must be 16-byte aligned (k a multiple of 4
+// in an array that starts on a 16-byte boundary)
+struct U32x4 {
+  uint32_t v[4];
+};
+MODLE_DEV U32x4 ld4(const uint32_t* p, uint32_t k) {
+  U32x4 x;
+  for (int q = 0; q < 4; ++q) x.v[q] = p[k + q];
+  return x;
+}
+MODLE_DEV void st4(uint32_t* p, uint32_t k, const U32x4& x) {
+  for (int q = 0; q < 4; ++q) p[k + q] = x.v[q];
+}
 // The two halves of ld_sel for loads that are requested one group ahead of their use: LdRaw at
 // the request (no select, hence no wait, behind the load), LdMask where the values are consumed.
 // A loader written as `r.x = op(p, k, ok, dflt, r.x)` serves both.
