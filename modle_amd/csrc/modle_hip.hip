@@ -767,13 +767,14 @@ int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen) {
   {
     static const char* names[16] = {"burnin_stats", "bind", "rank_rev", "rank_fwd", "sample", "gen_moves",
                                     "adjust_moves", "barriers+clear", "boundaries", "lef_bar", "primary",
-                                    "secondary", "fix_secondary", "extrude_release", "-", "-"};
+                                    "secondary", "fix_secondary", "extrude_release", "sub_a", "sub_b"};
     u64 ticks[16];
     HIP_TRY(hipMemcpy(ticks, h->d_phase_ticks.p, sizeof(ticks), hipMemcpyDeviceToHost));
     u64 total = 0;
     for (int i = 0; i < 14; ++i) total += ticks[i];
     std::fprintf(stderr, "[modle_hip prof] kernel %.1f ms, wave-time per phase (sum over waves, 100 MHz ticks):\n", h->last_ms);
-    for (int i = 0; i < 14; ++i)
+    for (int i = 0; i < 16; ++i)
+      if (i < 14 || ticks[i] != 0)  // (14, 15: free for a measurement inside a phase)
       std::fprintf(stderr, "  %-16s %12.3f s  %5.1f %%\n", names[i], static_cast<double>(ticks[i]) * 1e-8,
                    total ? 100.0 * static_cast<double>(ticks[i]) / static_cast<double>(total) : 0.0);
   }

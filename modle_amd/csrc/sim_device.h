@@ -32,6 +32,10 @@ struct Cell {
   u32 n_rel;
   bool rel_valid;
   u32 n_bound;    // LEFs [0, n_bound) have been bound at least once (the rest were just activated)
+  // phase_bind_listed leaves the sort keys of the units it bound ((position << 32) | rank slot, one
+  // set per direction, in ws.tmp[2..3] / ws.tmp[4..5]) for the two rank updates that follow it
+  u32 n_keys;
+  bool keys_valid;
 #ifdef MODLE_PHASE_TIMERS
   u64 ph[16];     // profiling build: time spent per phase (wave::clock ticks)
 #endif
@@ -88,6 +92,7 @@ MODLE_DEV u32 lower_bound_u32(const u32* a, u32 n, u32 key) {  // first index wi
 // =============================================================================================
 MODLE_DEV_NOINLINE void phase_bind(Cell& c, u32 epoch_now) {
   const Interval& iv = *c.iv;
+  c.keys_valid = false;
   Workspace& ws = c.ws;
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
@@ -176,6 +181,8 @@ MODLE_DEV_NOINLINE void phase_bind_listed(Cell& c, u32 epoch_now) {
   const bool fast_div = bucket <= (u64(1) << 62) && bucket >= (u64(1) << 24);
   const f64 inv_bucket = 1.0 / static_cast<f64>(bucket);
   const u32* list = reinterpret_cast<const u32*>(c.lds.sort_lds);
+  u64* keys_rev = reinterpret_cast<u64*>(ws.tmp[2]);  // (two arrays each: capacity >= total keys)
+  u64* keys_fwd = reinterpret_cast<u64*>(ws.tmp[4]);
   for (u32 base = 0; base < total; base += 64) {
     const u32 e = base + lane;
     const bool act = e < total;
@@ -209,10 +216,14 @@ MODLE_DEV_NOINLINE void phase_bind_listed(Cell& c, u32 epoch_now) {
       ws.r_move[kr] = NEW_MARK;
       ws.f_pos[kf] = posv;
       ws.f_move[kf] = NEW_MARK;
+      keys_rev[e] = (static_cast<u64>(posv) << 32) | kr;
+      keys_fwd[e] = (static_cast<u64>(posv) << 32) | kf;
     }
   }
   c.n_rel = 0;
   c.n_bound = c.n_active;
+  c.n_keys = total;
+  c.keys_valid = true;
   wave::sync_mem();
 }
 
@@ -402,15 +413,319 @@ MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_
   return ties;
 }
 
+// Steps 4 and 5 of a rank update: order equal positions, make the new arrays current.
+// Every pair of neighbours with equal positions lies inside the output slots [t_lo, t_hi] (the
+// sweeps flag at least one member of every such pair): the transposition passes stay inside that
+// range (one slot of margin on both sides) and keep the inverse permutation up to date as they go.
+template <bool FWD>
+MODLE_DEV void rank_finish(Cell& c, bool ties, const u32* where, u32 t_lo, u32 t_hi) {
+  Workspace& ws = c.ws;
+  const u32 n = wave::uniform(c.n_active);
+  const u32 lane = wave::lane();
+  u32*& pos = FWD ? ws.f_pos : ws.r_pos;
+  u32*& ids = FWD ? ws.f_id : ws.r_id;
+  u32* out_pos = ws.tmp[0];
+  u32* out_id = ws.tmp[1];
+  u32* where_new = ws.tmp[7];
+  if (ties) {
+    // 4. order equal positions (epoch rule, then previous rank) with a stable odd-even
+    //    transposition
+    const u32 s_lo = t_lo > 0 ? t_lo - 1 : 0;
+    const u32 s_hi = umin(n, t_hi + 2);  // slots [s_lo, s_hi)
+    bool bad = true;
+    while (bad) {
+      bad = false;
+      for (u32 parity = 0; parity < 2; ++parity) {
+        for (u32 base = s_lo & ~1u; base < s_hi; base += 128) {
+          const u32 k = base + 2 * lane + parity;
+          bool sw = false;
+          if (k >= s_lo && k + 1 < s_hi) {
+            const u32 pa = out_pos[k], pb = out_pos[k + 1];
+            if (pa == pb) {
+              const u32 ia = out_id[k], ib = out_id[k + 1];
+              if (rank_pair_out_of_order<FWD>(ws, where, pa, ia, pb, ib)) {
+                out_id[k] = ib;
+                out_id[k + 1] = ia;
+                where_new[ib] = k;
+                where_new[ia] = k + 1;
+                sw = true;
+              }
+            }
+          }
+          bad = wave::any(sw) || bad;
+        }
+        wave::sync_mem();
+      }
+    }
+  }
+  // 5. the new arrays become current
+  swap_ptr(pos, ws.tmp[0]);
+  swap_ptr(ids, ws.tmp[1]);
+  if (FWD) swap_ptr(ws.f_rank, ws.tmp[7]); else swap_ptr(ws.r_rank, ws.tmp[7]);
+}
+
+// The rank update of the epoch loop when phase_bind_listed has left the keys of the units it bound
+// (c.keys_valid): no split pass, and four consecutive ranks per lane.  The keys are sorted in LDS,
+// then ONE sweep over the incoming rank order sends every carried-over unit to (its index among the
+// carried-over units) + (keys before it) and notes, per key, how many carried-over units precede
+// it; the new units follow from that.  Per block of 256 ranks: three 128-bit loads per lane, three
+// cross-lane scans (running maximum of the carried-over positions, new units so far, keys so far)
+// and four independent key searches per lane.
+// Carried-over units that are out of order (a unit that went past another one behind an avoided
+// secondary collision; every epoch has a few) are re-inserted like new units: a light sweep
+// (positions and marks only) finds them first and adds their keys.
+// Returns false -- nothing committed, the caller runs the general update -- when the keys do not
+// fit the LDS buffers.
+template <bool FWD>
+MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
+  Workspace& ws = c.ws;
+  const u32 n = wave::uniform(c.n_active);
+  const u32 n_listed = wave::uniform(c.n_keys);
+  const u32 lane = wave::lane();
+  const u32* pos = FWD ? ws.f_pos : ws.r_pos;
+  const u32* ids = FWD ? ws.f_id : ws.r_id;
+  const u32* marks = FWD ? ws.f_move : ws.r_move;
+  u64* keys = c.lds.sort_lds;
+  u32* cnt_lds = c.lds.stage;
+  const u64* src = reinterpret_cast<const u64*>(FWD ? ws.tmp[4] : ws.tmp[2]);
+  u32* out_pos = ws.tmp[0];
+  u32* out_id = ws.tmp[1];
+  u32* where_new = ws.tmp[7];
+  const u32 nblk = (n + 255) / 256;
+  wave::lockstep();
+  for (u32 base = 0; base < n_listed; base += 64) {
+    const u32 k = base + lane;
+    const u64 kv = wave::ld_sel(src, k, k < n_listed, ~u64(0));
+    if (k < n_listed) keys[k] = kv;
+  }
+  // the out-of-order units: carried-over units below the running maximum of the carried-over
+  // units before them
+  u32 n_new = n_listed;
+  {
+    struct Pre {
+      wave::U32x4 P, K;
+    };
+    const auto load_pre = [&](u32 t, Pre& r) {
+      const u32 w = 256 * t + 4 * lane;
+      const u32 wq = w < n ? w : 0u;
+      r.P = wave::ld4(pos, wq);
+      r.K = wave::ld4(marks, wq);
+    };
+    u32 run_max = 0;
+    Pre cur;
+    load_pre(0, cur);
+    for (u32 t = 0; t < nblk; ++t) {
+      const Pre g = cur;
+      if (t + 1 < nblk) load_pre(t + 1, cur);
+      const u32 w = 256 * t + 4 * lane;
+      u32 mx[4];
+      bool carried[4];
+#pragma unroll
+      for (u32 j = 0; j < 4; ++j) {
+        carried[j] = w + j < n && g.K.v[j] != NEW_MARK;
+        const u32 cp = carried[j] ? g.P.v[j] : 0u;
+        mx[j] = j == 0 ? cp : umax(mx[j - 1], cp);
+      }
+      const u32 pm = wave_prefix_max_u32(mx[3]);
+      const u32 pm_prev = wave::shfl_up1(pm);
+      const u32 lane_excl = umax(run_max, lane > 0 ? pm_prev : 0);
+      run_max = umax(run_max, wave::bcast(pm, 63));
+      bool disp[4];
+      bool any_d = false;
+#pragma unroll
+      for (u32 j = 0; j < 4; ++j) {
+        disp[j] = carried[j] && g.P.v[j] < (j == 0 ? lane_excl : umax(lane_excl, mx[j - 1]));
+        any_d = any_d || disp[j];
+      }
+      if (wave::any(any_d)) {
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          const u64 dm = wave::ballot(disp[j]);
+          const u32 e = n_new + static_cast<u32>(wave::popc64(dm & lanemask_lt(lane)));
+          if (disp[j] && e < STAGE_CAP) keys[e] = (static_cast<u64>(g.P.v[j]) << 32) | (w + j);
+          n_new += static_cast<u32>(wave::popc64(dm));
+        }
+      }
+    }
+  }
+  if (n_new > STAGE_CAP) return false;
+  const u32 n_old = n - n_new;
+  const u32 m2 = n_new != 0 ? pow2_ceil(n_new) : 0;
+  for (u32 k = n_new + lane; k < m2; k += 64) keys[k] = ~u64(0);
+  for (u32 j = lane; j < n_new; j += 64) cnt_lds[j] = n_old;
+  wave::sync_lds();
+  PHASE(c, 14, if (m2 > 1) bitonic_sort_u64<true>(keys, m2));
+
+  bool ties = false;
+  u32 t_lo = 0xFFFFFFFFu, t_hi = 0;  // output slots of the units flagged for equal positions
+  u32 seen_new = 0;   // new units in the blocks before this one
+  u32 run_max = 0;    // max position of the carried-over units before this block
+  u32 carry_lo = 0;   // keys before the last carried-over unit so far
+  struct Blk {
+    wave::U32x4 P, I, K;
+  };
+  const auto load_blk = [&](u32 t, Blk& r) {
+    const u32 w = 256 * t + 4 * lane;
+    const u32 wq = w < n ? w : 0u;
+    r.P = wave::ld4(pos, wq);
+    r.I = wave::ld4(ids, wq);
+    r.K = wave::ld4(marks, wq);
+  };
+  Blk cur;
+  load_blk(0, cur);
+  for (u32 t = 0; t < nblk; ++t) {
+    const Blk g = cur;
+    if (t + 1 < nblk) load_blk(t + 1, cur);
+    const u32 w = 256 * t + 4 * lane;
+    u32 pp[4], oid[4], mx[4], nb[4];
+    bool carried[4];  // here: carried over AND still in order (the units that keep their order)
+    bool act4[4];
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j) {
+      act4[j] = w + j < n;
+      pp[j] = g.P.v[j];
+      oid[j] = g.I.v[j];
+      carried[j] = act4[j] && g.K.v[j] != NEW_MARK;
+      const u32 cp = carried[j] ? pp[j] : 0u;
+      mx[j] = j == 0 ? cp : umax(mx[j - 1], cp);  // running max of the carried-over positions
+    }
+    const u32 pm = wave_prefix_max_u32(mx[3]);
+    const u32 pm_prev = wave::shfl_up1(pm);
+    const u32 lane_excl = umax(run_max, lane > 0 ? pm_prev : 0);
+    run_max = umax(run_max, wave::bcast(pm, 63));
+    u32 excl[4];  // position of the carried-over unit before unit j (0: none)
+    u32 lane_new = 0;
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j) {
+      excl[j] = j == 0 ? lane_excl : umax(lane_excl, mx[j - 1]);
+      carried[j] = carried[j] && !(pp[j] < excl[j]);  // (an out-of-order unit never raises the maximum)
+      nb[j] = lane_new;  // re-inserted units of this lane before unit j
+      lane_new += (act4[j] && !carried[j]) ? 1u : 0u;
+    }
+    const u32 ps = wave_prefix_sum_u32(lane_new);
+    const u32 lane_before = seen_new + ps - lane_new;
+    seen_new += wave::bcast(ps, 63);
+    // lo = number of keys that go before the unit (see rank_merge): four searches side by side
+    u32 lo[4];
+    u64 thr[4];
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j) {
+      lo[j] = carried[j] ? carry_lo : 0u;
+      thr[j] = FWD ? ((static_cast<u64>(pp[j]) + 1) << 32) : (static_cast<u64>(pp[j]) << 32);
+    }
+#pragma unroll
+    for (u32 sft = 8; sft >= 1; sft >>= 1) {
+#pragma unroll
+      for (u32 j = 0; j < 4; ++j) {
+        const u32 jx = lo[j] + sft;
+        const bool in = carried[j] & (jx <= n_new);
+        const u64 kv = keys[in ? jx - 1 : 0];  // (no branch around the read)
+        if (in & (kv < thr[j])) lo[j] = jx;
+      }
+    }
+    u32 lmx[4];
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j) {
+      if (carried[j] && lo[j] == carry_lo + 15 && lo[j] < n_new) {
+        u32 hi = n_new;
+        u32 l = lo[j];
+        while (l < hi) {
+          const u32 mid = (l + hi) >> 1;
+          if (keys[mid] < thr[j]) l = mid + 1; else hi = mid;
+        }
+        lo[j] = l;
+      }
+      const u32 cl = carried[j] ? lo[j] : 0u;
+      lmx[j] = j == 0 ? cl : umax(lmx[j - 1], cl);  // keys before the carried-over units so far
+    }
+    const u32 lpm = wave_prefix_max_u32(lmx[3]);
+    const u32 lpm_prev = wave::shfl_up1(lpm);
+    const u32 lane_lo = umax(carry_lo, lane > 0 ? lpm_prev : 0);
+    carry_lo = umax(carry_lo, wave::bcast(lpm, 63));
+    bool tie = false;
+    u32 tie_lo = 0xFFFFFFFFu, tie_hi = 0;
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j) {
+      if (carried[j]) {
+        const u32 a = w + j - (lane_before + nb[j]);
+        // keys [lo of the carried-over unit before, lo) lie between that unit and this one
+        const u32 lo_prev = j == 0 ? lane_lo : umax(lane_lo, lmx[j - 1]);
+        for (u32 q = lo_prev; q < lo[j]; ++q) cnt_lds[q] = a;
+        if (pp[j] != UNBOUND) {
+          bool tj;
+          if (FWD) {
+            tj = lo[j] > 0 && static_cast<u32>(keys[lo[j] - 1] >> 32) == pp[j];
+          } else {
+            tj = lo[j] < n_new && static_cast<u32>(keys[lo[j]] >> 32) == pp[j];
+          }
+          tj = tj || (a > 0 && excl[j] == pp[j]);
+          if (tj) {
+            tie = true;
+            tie_lo = umin(tie_lo, a + lo[j]);
+            tie_hi = umax(tie_hi, a + lo[j]);
+          }
+        }
+        out_pos[a + lo[j]] = pp[j];
+        out_id[a + lo[j]] = oid[j];
+        where_new[oid[j]] = a + lo[j];
+      }
+    }
+    if (wave::any(tie)) {
+      ties = true;
+      t_lo = umin(t_lo, ~wave::bcast(wave_prefix_max_u32(~tie_lo), 63));
+      t_hi = umax(t_hi, wave::bcast(wave_prefix_max_u32(tie_hi), 63));
+    }
+  }
+  if (seen_new != n_new) return false;  // (the marks and the list disagree: cannot happen)
+  wave::sync_lds();
+#ifdef MODLE_PHASE_TIMERS
+  const u64 t15_ = wave::clock();
+#endif
+  for (u32 base = 0; base < n_new; base += 64) {
+    const u32 bq = base + lane;
+    bool tie = false;
+    if (bq < n_new) {
+      const u64 key = keys[bq];
+      const u32 pp = static_cast<u32>(key >> 32);
+      const u32 lo = cnt_lds[bq];
+      const u32 nid = ids[static_cast<u32>(key)];  // the slot the unit was bound in
+      wave::st_stream(&out_pos[bq + lo], pp);
+      wave::st_stream(&out_id[bq + lo], nid);
+      where_new[nid] = bq + lo;
+      tie = bq + 1 < n_new && static_cast<u32>(keys[bq + 1] >> 32) == pp;
+    }
+    if (wave::any(tie)) {
+      ties = true;
+      const u32 slot = bq < n_new ? bq + cnt_lds[bq < n_new ? bq : 0] : 0;
+      t_lo = umin(t_lo, ~wave::bcast(wave_prefix_max_u32(tie ? ~slot : 0u), 63));
+      t_hi = umax(t_hi, wave::bcast(wave_prefix_max_u32(tie ? slot : 0u), 63));
+    }
+  }
+  wave::sync_mem();
+  rank_finish<FWD>(c, ties, FWD ? ws.f_rank : ws.r_rank, t_lo, t_hi);
+#ifdef MODLE_PHASE_TIMERS
+  c.ph[15] += wave::clock() - t15_;
+#endif
+  return true;
+}
+
 // all_new: treat every entry as newly bound (full sort; used by the phase-level test entry point)
 template <bool FWD>
 MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
   Workspace& ws = c.ws;
   const u32 n = wave::uniform(c.n_active);
   if (n < 2) return;
+  {
+    const bool listed = !all_new && c.keys_valid && c.n_keys <= STAGE_CAP;
+    if (listed && rank_update_listed<FWD>(c)) {
+      if (FWD) c.keys_valid = false;  // (the keys serve the rev update, then the fwd update)
+      return;
+    }
+    c.keys_valid = false;  // (the general update below overwrites the arrays that hold them)
+  }
   const u32 lane = wave::lane();
-  u32*& pos = FWD ? ws.f_pos : ws.r_pos;
-  u32*& ids = FWD ? ws.f_id : ws.r_id;
+  const u32* pos = FWD ? ws.f_pos : ws.r_pos;
+  const u32* ids = FWD ? ws.f_id : ws.r_id;
   const u32* marks = FWD ? ws.f_move : ws.r_move;
   u32* where = FWD ? ws.f_rank : ws.r_rank;  // previous ranks until the final scatter
   u32* old_pos = ws.tmp[2];
@@ -521,42 +836,7 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
                         : rank_merge<FWD>(keys_glb, n_new, n_old, old_pos, old_id, new_id, out_pos,
                                           out_id, where_new, c.lds.stage);
   wave::sync_mem();
-  if (ties) {
-    // 4. order equal positions (epoch rule, then previous rank) with a stable odd-even
-    //    transposition, then rebuild the inverse permutation
-    bool bad = true;
-    while (bad) {
-      bad = false;
-      for (u32 parity = 0; parity < 2; ++parity) {
-        for (u32 base = 0; base < n; base += 128) {
-          const u32 k = base + 2 * lane + parity;
-          bool sw = false;
-          if (k + 1 < n) {
-            const u32 pa = out_pos[k], pb = out_pos[k + 1];
-            const u32 ia = out_id[k], ib = out_id[k + 1];
-            if (rank_pair_out_of_order<FWD>(ws, where, pa, ia, pb, ib)) {
-              out_pos[k] = pb;
-              out_pos[k + 1] = pa;
-              out_id[k] = ib;
-              out_id[k + 1] = ia;
-              sw = true;
-            }
-          }
-          bad = wave::any(sw) || bad;
-        }
-        wave::sync_mem();
-      }
-    }
-    for (u32 base = 0; base < n; base += 64) {
-      const u32 k = base + lane;
-      if (k < n) where_new[out_id[k]] = k;
-    }
-    wave::sync_mem();
-  }
-  // 5. the new arrays become current
-  swap_ptr(pos, ws.tmp[0]);
-  swap_ptr(ids, ws.tmp[1]);
-  if (FWD) swap_ptr(ws.f_rank, ws.tmp[7]); else swap_ptr(ws.r_rank, ws.tmp[7]);
+  rank_finish<FWD>(c, ties, where, 0, n - 1);
 }
 
 // =============================================================================================
@@ -3162,6 +3442,8 @@ MODLE_DEV void init_cell(Cell& c, const Params& p, const Interval& iv, const Wor
   c.n_hit[1] = 0;
   c.n_rel = 0;
   c.rel_valid = false;  // the epoch loop turns the list on; the phase-level hooks sweep
+  c.keys_valid = false;
+  c.n_keys = 0;
   c.n_bound = 0;
 #ifdef MODLE_PHASE_TIMERS
   for (int i = 0; i < 16; ++i) c.ph[i] = 0;
