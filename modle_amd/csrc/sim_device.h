@@ -2876,112 +2876,156 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
   const f64 base_p = burnin_completed ? p.p_release : p.p_release_burnin;
-  // extrude in rank order (rev and fwd units of the same rank in one step: their loads are
-  // independent); units stalled by a barrier that blocks their own direction ("hard" stalls)
-  // are reported to their LEF through stall[id].  The collision words are consumed here, so
-  // they are cleared on the way (the next epoch starts with clean arrays).
-  // The loads of the next group of batches are issued before the stores of the current one: a
+  // extrude in rank order, four consecutive ranks per lane (128-bit accesses; rev and fwd units of
+  // the same ranks in one step: their loads are independent); units stalled by a barrier that
+  // blocks their own direction ("hard" stalls) are reported to their LEF through stall[id].  The
+  // collision words are consumed here, so they are cleared on the way (the next epoch starts with
+  // clean arrays).  The loads of the next block are issued before the stores of the current one: a
   // wait for a load also waits for every store issued before it.
-  constexpr u32 UX = 4;  // batches per group
+  const u32 nblk = (n + 255) / 256;
   struct UnitRegs {
-    u32 rP[UX], rM[UX], rc[UX], fP[UX], fM[UX], fc[UX], rI[UX], fI[UX];
+    wave::U32x4 rP, rM, rc, rI, fP, fM, fc, fI;
   };
-  const auto load_units = [&](auto op, u32 base, UnitRegs& r) {
-#pragma unroll
-    for (u32 u = 0; u < UX; ++u) {
-      const u32 k = base + 64 * u + lane;
-      const bool act = k < n;
-      r.rP[u] = op(ws.r_pos, k, act, UNBOUND, r.rP[u]);
-      r.rM[u] = op(ws.r_move, k, act, 0, r.rM[u]);
-      r.rc[u] = op(ws.r_coll, k, act, 0, r.rc[u]);
-      r.rI[u] = op(ws.r_id, k, act, 0, r.rI[u]);
-      r.fP[u] = op(ws.f_pos, k, act, UNBOUND, r.fP[u]);
-      r.fM[u] = op(ws.f_move, k, act, 0, r.fM[u]);
-      r.fc[u] = op(ws.f_coll, k, act, 0, r.fc[u]);
-      r.fI[u] = op(ws.f_id, k, act, 0, r.fI[u]);
-    }
+  const auto load_units = [&](u32 t, UnitRegs& r) {
+    const u32 w = 256 * t + 4 * lane;
+    const u32 wq = w < n ? w : 0u;
+    r.rP = wave::ld4(ws.r_pos, wq);
+    r.rM = wave::ld4(ws.r_move, wq);
+    r.rc = wave::ld4(ws.r_coll, wq);
+    r.rI = wave::ld4(ws.r_id, wq);
+    r.fP = wave::ld4(ws.f_pos, wq);
+    r.fM = wave::ld4(ws.f_move, wq);
+    r.fc = wave::ld4(ws.f_coll, wq);
+    r.fI = wave::ld4(ws.f_id, wq);
   };
-  UnitRegs cur;
-  load_units(wave::LdRaw{}, 0, cur);
-  for (u32 base = 0; base < n; base += 64 * UX) {
-    UnitRegs g = cur;
-    load_units(wave::LdMask{}, base, g);  // (defaults of the lanes outside the range)
-    if (base + 64 * UX < n) load_units(wave::LdRaw{}, base + 64 * UX, cur);
+  {
+    UnitRegs cur;
+    load_units(0, cur);
+    for (u32 t = 0; t < nblk; ++t) {
+      const UnitRegs g = cur;
+      if (t + 1 < nblk) load_units(t + 1, cur);
+      const u32 w = 256 * t + 4 * lane;
+      if (w < n) {
+        wave::U32x4 nr, nf;
+        bool rc_any = false, fc_any = false;
 #pragma unroll
-    for (u32 u = 0; u < UX; ++u) {
-      const u32 k = base + 64 * u + lane;
-      if (k < n) {
-        if (g.rP[u] != UNBOUND) wave::st_stream(&ws.r_pos[k], g.rP[u] - g.rM[u]);
-        if (g.fP[u] != UNBOUND) wave::st_stream(&ws.f_pos[k], g.fP[u] + g.fM[u]);
-        if (g.rc[u] != 0) ws.r_coll[k] = 0;
-        if (g.fc[u] != 0) ws.f_coll[k] = 0;
-        if (g.rP[u] != UNBOUND && cw_occurred_as(g.rc[u], EV_LEF_BAR) && (g.rc[u] & CW_HARD))
-          wave::atomic_inc_u32(&ws.stall[g.rI[u]]);
-        if (g.fP[u] != UNBOUND && cw_occurred_as(g.fc[u], EV_LEF_BAR) && (g.fc[u] & CW_HARD))
-          wave::atomic_inc_u32(&ws.stall[g.fI[u]]);
+        for (u32 q = 0; q < 4; ++q) {
+          const bool act = w + q < n;
+          const bool rb = act && g.rP.v[q] != UNBOUND, fb = act && g.fP.v[q] != UNBOUND;
+          nr.v[q] = rb ? g.rP.v[q] - g.rM.v[q] : g.rP.v[q];
+          nf.v[q] = fb ? g.fP.v[q] + g.fM.v[q] : g.fP.v[q];
+          rc_any = rc_any || (act && g.rc.v[q] != 0);
+          fc_any = fc_any || (act && g.fc.v[q] != 0);
+          if (rb && cw_occurred_as(g.rc.v[q], EV_LEF_BAR) && (g.rc.v[q] & CW_HARD))
+            wave::atomic_inc_u32(&ws.stall[g.rI.v[q]]);
+          if (fb && cw_occurred_as(g.fc.v[q], EV_LEF_BAR) && (g.fc.v[q] & CW_HARD))
+            wave::atomic_inc_u32(&ws.stall[g.fI.v[q]]);
+        }
+        if (w + 3 < n) {
+          wave::st4(ws.r_pos, w, nr);
+          wave::st4(ws.f_pos, w, nf);
+          const wave::U32x4 zero = {{0, 0, 0, 0}};
+          if (rc_any) wave::st4(ws.r_coll, w, zero);
+          if (fc_any) wave::st4(ws.f_coll, w, zero);
+        } else {
+#pragma unroll
+          for (u32 q = 0; q < 4; ++q) {
+            if (w + q < n) {
+              ws.r_pos[w + q] = nr.v[q];
+              ws.f_pos[w + q] = nf.v[q];
+              if (g.rc.v[q] != 0) ws.r_coll[w + q] = 0;
+              if (g.fc.v[q] != 0) ws.f_coll[w + q] = 0;
+            }
+          }
+        }
       }
     }
   }
   wave::sync_mem();
   const f64 affinity_soft = 1.0 / p.soft_stall_mult, affinity_hard = 1.0 / p.hard_stall_mult;
-  // Release draws in LEF-id order.  The released LEFs (a few per cent) are listed in LDS; their
-  // units are marked afterwards from the list (the only place their ranks are needed), and the
-  // next epoch's select_and_bind_lefs binds from the same list.
+  // Release draws in LEF-id order, four consecutive ids per lane: the draw of a LEF is the raw at
+  // (stream position) + (bound LEFs with a non-zero probability before it).  The released LEFs (a
+  // few per cent) are listed in LDS; their units are marked afterwards from the list (the only
+  // place their ranks are needed), and the next epoch's select_and_bind_lefs binds from the same
+  // list.
   struct LefRegs {
-    u32 E[UX], H[UX];
+    wave::U32x4 E, H;
   };
-  const auto load_lefs = [&](auto op, u32 group, LefRegs& r) {
-#pragma unroll
-    for (u32 u = 0; u < UX; ++u) {
-      const u32 iq = group + 64 * u + lane;
-      r.E[u] = op(ws.epoch, iq, iq < n, UNBOUND, r.E[u]);
-      r.H[u] = op(ws.stall, iq, iq < n, 0, r.H[u]);
-    }
+  const auto load_lefs = [&](u32 t, LefRegs& r) {
+    const u32 w = 256 * t + 4 * lane;
+    const u32 wq = w < n ? w : 0u;
+    r.E = wave::ld4(ws.epoch, wq);
+    r.H = wave::ld4(ws.stall, wq);
   };
   u32* list = reinterpret_cast<u32*>(c.lds.sort_lds);
   u32 n_rel = 0;
   wave::lockstep();
   LefRegs lcur;
-  load_lefs(wave::LdRaw{}, 0, lcur);
-  for (u32 group = 0; group < n; group += 64 * UX) {
-    LefRegs g = lcur;
-    load_lefs(wave::LdMask{}, group, g);  // (defaults of the lanes outside the range)
-    if (group + 64 * UX < n) load_lefs(wave::LdRaw{}, group + 64 * UX, lcur);
+  load_lefs(0, lcur);
+  for (u32 t = 0; t < nblk; ++t) {
+    const LefRegs g = lcur;
+    if (t + 1 < nblk) load_lefs(t + 1, lcur);
+    const u32 w = 256 * t + 4 * lane;
+    f64 prob[4];
+    bool draws[4];
+    u32 before[4];  // draws of this lane before LEF q
+    u32 lane_draws = 0;
+    bool hard_any = false;
 #pragma unroll
-    for (u32 u = 0; u < UX; ++u) {
-    const u32 base = group + 64 * u;
-    if (base >= n) break;
-    const u32 i = base + lane;
-    const bool act = i < n;
-    const u32 ep = g.E[u];
-    const u32 hard = g.H[u];
-    const bool bnd = ep != UNBOUND;
-    f64 prob = 0.0;
-    if (act) {
-      if (hard != 0) ws.stall[i] = 0;
+    for (u32 q = 0; q < 4; ++q) {
+      const bool act = w + q < n;
+      const u32 hard = g.H.v[q];
+      hard_any = hard_any || (act && hard != 0);
       const f64 affinity = hard == 0 ? 1.0 : (hard == 1 ? affinity_soft : affinity_hard);
-      prob = affinity * base_p;
+      prob[q] = act ? affinity * base_p : 0.0;
+      draws[q] = act && g.E.v[q] != UNBOUND && prob[q] != 0.0;
+      before[q] = lane_draws;
+      lane_draws += draws[q] ? 1u : 0u;
     }
-    const bool draws = bnd && prob != 0.0;
-    const u64 dm = wave::ballot(draws);
-    const u32 cnt = static_cast<u32>(wave::popc64(dm));
-    rng_ensure(c.g, cnt);
-    const u32 k = static_cast<u32>(wave::popc64(dm & lanemask_lt(lane)));
-    const bool rel = draws && bernoulli_raw(rng_peek(c.g, c.g.pos + k), prob);
-    rng_advance(c.g, cnt);
-    const u64 rm = wave::ballot(rel);
-    if (rel) {
-      ws.epoch[i] = UNBOUND;
-      const u32 j = n_rel + static_cast<u32>(wave::popc64(rm & lanemask_lt(lane)));
-      if (j < REL_CAP) {
-        list[j] = i;
+    if (hard_any) {
+      if (w + 3 < n) {
+        const wave::U32x4 zero = {{0, 0, 0, 0}};
+        wave::st4(ws.stall, w, zero);
       } else {
-        // more releases than the list holds (the next bind then sweeps the LEFs instead)
-        ws.r_pos[ws.r_rank[i]] = UNBOUND;
-        ws.f_pos[ws.f_rank[i]] = UNBOUND;
+#pragma unroll
+        for (u32 q = 0; q < 4; ++q) {
+          if (w + q < n && g.H.v[q] != 0) ws.stall[w + q] = 0;
+        }
       }
     }
-    n_rel += static_cast<u32>(wave::popc64(rm));
+    const u32 ps = wave_prefix_sum_u32(lane_draws);
+    const u32 cnt = wave::bcast(ps, 63);
+    const u32 lane_first = ps - lane_draws;
+    rng_ensure(c.g, cnt);
+    bool rel[4];
+    u32 rel_before[4];
+    u32 lane_rel = 0;
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+      rel[q] = draws[q] && bernoulli_raw(rng_peek(c.g, c.g.pos + lane_first + before[q]), prob[q]);
+      rel_before[q] = lane_rel;
+      lane_rel += rel[q] ? 1u : 0u;
+    }
+    rng_advance(c.g, cnt);
+    if (wave::any(lane_rel != 0)) {
+      const u32 rs = wave_prefix_sum_u32(lane_rel);
+      const u32 lane_slot = n_rel + rs - lane_rel;
+#pragma unroll
+      for (u32 q = 0; q < 4; ++q) {
+        if (rel[q]) {
+          const u32 i = w + q;
+          ws.epoch[i] = UNBOUND;
+          const u32 j = lane_slot + rel_before[q];
+          if (j < REL_CAP) {
+            list[j] = i;
+          } else {
+            // more releases than the list holds (the next bind then sweeps the LEFs instead)
+            ws.r_pos[ws.r_rank[i]] = UNBOUND;
+            ws.f_pos[ws.f_rank[i]] = UNBOUND;
+          }
+        }
+      }
+      n_rel += wave::bcast(rs, 63);
     }
   }
   wave::sync_lds();
