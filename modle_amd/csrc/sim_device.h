@@ -1831,7 +1831,7 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
   const u32 j_fwd0 = bc.n3 == 0 ? n - 1 : n - bc.n3;
   u32 carry_pos = 0;
   const u32 nh = wave::uniform(c.n_hit[FWD ? 1 : 0]);
-  if (nh == 0) return;  // no barrier stalls a unit of this direction in this epoch
+  if (nh == 0 || n == 0) return;  // no barrier stalls a unit of this direction in this epoch
   const u32* hpos = ws.hit_pos[FWD ? 1 : 0];
   const u32* hidx = ws.hit_idx[FWD ? 1 : 0];
   constexpr u32 c0 = 0;
@@ -1840,195 +1840,236 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
   u32 lo_cover = 1, hi_cover = 0;   // nothing staged yet (0xFFFFFFFF: no bound)
   u32 anchor = 0;                   // rev: entries below it lie before the batch; fwd: entries at
                                     // or above it lie beyond the batch (relative to c0)
-  const u32 nbatch = (n + 63) / 64;
-  constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
-  struct UnitRegs {
-    u32 P[UX], M[UX];
+  // Four consecutive ranks per lane, blocks of 256 ranks on 256-rank boundaries (128-bit loads);
+  // rev: ranks ascending from j_rev0, fwd: ranks descending from j_fwd0 (lane 0 holds the highest
+  // ranks of a block and walks its four units downwards).  Ranks outside the sweep are masked.
+  const u32 b_first = (FWD ? j_fwd0 : j_rev0) / 256;
+  const u32 nblk = FWD ? b_first + 1 : (n + 255) / 256 - b_first;
+  const auto word0 = [&](u32 t) { return (FWD ? b_first - t : b_first + t) * 256 + 4 * (FWD ? 63 - lane : lane); };
+  struct Blk {
+    wave::U32x4 P, M;
   };
-  const auto load_units = [&](auto op, u32 bg, UnitRegs& r) {
+  const auto load_blk = [&](u32 t, Blk& r) {
+    const u32 w = word0(t);
+    const u32 wq = w < n ? w : 0u;
+    r.P = wave::ld4(pos, wq);
+    r.M = wave::ld4(moves, wq);
+  };
+  Blk cur;
+  load_blk(0, cur);
+  for (u32 t = 0; t < nblk; ++t) {
+    const Blk g = cur;
+    if (t + 1 < nblk) load_blk(t + 1, cur);
+    const u32 w = word0(t);
+    u32 k[4], P[4], lo_key[4], hi_key[4];
+    bool bnd[4];
 #pragma unroll
-    for (u32 u = 0; u < UX; ++u) {
-      // (ranks stay far below 2^31: 32-bit index arithmetic)
-      const i32 kk = FWD ? static_cast<i32>(j_fwd0) - static_cast<i32>((bg + u) * 64 + lane)
-                         : static_cast<i32>(j_rev0 + (bg + u) * 64 + lane);
-      const bool act = kk >= 0 && static_cast<u32>(kk) < n;
-      r.P[u] = op(pos, static_cast<u32>(kk), act, 0, r.P[u]);
-      r.M[u] = op(moves, static_cast<u32>(kk), act, 0, r.M[u]);
+    for (u32 j = 0; j < 4; ++j) {  // j: position in sweep order inside the lane
+      const u32 q = FWD ? 3 - j : j;
+      k[j] = w + q;
+      const bool act = FWD ? k[j] <= j_fwd0 : (k[j] >= j_rev0 && k[j] < n);
+      P[j] = act ? g.P.v[q] : 0u;
+      bnd[j] = act && P[j] != UNBOUND;
     }
-  };
-  UnitRegs cur;
-  load_units(wave::LdRaw{}, 0, cur);
-  for (u32 bg = 0; bg < nbatch; bg += UX) {
-    UnitRegs g = cur;
-    load_units(wave::LdMask{}, bg, g);  // (defaults of the lanes outside the range)
-    if (bg + UX < nbatch) load_units(wave::LdRaw{}, bg + UX, cur);
-    const u32* Pq = g.P;
-    const u32* Mq = g.M;
+    const u32 nbr_in = wave::shfl_up1(P[3]);
+    const u32 nbr0 = lane > 0 ? nbr_in : carry_pos;
+    carry_pos = wave::bcast(P[3], 63);
 #pragma unroll
-    for (u32 u = 0; u < UX; ++u) {
-      const u32 bi = bg + u;
-      const i32 kk = FWD ? static_cast<i32>(j_fwd0) - static_cast<i32>(bi * 64 + lane)
-                         : static_cast<i32>(j_rev0 + bi * 64 + lane);
-      const bool act = kk >= 0 && static_cast<u32>(kk) < n;
-      if (!wave::any(act)) break;
-      const u32 k = act ? static_cast<u32>(kk) : 0;
-      const u32 P = Pq[u];
-      const u32 M = Mq[u];
-      const bool bnd = act && P != UNBOUND;
-      const u32 nbr_in = wave::shfl_up1(P);
-      const bool first = (bi == 0 && lane == 0);
-      const u32 nbr = lane > 0 ? nbr_in : carry_pos;
+    for (u32 j = 0; j < 4; ++j) {
+      const u32 q = FWD ? 3 - j : j;
+      const u32 M = g.M.v[q];
+      const bool first = k[j] == (FWD ? j_fwd0 : j_rev0);
+      const u32 nbr = j == 0 ? nbr0 : P[j - 1];
       // see detect_lef_bar; 32-bit keys: positions lie below 2^32 - 2 (the host rejects longer
       // intervals), and a reach beyond that is as good as 2^32 - 2
-      u32 lo_key = 0, hi_key = 0;
-      if (bnd) {
+      lo_key[j] = 0;
+      hi_key[j] = 0;
+      if (bnd[j]) {
         if (!FWD) {
-          const u32 reach = P - M;
-          lo_key = first ? reach : umax(reach, nbr);
-          hi_key = P;
+          const u32 reach = P[j] - M;
+          lo_key[j] = first ? reach : umax(reach, nbr);
+          hi_key[j] = P[j];
         } else {
-          const u32 sum = P + M;
-          const u32 reach = (sum < P || sum > 0xFFFFFFFEu) ? 0xFFFFFFFEu : sum;
-          lo_key = P + 1;
-          hi_key = (first ? reach : umin(reach, nbr)) + 1;
+          const u32 sum = P[j] + M;
+          const u32 reach = (sum < P[j] || sum > 0xFFFFFFFEu) ? 0xFFFFFFFEu : sum;
+          lo_key[j] = P[j] + 1;
+          hi_key[j] = (first ? reach : umin(reach, nbr)) + 1;
         }
       }
-      const u64 bm = wave::ballot(bnd);
-      carry_pos = wave::bcast(P, 63);
-      if (bm == 0) continue;
-      const u32 l_first = static_cast<u32>(wave::ctz64(bm));
-      const u32 l_last = static_cast<u32>(63 - wave::clz64(bm));
-      // keys the batch spans (lanes hold ascending positions for rev, descending for fwd)
-      const u32 need_lo = wave::bcast(lo_key, FWD ? l_last : l_first);
-      const u32 need_hi = wave::bcast(hi_key, FWD ? l_first : l_last);
-      if (need_lo < lo_cover || need_hi > hi_cover) {
-        // Move the window along the list to where this batch starts (one coalesced load of
-        // positions and indices).  Entries the window has already passed are dropped by counting;
-        // when the batch lies beyond the whole window, the window keeps moving.
-        u32 moved = 0;
-        for (;;) {
-          if (staged) {
-            // window entries before the batch (rev: below need_lo; fwd: below need_hi)
-            const u32 key = FWD ? need_hi : need_lo;
-            u32 below = 0;
+    }
+    const u64 bm = wave::ballot(bnd[0] || bnd[1] || bnd[2] || bnd[3]);
+    if (bm == 0) continue;
+    const u32 l_first = static_cast<u32>(wave::ctz64(bm));
+    const u32 l_last = static_cast<u32>(63 - wave::clz64(bm));
+    // keys of the lane's first / last bound unit in sweep order
+    const u32 jf = bnd[0] ? 0u : bnd[1] ? 1u : bnd[2] ? 2u : 3u;
+    const u32 jl = bnd[3] ? 3u : bnd[2] ? 2u : bnd[1] ? 1u : 0u;
+    const u32 lo_f = jf == 0 ? lo_key[0] : jf == 1 ? lo_key[1] : jf == 2 ? lo_key[2] : lo_key[3];
+    const u32 hi_f = jf == 0 ? hi_key[0] : jf == 1 ? hi_key[1] : jf == 2 ? hi_key[2] : hi_key[3];
+    const u32 lo_l = jl == 3 ? lo_key[3] : jl == 2 ? lo_key[2] : jl == 1 ? lo_key[1] : lo_key[0];
+    const u32 hi_l = jl == 3 ? hi_key[3] : jl == 2 ? hi_key[2] : jl == 1 ? hi_key[1] : hi_key[0];
+    // keys the block spans (sweep order holds ascending positions for rev, descending for fwd)
+    const u32 need_lo = FWD ? wave::bcast(lo_l, l_last) : wave::bcast(lo_f, l_first);
+    const u32 need_hi = FWD ? wave::bcast(hi_f, l_first) : wave::bcast(hi_l, l_last);
+    if (need_lo < lo_cover || need_hi > hi_cover) {
+      // Move the window along the list to where this block starts (one coalesced load of
+      // positions and indices).  Entries the window has already passed are dropped by counting;
+      // when the block lies beyond the whole window, the window keeps moving.
+      u32 moved = 0;
+      for (;;) {
+        if (staged) {
+          // window entries before the block (rev: below need_lo; fwd: below need_hi)
+          const u32 key = FWD ? need_hi : need_lo;
+          u32 below = 0;
 #pragma unroll
-            for (u32 t = 0; t < BAR_WIN / 64; ++t) {
-              const u32 e = lane + 64 * t;
-              const u32 ce = cp[e];  // (e < BAR_WIN: inside the window whatever cnt is)
-              below += static_cast<u32>(wave::popc64(wave::ballot((e < cnt) & (ce < key))));
-            }
-            if (!FWD) {
-              g0 += below;
-            } else {
-              g1 = g0 + below;
-            }
-          } else {
-            if (FWD) g1 = nh; else g0 = 0;
+          for (u32 e0 = 0; e0 < BAR_WIN / 64; ++e0) {
+            const u32 e = lane + 64 * e0;
+            const u32 ce = cp[e];  // (e < BAR_WIN: inside the window whatever cnt is)
+            below += static_cast<u32>(wave::popc64(wave::ballot((e < cnt) & (ce < key))));
           }
           if (!FWD) {
-            g1 = umin(g0 + BAR_WIN, nh);
+            g0 += below;
           } else {
-            g0 = g1 > BAR_WIN ? g1 - BAR_WIN : 0;
-          }
-          cnt = g1 - g0;
-          wave::lockstep();
-          {
-            // what the window does not hold: everything before it lies below lo_cover,
-            // everything after it at or above hi_cover
-            const u32 edge_lo = g0 > 0 ? hpos[g0 - 1] : 0;
-            const u32 edge_hi = g1 < nh ? hpos[g1] : 0;
-            stage_stalling_window_call((MODLE_LDS u32*)cp, (MODLE_LDS u32*)ci, hpos + g0, hidx + g0, cnt);
-            lo_cover = g0 > 0 ? wave::uniform(edge_lo) + 1 : 0;
-            hi_cover = g1 < nh ? wave::uniform(edge_hi) : 0xFFFFFFFFu;
-          }
-          wave::sync_lds();
-          staged = true;
-          anchor = FWD ? cnt : 0;
-          // done unless the batch starts beyond this window and the list goes on
-          const bool beyond = FWD ? (need_hi <= lo_cover && g0 > 0) : (need_lo >= hi_cover && g1 < nh);
-          if (!beyond || ++moved > 64) break;  // (a batch that is still not covered is looked up in device memory)
-        }
-      }
-      u32 winner = 0xFFFFFFFFu, bpos = 0;
-      bool hard = false;
-      if (need_lo >= lo_cover && need_hi <= hi_cover) {
-        u32 q = anchor;
-        if (!FWD) {
-          // q = number of entries before the unit: the last of them is the candidate
-          if (bnd) {
-#pragma unroll
-            for (u32 sft = 64; sft >= 1; sft >>= 1) {
-              const u32 j = q + sft;
-              const bool in = j <= cnt;
-              const u32 kv = cp[c0 + (in ? j - 1 : 0)];  // (no branch around the read)
-              if (in & (kv < hi_key)) q = j;
-            }
-            if (q == anchor + HITBAR_NEAR && q < cnt) {
-              u32 hi = cnt;
-              while (q < hi) {
-                const u32 mid = (q + hi) >> 1;
-                if (cp[c0 + mid] < hi_key) q = mid + 1; else hi = mid;
-              }
-            }
-            if (q > 0) {
-              const u32 bp = cp[c0 + q - 1];
-              if (bp >= lo_key) {
-                const u32 w = ci[c0 + q - 1];
-                winner = w & ~HITBAR_HARD;
-                hard = (w & HITBAR_HARD) != 0;
-                bpos = bp;
-              }
-            }
+            g1 = g0 + below;
           }
         } else {
-          // q = number of entries at or before the unit: entry q is the candidate
-          if (bnd) {
+          if (FWD) g1 = nh; else g0 = 0;
+        }
+        if (!FWD) {
+          g1 = umin(g0 + BAR_WIN, nh);
+        } else {
+          g0 = g1 > BAR_WIN ? g1 - BAR_WIN : 0;
+        }
+        cnt = g1 - g0;
+        wave::lockstep();
+        {
+          // what the window does not hold: everything before it lies below lo_cover,
+          // everything after it at or above hi_cover
+          const u32 edge_lo = g0 > 0 ? hpos[g0 - 1] : 0;
+          const u32 edge_hi = g1 < nh ? hpos[g1] : 0;
+          stage_stalling_window_call((MODLE_LDS u32*)cp, (MODLE_LDS u32*)ci, hpos + g0, hidx + g0, cnt);
+          lo_cover = g0 > 0 ? wave::uniform(edge_lo) + 1 : 0;
+          hi_cover = g1 < nh ? wave::uniform(edge_hi) : 0xFFFFFFFFu;
+        }
+        wave::sync_lds();
+        staged = true;
+        anchor = FWD ? cnt : 0;
+        // done unless the block starts beyond this window and the list goes on
+        const bool beyond = FWD ? (need_hi <= lo_cover && g0 > 0) : (need_lo >= hi_cover && g1 < nh);
+        if (!beyond || ++moved > 64) break;  // (a block that is still not covered is looked up in device memory)
+      }
+    }
+    u32 winner[4], bpos[4];
+    bool hard[4];
 #pragma unroll
-            for (u32 sft = 64; sft >= 1; sft >>= 1) {
-              const bool in = q >= sft;
-              const u32 kv = cp[c0 + (in ? q - sft : 0)];  // (no branch around the read)
-              if (in & (kv >= lo_key)) q -= sft;
-            }
-            if (q + HITBAR_NEAR == anchor && q > 0) {
-              u32 lo = 0;
-              while (lo < q) {
-                const u32 mid = (lo + q) >> 1;
-                if (cp[c0 + mid] < lo_key) lo = mid + 1; else q = mid;
+    for (u32 j = 0; j < 4; ++j) {
+      winner[j] = 0xFFFFFFFFu;
+      bpos[j] = 0;
+      hard[j] = false;
+    }
+    if (need_lo >= lo_cover && need_hi <= hi_cover) {
+      // four searches side by side, all from the anchor the previous block left
+      u32 q[4];
+#pragma unroll
+      for (u32 j = 0; j < 4; ++j) q[j] = anchor;
+      if (!FWD) {
+        // q = number of entries before the unit: the last of them is the candidate
+#pragma unroll
+        for (u32 sft = 64; sft >= 1; sft >>= 1) {
+#pragma unroll
+          for (u32 j = 0; j < 4; ++j) {
+            const u32 jx = q[j] + sft;
+            const bool in = bnd[j] & (jx <= cnt);
+            const u32 kv = cp[c0 + (in ? jx - 1 : 0)];  // (no branch around the read)
+            if (in & (kv < hi_key[j])) q[j] = jx;
+          }
+        }
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          if (bnd[j]) {
+            if (q[j] == anchor + HITBAR_NEAR && q[j] < cnt) {
+              u32 hi = cnt;
+              u32 l = q[j];
+              while (l < hi) {
+                const u32 mid = (l + hi) >> 1;
+                if (cp[c0 + mid] < hi_key[j]) l = mid + 1; else hi = mid;
               }
+              q[j] = l;
             }
-            if (q < cnt) {
-              const u32 bp = cp[c0 + q];
-              if (bp < hi_key) {
-                const u32 w = ci[c0 + q];
-                winner = w & ~HITBAR_HARD;
-                hard = (w & HITBAR_HARD) != 0;
-                bpos = bp;
+            if (q[j] > 0) {
+              const u32 bp = cp[c0 + q[j] - 1];
+              if (bp >= lo_key[j]) {
+                const u32 wd = ci[c0 + q[j] - 1];
+                winner[j] = wd & ~HITBAR_HARD;
+                hard[j] = (wd & HITBAR_HARD) != 0;
+                bpos[j] = bp;
               }
             }
           }
         }
-        anchor = wave::bcast(q, l_last);
       } else {
-        // the batch spans more stalling barriers than the window holds (few, far apart units):
-        // per-unit searches in device memory
-        BarView v;
-        v.iv = &iv;
-        v.active = ws.bar_active;
-        v.st_pos = cp;
-        v.st_flag = ci;
-        v.s0 = FWD ? nb : 0;  // empty staged range at the end the search starts from
-        v.s1 = v.s0;
+        // q = number of entries at or before the unit: entry q is the candidate
+#pragma unroll
+        for (u32 sft = 64; sft >= 1; sft >>= 1) {
+#pragma unroll
+          for (u32 j = 0; j < 4; ++j) {
+            const bool in = bnd[j] & (q[j] >= sft);
+            const u32 kv = cp[c0 + (in ? q[j] - sft : 0)];  // (no branch around the read)
+            if (in & (kv >= lo_key[j])) q[j] -= sft;
+          }
+        }
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          if (bnd[j]) {
+            if (q[j] + HITBAR_NEAR == anchor && q[j] > 0) {
+              u32 lo = 0;
+              u32 h = q[j];
+              while (lo < h) {
+                const u32 mid = (lo + h) >> 1;
+                if (cp[c0 + mid] < lo_key[j]) lo = mid + 1; else h = mid;
+              }
+              q[j] = h;
+            }
+            if (q[j] < cnt) {
+              const u32 bp = cp[c0 + q[j]];
+              if (bp < hi_key[j]) {
+                const u32 wd = ci[c0 + q[j]];
+                winner[j] = wd & ~HITBAR_HARD;
+                hard[j] = (wd & HITBAR_HARD) != 0;
+                bpos[j] = bp;
+              }
+            }
+          }
+        }
+      }
+      const u32 q_last = jl == 3 ? q[3] : jl == 2 ? q[2] : jl == 1 ? q[1] : q[0];
+      anchor = wave::bcast(q_last, l_last);
+    } else {
+      // the block spans more stalling barriers than the window holds (few, far apart units):
+      // per-unit searches in device memory
+      BarView v;
+      v.iv = &iv;
+      v.active = ws.bar_active;
+      v.st_pos = cp;
+      v.st_flag = ci;
+      v.s0 = FWD ? nb : 0;  // empty staged range at the end the search starts from
+      v.s1 = v.s0;
+#pragma unroll
+      for (u32 j = 0; j < 4; ++j) {
         u32 b_lo = 0, b_hi = 0;
         bool edge = false;
-        if (bnd) lef_bar_window<FWD, false>(v, nb, 0, lo_key, hi_key, b_lo, b_hi, edge);
-        winner = lef_bar_pick<FWD, false>(v, p, c.g, b_lo, b_hi, 0, hard, bpos);
-        // the staged entries stay valid, but the next batch must not trust the anchor
-        lo_cover = 1;
-        hi_cover = 0;
+        if (bnd[j]) lef_bar_window<FWD, false>(v, nb, 0, lo_key[j], hi_key[j], b_lo, b_hi, edge);
+        winner[j] = lef_bar_pick<FWD, false>(v, p, c.g, b_lo, b_hi, 0, hard[j], bpos[j]);
       }
-      if (winner != 0xFFFFFFFFu) {
-        coll[k] = cw_make(winner, EV_COLLISION | EV_LEF_BAR) | (hard ? CW_HARD : 0u);
-        barpos[k] = bpos;
+      // the staged entries stay valid, but the next block must not trust the anchor
+      lo_cover = 1;
+      hi_cover = 0;
+    }
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j) {
+      if (winner[j] != 0xFFFFFFFFu) {
+        coll[k[j]] = cw_make(winner[j], EV_COLLISION | EV_LEF_BAR) | (hard[j] ? CW_HARD : 0u);
+        barpos[k[j]] = bpos[j];
       }
     }
   }
