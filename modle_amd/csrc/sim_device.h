@@ -554,7 +554,7 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
   for (u32 k = n_new + lane; k < m2; k += 64) keys[k] = ~u64(0);
   for (u32 j = lane; j < n_new; j += 64) cnt_lds[j] = n_old;
   wave::sync_lds();
-  PHASE(c, 14, if (m2 > 1) bitonic_sort_u64<true>(keys, m2));
+  if (m2 > 1) bitonic_sort_u64<true>(keys, m2);
 
   bool ties = false;
   u32 t_lo = 0xFFFFFFFFu, t_hi = 0;  // output slots of the units flagged for equal positions
@@ -678,9 +678,6 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
   }
   if (seen_new != n_new) return false;  // (the marks and the list disagree: cannot happen)
   wave::sync_lds();
-#ifdef MODLE_PHASE_TIMERS
-  const u64 t15_ = wave::clock();
-#endif
   for (u32 base = 0; base < n_new; base += 64) {
     const u32 bq = base + lane;
     bool tie = false;
@@ -703,9 +700,6 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
   }
   wave::sync_mem();
   rank_finish<FWD>(c, ties, FWD ? ws.f_rank : ws.r_rank, t_lo, t_hi);
-#ifdef MODLE_PHASE_TIMERS
-  c.ph[15] += wave::clock() - t15_;
-#endif
   return true;
 }
 
