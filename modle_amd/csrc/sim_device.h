@@ -615,13 +615,22 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
     }
 #pragma unroll
     for (u32 sft = 8; sft >= 1; sft >>= 1) {
+      // (the four reads of a round are issued together: left alone the compiler waits for each)
+      u32 jx[4];
+      bool in[4];
+      u64 kv[4];
 #pragma unroll
       for (u32 j = 0; j < 4; ++j) {
-        const u32 jx = lo[j] + sft;
-        const bool in = carried[j] & (jx <= n_new);
-        const u64 kv = keys[in ? jx - 1 : 0];  // (no branch around the read)
-        if (in & (kv < thr[j])) lo[j] = jx;
+        jx[j] = lo[j] + sft;
+        in[j] = carried[j] & (jx[j] <= n_new);
+        kv[j] = keys[in[j] ? jx[j] - 1 : 0];  // (no branch around the read)
       }
+      wave::sched_fence();
+#pragma unroll
+      for (u32 j = 0; j < 4; ++j) {
+        if (in[j] & (kv[j] < thr[j])) lo[j] = jx[j];
+      }
+      wave::sched_fence();
     }
     u32 lmx[4];
 #pragma unroll
@@ -1970,18 +1979,29 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
         // q = number of entries before the unit: the last of them is the candidate
 #pragma unroll
         for (u32 sft = 64; sft >= 1; sft >>= 1) {
+          // (the four reads of a round are issued together: left alone the compiler waits for each)
+          u32 jx[4], kv[4];
+          bool in[4];
 #pragma unroll
           for (u32 j = 0; j < 4; ++j) {
-            const u32 jx = q[j] + sft;
-            const bool in = bnd[j] & (jx <= cnt);
-            const u32 kv = cp[c0 + (in ? jx - 1 : 0)];  // (no branch around the read)
-            if (in & (kv < hi_key[j])) q[j] = jx;
+            jx[j] = q[j] + sft;
+            in[j] = bnd[j] & (jx[j] <= cnt);
+            kv[j] = cp[c0 + (in[j] ? jx[j] - 1 : 0)];  // (no branch around the read)
           }
-        }
+          wave::sched_fence();
 #pragma unroll
-        for (u32 j = 0; j < 4; ++j) {
-          if (bnd[j]) {
-            if (q[j] == anchor + HITBAR_NEAR && q[j] < cnt) {
+          for (u32 j = 0; j < 4; ++j) {
+            if (in[j] & (kv[j] < hi_key[j])) q[j] = jx[j];
+          }
+          wave::sched_fence();
+        }
+        bool far = false;  // the fixed steps ran out: finish with a binary search (rare)
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) far = far || (bnd[j] && q[j] == anchor + HITBAR_NEAR && q[j] < cnt);
+        if (wave::any(far)) {
+#pragma unroll
+          for (u32 j = 0; j < 4; ++j) {
+            if (bnd[j] && q[j] == anchor + HITBAR_NEAR && q[j] < cnt) {
               u32 hi = cnt;
               u32 l = q[j];
               while (l < hi) {
@@ -1990,32 +2010,50 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
               }
               q[j] = l;
             }
-            if (q[j] > 0) {
-              const u32 bp = cp[c0 + q[j] - 1];
-              if (bp >= lo_key[j]) {
-                const u32 wd = ci[c0 + q[j] - 1];
-                winner[j] = wd & ~HITBAR_HARD;
-                hard[j] = (wd & HITBAR_HARD) != 0;
-                bpos[j] = bp;
-              }
-            }
+          }
+        }
+        // the candidates of the four units: position and index read together, then tested
+        u32 bp[4], wd[4];
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          const u32 e = c0 + (q[j] > 0 ? q[j] - 1 : 0);
+          bp[j] = cp[e];
+          wd[j] = ci[e];
+        }
+        wave::sched_fence();
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          if (bnd[j] & (q[j] > 0) & (bp[j] >= lo_key[j])) {
+            winner[j] = wd[j] & ~HITBAR_HARD;
+            hard[j] = (wd[j] & HITBAR_HARD) != 0;
+            bpos[j] = bp[j];
           }
         }
       } else {
         // q = number of entries at or before the unit: entry q is the candidate
 #pragma unroll
         for (u32 sft = 64; sft >= 1; sft >>= 1) {
+          u32 kv[4];
+          bool in[4];
 #pragma unroll
           for (u32 j = 0; j < 4; ++j) {
-            const bool in = bnd[j] & (q[j] >= sft);
-            const u32 kv = cp[c0 + (in ? q[j] - sft : 0)];  // (no branch around the read)
-            if (in & (kv >= lo_key[j])) q[j] -= sft;
+            in[j] = bnd[j] & (q[j] >= sft);
+            kv[j] = cp[c0 + (in[j] ? q[j] - sft : 0)];  // (no branch around the read)
           }
-        }
+          wave::sched_fence();
 #pragma unroll
-        for (u32 j = 0; j < 4; ++j) {
-          if (bnd[j]) {
-            if (q[j] + HITBAR_NEAR == anchor && q[j] > 0) {
+          for (u32 j = 0; j < 4; ++j) {
+            if (in[j] & (kv[j] >= lo_key[j])) q[j] -= sft;
+          }
+          wave::sched_fence();
+        }
+        bool far = false;  // the fixed steps ran out: finish with a binary search (rare)
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) far = far || (bnd[j] && q[j] + HITBAR_NEAR == anchor && q[j] > 0);
+        if (wave::any(far)) {
+#pragma unroll
+          for (u32 j = 0; j < 4; ++j) {
+            if (bnd[j] && q[j] + HITBAR_NEAR == anchor && q[j] > 0) {
               u32 lo = 0;
               u32 h = q[j];
               while (lo < h) {
@@ -2024,15 +2062,23 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
               }
               q[j] = h;
             }
-            if (q[j] < cnt) {
-              const u32 bp = cp[c0 + q[j]];
-              if (bp < hi_key[j]) {
-                const u32 wd = ci[c0 + q[j]];
-                winner[j] = wd & ~HITBAR_HARD;
-                hard[j] = (wd & HITBAR_HARD) != 0;
-                bpos[j] = bp;
-              }
-            }
+          }
+        }
+        // the candidates of the four units: position and index read together, then tested
+        u32 bp[4], wd[4];
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          const u32 e = c0 + (q[j] < cnt ? q[j] : 0);
+          bp[j] = cp[e];
+          wd[j] = ci[e];
+        }
+        wave::sched_fence();
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          if (bnd[j] & (q[j] < cnt) & (bp[j] < hi_key[j])) {
+            winner[j] = wd[j] & ~HITBAR_HARD;
+            hard[j] = (wd[j] & HITBAR_HARD) != 0;
+            bpos[j] = bp[j];
           }
         }
       }
@@ -2059,11 +2105,13 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
       lo_cover = 1;
       hi_cover = 0;
     }
+    if (wave::any((winner[0] & winner[1] & winner[2] & winner[3]) != 0xFFFFFFFFu)) {
 #pragma unroll
-    for (u32 j = 0; j < 4; ++j) {
-      if (winner[j] != 0xFFFFFFFFu) {
-        coll[k[j]] = cw_make(winner[j], EV_COLLISION | EV_LEF_BAR) | (hard[j] ? CW_HARD : 0u);
-        barpos[k[j]] = bpos[j];
+      for (u32 j = 0; j < 4; ++j) {
+        if (winner[j] != 0xFFFFFFFFu) {
+          coll[k[j]] = cw_make(winner[j], EV_COLLISION | EV_LEF_BAR) | (hard[j] ? CW_HARD : 0u);
+          barpos[k[j]] = bpos[j];
+        }
       }
     }
   }
