@@ -2378,25 +2378,30 @@ MODLE_DEV u32 stalling_barrier_pos(const Interval& iv, u32 word) {
 // slice of STAGE_CAP fwd units
 // (positions for the whole slice: every lane searches them; moves, collision words and ids for
 // its first PRIMARY_NEAR units only: a rev unit's partner is almost always among them)
-constexpr u32 PRIMARY_NEAR = 128;
+constexpr u32 PRIMARY_NEAR = 256;
+// one block of detect_primary: TWO consecutive rev ranks per lane (128 ranks, 64-bit loads) and
+// the slices of the fwd-side arrays
 struct PrimaryBatch {
-  u32 R, rev_move, rev_id, rc, rbp;
+  wave::U32x2 R, rev_move, rev_id, rc, rbp;
   u32 sp[STAGE_CAP / 64];
   u32 sm[PRIMARY_NEAR / 64], sc[PRIMARY_NEAR / 64], si[PRIMARY_NEAR / 64], sb[PRIMARY_NEAR / 64];
 };
+// `base` is even; ranks outside [first, n) are masked where the values are used
 template <class Op>
 MODLE_DEV void primary_load_batch(Op op, const Workspace& ws, u32 n, u32 base, u32 w0, u32 lane,
-                                  PrimaryBatch& b) {
-  const u32 k = base + lane;
-  const bool act = k < n;
-  b.R = op(ws.r_pos, k, act, UNBOUND, b.R);
-  b.rev_move = op(ws.r_move, k, act, 0, b.rev_move);
-  b.rev_id = op(ws.r_id, k, act, 0, b.rev_id);
-  b.rc = op(ws.r_coll, k, act, 0, b.rc);
-  // position of the barrier that stalls the unit (meaningful where the word says LEF-BAR):
-  // having it here keeps a dependent load, and with it a wait for everything in flight, out of
-  // the batch's work
-  b.rbp = op(stalling_barrier_positions<false>(ws), k, act, 0, b.rbp);
+                                  PrimaryBatch& b, bool rev_side) {
+  if (rev_side) {
+    const u32 k0 = base + 2 * lane;
+    const u32 kq = k0 < n ? k0 : 0u;
+    b.R = wave::ld2(ws.r_pos, kq);
+    b.rev_move = wave::ld2(ws.r_move, kq);
+    b.rev_id = wave::ld2(ws.r_id, kq);
+    b.rc = wave::ld2(ws.r_coll, kq);
+    // position of the barrier that stalls the unit (meaningful where the word says LEF-BAR):
+    // having it here keeps a dependent load, and with it a wait for everything in flight, out of
+    // the block's work
+    b.rbp = wave::ld2(stalling_barrier_positions<false>(ws), kq);
+  }
 #pragma unroll
   for (u32 q = 0; q < STAGE_CAP / 64; ++q) {
     const u32 t = lane + 64 * q;
@@ -2429,7 +2434,7 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
   const bool trials = p.p_bypass != 0.0 && !never_collide;
   const u32 prim = EV_COLLISION | EV_LEF_LEF_PRIMARY;
   // LDS slices of the fwd-side arrays, ranks [w0, w0 + STAGE_CAP): positions in the staging
-  // buffer, moves / collision words / ids in the (idle) sort buffer
+  // buffer, moves / collision words / ids / barrier positions in the (idle) sort buffer
   u32* stage = c.lds.stage;
   u32* st_move = reinterpret_cast<u32*>(c.lds.sort_lds);
   u32* st_coll = st_move + PRIMARY_NEAR;
@@ -2439,26 +2444,32 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
   u32 carry_pos = 0;
   u32 carry_pf = 0;  // fwd units strictly upstream of the last rev unit handled so far
   // pf = number of fwd units strictly upstream of R.  pf is monotone in the rank, so slices of
-  // the fwd arrays starting at the previous batch's value are staged in LDS (one round trip
-  // together with the batch's rev-side loads) and everything is looked up there; lanes whose
-  // partner lies beyond the slice use device memory.  The loads of the next batch are issued as
-  // soon as this batch knows where its last unit falls among the fwd units, before the rest of
-  // its work.  What they can miss are this batch's updates of the fwd unit at the start of the
-  // next slice (its move and collision word), and no unit of the next batch can pair with that
-  // unit: it lies upstream of this batch's last rev unit, which is then the "first rev unit
+  // the fwd arrays starting at the previous block's value are staged in LDS (one round trip
+  // together with the block's rev-side loads) and everything is looked up there; units whose
+  // partner lies beyond the slice use device memory.  The loads of the next block are issued as
+  // soon as this block knows where its last unit falls among the fwd units, before the rest of
+  // its work.  What they can miss are this block's updates of the fwd unit at the start of the
+  // next slice (its move and collision word), and no unit of the next block can pair with that
+  // unit: it lies upstream of this block's last rev unit, which is then the "first rev unit
   // downstream of it".
+  const u32 first = bc.n5;
   PrimaryBatch cur;
-  primary_load_batch(wave::LdRaw{}, ws, n, bc.n5, 0, lane, cur);
-  for (u32 base = bc.n5; base < n; base += 64) {
-    const u32 k = base + lane;
-    const bool act = k < n;
+  primary_load_batch(wave::LdRaw{}, ws, n, first & ~1u, 0, lane, cur, true);
+  for (u32 base = first & ~1u; base < n; base += 128) {
     const u32 w0 = carry_pf > 0 ? carry_pf - 1 : 0;
-    primary_load_batch(wave::LdMask{}, ws, n, base, w0, lane, cur);  // (defaults outside the range)
-    const u32 R = cur.R;
-    const u32 rev_move_k = cur.rev_move;
-    const u32 rev_id_k = cur.rev_id;
-    const u32 rc_k = cur.rc;
-    const u32 rbp_k = cur.rbp;
+    primary_load_batch(wave::LdMask{}, ws, n, base, w0, lane, cur, false);  // (defaults outside the range)
+    u32 k[2], R[2], rev_move_k[2], rev_id_k[2], rc_k[2], rbp_k[2];
+    bool act[2];
+#pragma unroll
+    for (u32 j = 0; j < 2; ++j) {
+      k[j] = base + 2 * lane + j;
+      act[j] = k[j] >= first && k[j] < n;
+      R[j] = act[j] ? cur.R.v[j] : UNBOUND;
+      rev_move_k[j] = act[j] ? cur.rev_move.v[j] : 0u;
+      rev_id_k[j] = act[j] ? cur.rev_id.v[j] : 0u;
+      rc_k[j] = act[j] ? cur.rc.v[j] : 0u;
+      rbp_k[j] = act[j] ? cur.rbp.v[j] : 0u;
+    }
     wave::lockstep();
 #pragma unroll
     for (u32 q = 0; q < STAGE_CAP / 64; ++q) stage[lane + 64 * q] = cur.sp[q];
@@ -2471,97 +2482,125 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
       st_bp[t] = cur.sb[q];
     }
     wave::sync_lds();
-    const u32 prev_in = wave::shfl_up1(R);
-    const u32 Rprev = lane > 0 ? prev_in : carry_pos;
-    u32 pf = 0;
-    if (act) {
-      // number of staged positions below R: a fixed-step search (no loop control, the eight
-      // steps are the same for every lane)
-      u32 lo = 0;
-      static_assert(STAGE_CAP == 256, "the search below covers 256 entries");
+    const u32 prev_in = wave::shfl_up1(R[1]);
+    const u32 Rprev0 = lane > 0 ? prev_in : carry_pos;
+    // number of staged positions below R: a fixed-step search (no loop control, the eight steps
+    // are the same for every unit; the two reads of a round are issued together)
+    u32 lo[2] = {0, 0};
+    static_assert(STAGE_CAP == 256, "the search below covers 256 entries");
 #pragma unroll
-      for (u32 sft = 128; sft >= 1; sft >>= 1) {
-        if (stage[lo + sft - 1] < R) lo += sft;
+    for (u32 sft = 128; sft >= 1; sft >>= 1) {
+      u32 sv[2];
+#pragma unroll
+      for (u32 j = 0; j < 2; ++j) sv[j] = stage[lo[j] + sft - 1];
+      wave::sched_fence();
+#pragma unroll
+      for (u32 j = 0; j < 2; ++j) {
+        if (sv[j] < R[j]) lo[j] += sft;
       }
-      if (lo == STAGE_CAP - 1 && stage[STAGE_CAP - 1] < R) lo = STAGE_CAP;
-      if (lo == STAGE_CAP && w0 + STAGE_CAP < n) {
-        pf = lower_bound_u32(ws.f_pos, n, R);
-      } else {
-        pf = umin(w0 + lo, n);
+      wave::sched_fence();
+    }
+    const u32 st_last = stage[STAGE_CAP - 1];
+    u32 pf[2] = {0, 0};
+#pragma unroll
+    for (u32 j = 0; j < 2; ++j) {
+      if (act[j]) {
+        u32 l = lo[j];
+        if (l == STAGE_CAP - 1 && st_last < R[j]) l = STAGE_CAP;
+        if (l == STAGE_CAP && w0 + STAGE_CAP < n) {
+          pf[j] = lower_bound_u32(ws.f_pos, n, R[j]);
+        } else {
+          pf[j] = umin(w0 + l, n);
+        }
       }
     }
-    // last active lane's pf (inactive lanes hold 0)
-    const u64 am = wave::ballot(act);
-    const u32 next_pf = wave::bcast(pf, static_cast<u32>(63 - wave::clz64(am)));
-    if (base + 64 < n) primary_load_batch(wave::LdRaw{}, ws, n, base + 64, next_pf > 0 ? next_pf - 1 : 0, lane, cur);
-    bool cand = false;
-    u32 F = 0, rev_move = 0, fwd_move = 0, fwd_id_s = 0, fc_s = 0, fbp_s = 0;
-    if (act && pf >= 1 && pf < i2) {
-      const u32 kf = pf - 1;
-      const bool staged = kf >= w0 && kf - w0 < STAGE_CAP;
-      const bool near = kf >= w0 && kf - w0 < PRIMARY_NEAR;
-      F = staged ? stage[kf - w0] : ws.f_pos[kf];
-      const bool first_after = (k == bc.n5) || Rprev <= F;
-      if (first_after) {
-        rev_move = rev_move_k;
-        fwd_move = near ? st_move[kf - w0] : ws.f_move[kf];
-        fwd_id_s = near ? st_id[kf - w0] : ws.f_id[kf];
-        fc_s = near ? st_coll[kf - w0] : ws.f_coll[kf];
-        fbp_s = near ? st_bp[kf - w0] : stalling_barrier_positions<true>(ws)[kf];
-        const u32 delta = R - F;  // > 0 by construction
-        cand = static_cast<u64>(delta) < static_cast<u64>(rev_move) + fwd_move;
+    // pf of the last active unit
+    const u64 am = wave::ballot(act[0] || act[1]);
+    const u32 next_pf = wave::bcast(act[1] ? pf[1] : pf[0], static_cast<u32>(63 - wave::clz64(am)));
+    if (base + 128 < n) {
+      primary_load_batch(wave::LdRaw{}, ws, n, base + 128, next_pf > 0 ? next_pf - 1 : 0, lane, cur, true);
+    }
+    bool cand[2] = {false, false};
+    u32 F[2] = {0, 0}, rev_move[2] = {0, 0}, fwd_move[2] = {0, 0}, fwd_id_s[2] = {0, 0}, fc_s[2] = {0, 0},
+        fbp_s[2] = {0, 0};
+#pragma unroll
+    for (u32 j = 0; j < 2; ++j) {
+      if (act[j] && pf[j] >= 1 && pf[j] < i2) {
+        const u32 kf = pf[j] - 1;
+        const bool staged = kf >= w0 && kf - w0 < STAGE_CAP;
+        const bool near = kf >= w0 && kf - w0 < PRIMARY_NEAR;
+        F[j] = staged ? stage[kf - w0] : ws.f_pos[kf];
+        const u32 Rprev = j == 0 ? Rprev0 : R[0];
+        const bool first_after = (k[j] == first) || Rprev <= F[j];
+        if (first_after) {
+          rev_move[j] = rev_move_k[j];
+          fwd_move[j] = near ? st_move[kf - w0] : ws.f_move[kf];
+          fwd_id_s[j] = near ? st_id[kf - w0] : ws.f_id[kf];
+          fc_s[j] = near ? st_coll[kf - w0] : ws.f_coll[kf];
+          fbp_s[j] = near ? st_bp[kf - w0] : stalling_barrier_positions<true>(ws)[kf];
+          const u32 delta = R[j] - F[j];  // > 0 by construction
+          cand[j] = static_cast<u64>(delta) < static_cast<u64>(rev_move[j]) + fwd_move[j];
+        }
       }
     }
-    const u64 cm = wave::ballot(cand);
-    bool hit = cand && !never_collide;
-    if (trials && cm != 0) {
-      const u32 cnt = static_cast<u32>(wave::popc64(cm));
+    const u64 cm0 = wave::ballot(cand[0]), cm1 = wave::ballot(cand[1]);
+    bool hit[2] = {cand[0] && !never_collide, cand[1] && !never_collide};
+    if (trials && (cm0 | cm1) != 0) {
+      const u32 cnt = static_cast<u32>(wave::popc64(cm0) + wave::popc64(cm1));
       rng_ensure(c.g, cnt);
-      const u32 t = static_cast<u32>(wave::popc64(cm & lanemask_lt(lane)));
-      hit = cand && bernoulli_raw(rng_peek(c.g, c.g.pos + t), p_collide);
+      // draws in rank order: unit (lane, j) after the units of the lanes before it and after unit 0
+      // of its own lane
+      const u64 lt = lanemask_lt(lane);
+      const u32 t0 = static_cast<u32>(wave::popc64(cm0 & lt) + wave::popc64(cm1 & lt));
+      const u32 t1 = t0 + (cand[0] ? 1u : 0u);
+      hit[0] = cand[0] && bernoulli_raw(rng_peek(c.g, c.g.pos + t0), p_collide);
+      hit[1] = cand[1] && bernoulli_raw(rng_peek(c.g, c.g.pos + t1), p_collide);
       rng_advance(c.g, cnt);
     }
-    if (hit) {
-      const u32 kf = pf - 1;
-      const u32 rev_id = rev_id_k, fwd_id = fwd_id_s;
-      u32 cpos_rev, cpos_fwd;
-      lef_lef_collision_pos(R, F, rev_move, fwd_move, cpos_rev, cpos_fwd);
-      const u32 rc = rc_k, fc = fc_s;
-      const bool rev_occ = cw_occurred(rc), fwd_occ = cw_occurred(fc);
-      bool both = false;
-      if (!rev_occ && !fwd_occ) {
-        ws.r_coll[k] = cw_make(fwd_id, prim);
-        ws.f_coll[kf] = cw_make(rev_id, prim);
-        both = true;
-      } else if (rev_occ && !fwd_occ) {
-        const u32 barrier_pos = cw_occurred_as(rc, EV_LEF_BAR) ? rbp_k : stalling_barrier_pos(iv, rc);
-        ws.f_coll[kf] = cw_make(rev_id, prim);
-        if (cpos_fwd > barrier_pos) {
-          // the LEF-LEF collision happens before the predicted LEF-BAR one
-          ws.r_coll[k] = cw_make(fwd_id, prim);
-          both = true;
-        } else if (fuse_correct && cw_occurred_as(rc, EV_LEF_BAR)) {
-          // fwd unit runs into a rev unit that stays stalled 1 bp downstream of its barrier
-          const u32 rev_move_stalled = (R - barrier_pos) - 1;
-          ws.f_move[kf] = (R - rev_move_stalled) - F - 1;
-        }
-      } else if (!rev_occ && fwd_occ) {
-        const u32 barrier_pos = cw_occurred_as(fc, EV_LEF_BAR) ? fbp_s : stalling_barrier_pos(iv, fc);
-        ws.r_coll[k] = cw_make(fwd_id, prim);
-        if (cpos_rev < barrier_pos) {
+#pragma unroll
+    for (u32 j = 0; j < 2; ++j) {
+      if (hit[j]) {
+        const u32 kf = pf[j] - 1;
+        const u32 rev_id = rev_id_k[j], fwd_id = fwd_id_s[j];
+        u32 cpos_rev, cpos_fwd;
+        lef_lef_collision_pos(R[j], F[j], rev_move[j], fwd_move[j], cpos_rev, cpos_fwd);
+        const u32 rc = rc_k[j], fc = fc_s[j];
+        const bool rev_occ = cw_occurred(rc), fwd_occ = cw_occurred(fc);
+        bool both = false;
+        if (!rev_occ && !fwd_occ) {
+          ws.r_coll[k[j]] = cw_make(fwd_id, prim);
           ws.f_coll[kf] = cw_make(rev_id, prim);
           both = true;
-        } else if (fuse_correct && cw_occurred_as(fc, EV_LEF_BAR)) {
-          const u32 fwd_move_stalled = (barrier_pos - F) - 1;
-          ws.r_move[k] = R - (F + fwd_move_stalled) - 1;
+        } else if (rev_occ && !fwd_occ) {
+          const u32 barrier_pos = cw_occurred_as(rc, EV_LEF_BAR) ? rbp_k[j] : stalling_barrier_pos(iv, rc);
+          ws.f_coll[kf] = cw_make(rev_id, prim);
+          if (cpos_fwd > barrier_pos) {
+            // the LEF-LEF collision happens before the predicted LEF-BAR one
+            ws.r_coll[k[j]] = cw_make(fwd_id, prim);
+            both = true;
+          } else if (fuse_correct && cw_occurred_as(rc, EV_LEF_BAR)) {
+            // fwd unit runs into a rev unit that stays stalled 1 bp downstream of its barrier
+            const u32 rev_move_stalled = (R[j] - barrier_pos) - 1;
+            ws.f_move[kf] = (R[j] - rev_move_stalled) - F[j] - 1;
+          }
+        } else if (!rev_occ && fwd_occ) {
+          const u32 barrier_pos = cw_occurred_as(fc, EV_LEF_BAR) ? fbp_s[j] : stalling_barrier_pos(iv, fc);
+          ws.r_coll[k[j]] = cw_make(fwd_id, prim);
+          if (cpos_rev < barrier_pos) {
+            ws.f_coll[kf] = cw_make(rev_id, prim);
+            both = true;
+          } else if (fuse_correct && cw_occurred_as(fc, EV_LEF_BAR)) {
+            const u32 fwd_move_stalled = (barrier_pos - F[j]) - 1;
+            ws.r_move[k[j]] = R[j] - (F[j] + fwd_move_stalled) - 1;
+          }
+        }
+        if (both && fuse_correct) {
+          ws.r_move[k[j]] = R[j] - cpos_rev;
+          ws.f_move[kf] = cpos_fwd - F[j];
         }
       }
-      if (both && fuse_correct) {
-        ws.r_move[k] = R - cpos_rev;
-        ws.f_move[kf] = cpos_fwd - F;
-      }
     }
-    carry_pos = wave::bcast(R, 63);
+    carry_pos = wave::bcast(R[1], 63);
     carry_pf = next_pf;
   }
   wave::sync_mem();

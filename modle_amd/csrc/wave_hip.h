@@ -201,6 +201,11 @@ MODLE_DEV T known_uniform(T v) { return uniform(v); }
 // an `ok ? p[k] : dflt` as s_and_saveexec / s_cbranch_execz around every single load.
 // four consecutive words as one 128-bit access: p + k must be 16-byte aligned (k a multiple of 4
 // in an array that starts on a 16-byte boundary)
+// two consecutive words as one 64-bit access (p + k 8-byte aligned)
+struct alignas(8) U32x2 {
+  uint32_t v[2];
+};
+MODLE_DEV U32x2 ld2(const uint32_t* p, uint32_t k) { return *reinterpret_cast<const U32x2*>(p + k); }
 struct alignas(16) U32x4 {
   uint32_t v[4];
 };

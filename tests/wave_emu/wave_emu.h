@@ -202,6 +202,15 @@ template <class T>
 MODLE_DEV T known_uniform(T v) { return v; }
 // four consecutive words as one 128-bit access: p + k must be 16-byte aligned (k a multiple of 4
 // in an array that starts on a 16-byte boundary)
+struct U32x2 {
+  uint32_t v[2];
+};
+MODLE_DEV U32x2 ld2(const uint32_t* p, uint32_t k) {
+  U32x2 x;
+  x.v[0] = p[k];
+  x.v[1] = p[k + 1];
+  return x;
+}
 struct U32x4 {
   uint32_t v[4];
 };
