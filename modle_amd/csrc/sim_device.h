@@ -632,18 +632,26 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
       }
       wave::sched_fence();
     }
+    bool far = false;  // the fixed steps ran out: finish with a binary search (rare)
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j) far = far || (carried[j] && lo[j] == carry_lo + 15 && lo[j] < n_new);
+    if (wave::any(far)) {
+#pragma unroll
+      for (u32 j = 0; j < 4; ++j) {
+        if (carried[j] && lo[j] == carry_lo + 15 && lo[j] < n_new) {
+          u32 hi = n_new;
+          u32 l = lo[j];
+          while (l < hi) {
+            const u32 mid = (l + hi) >> 1;
+            if (keys[mid] < thr[j]) l = mid + 1; else hi = mid;
+          }
+          lo[j] = l;
+        }
+      }
+    }
     u32 lmx[4];
 #pragma unroll
     for (u32 j = 0; j < 4; ++j) {
-      if (carried[j] && lo[j] == carry_lo + 15 && lo[j] < n_new) {
-        u32 hi = n_new;
-        u32 l = lo[j];
-        while (l < hi) {
-          const u32 mid = (l + hi) >> 1;
-          if (keys[mid] < thr[j]) l = mid + 1; else hi = mid;
-        }
-        lo[j] = l;
-      }
       const u32 cl = carried[j] ? lo[j] : 0u;
       lmx[j] = j == 0 ? cl : umax(lmx[j - 1], cl);  // keys before the carried-over units so far
     }
@@ -653,30 +661,44 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
     carry_lo = umax(carry_lo, wave::bcast(lpm, 63));
     bool tie = false;
     u32 tie_lo = 0xFFFFFFFFu, tie_hi = 0;
+    u32 slot[4], lo_prev[4];
+    // the key next to each unit (fwd: the last key before it, rev: the first key after it), read
+    // together: equal positions are flagged for the final ordering
+    u64 nk[4];
+    bool nk_in[4];
+    bool gaps = false;  // keys lie between a unit and the carried-over unit before it
 #pragma unroll
     for (u32 j = 0; j < 4; ++j) {
-      if (carried[j]) {
-        const u32 a = w + j - (lane_before + nb[j]);
-        // keys [lo of the carried-over unit before, lo) lie between that unit and this one
-        const u32 lo_prev = j == 0 ? lane_lo : umax(lane_lo, lmx[j - 1]);
-        for (u32 q = lo_prev; q < lo[j]; ++q) cnt_lds[q] = a;
-        if (pp[j] != UNBOUND) {
-          bool tj;
-          if (FWD) {
-            tj = lo[j] > 0 && static_cast<u32>(keys[lo[j] - 1] >> 32) == pp[j];
-          } else {
-            tj = lo[j] < n_new && static_cast<u32>(keys[lo[j]] >> 32) == pp[j];
-          }
-          tj = tj || (a > 0 && excl[j] == pp[j]);
-          if (tj) {
-            tie = true;
-            tie_lo = umin(tie_lo, a + lo[j]);
-            tie_hi = umax(tie_hi, a + lo[j]);
-          }
+      slot[j] = w + j - (lane_before + nb[j]) + lo[j];
+      lo_prev[j] = j == 0 ? lane_lo : umax(lane_lo, lmx[j - 1]);
+      gaps = gaps || (carried[j] && lo_prev[j] < lo[j]);
+      nk_in[j] = carried[j] & (FWD ? lo[j] > 0 : lo[j] < n_new);
+      nk[j] = keys[nk_in[j] ? (FWD ? lo[j] - 1 : lo[j]) : 0];
+    }
+    wave::sched_fence();
+    if (wave::any(gaps)) {
+#pragma unroll
+      for (u32 j = 0; j < 4; ++j) {
+        if (carried[j]) {
+          // keys [lo of the carried-over unit before, lo) lie between that unit and this one
+          for (u32 q = lo_prev[j]; q < lo[j]; ++q) cnt_lds[q] = slot[j] - lo[j];
         }
-        out_pos[a + lo[j]] = pp[j];
-        out_id[a + lo[j]] = oid[j];
-        where_new[oid[j]] = a + lo[j];
+      }
+    }
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j) {
+      const u32 a = slot[j] - lo[j];
+      const bool tj = carried[j] && pp[j] != UNBOUND &&
+                      ((nk_in[j] && static_cast<u32>(nk[j] >> 32) == pp[j]) || (a > 0 && excl[j] == pp[j]));
+      if (tj) {
+        tie = true;
+        tie_lo = umin(tie_lo, slot[j]);
+        tie_hi = umax(tie_hi, slot[j]);
+      }
+      if (carried[j]) {
+        out_pos[slot[j]] = pp[j];
+        out_id[slot[j]] = oid[j];
+        where_new[oid[j]] = slot[j];
       }
     }
     if (wave::any(tie)) {
