@@ -2770,6 +2770,72 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
         if (grown == pend) break;
         pend = grown;
       }
+      // Runs of consecutive pending lanes are chains: the first lane's blocker is stalled already,
+      // every other lane's blocker is the lane before it.  A chain collides lane by lane until a
+      // lane cannot reach its blocker's landing position or draws "avoid"; whatever follows in the
+      // run stays as it is (its blocker is not stalled).  While the chain holds, the blocker of the
+      // lane at offset d of its run lands d bp behind (rev) / ahead of (fwd) the landing position
+      // of the run's own blocker, so which lanes can draw at all follows from the positions and
+      // moves alone and is worked out once; the draws are then taken in lane order, all at once,
+      // and every "avoid" only drops the rest of its run and moves the later lanes to earlier raws.
+      // The lane-by-lane rounds below handle what this does not: a pending unit AT its blocker's
+      // position (a collision then moves it by 0, not by distance - 1) and moves that wrap.
+      if (pend != 0) {
+        const bool mine = ((pend >> lane) & 1u) != 0;
+        const bool odd = (mine && P == blocker_pos) || (act && (FWD ? P + M < P : M > P));
+        const bool carry_odd = FWD ? carry_pos + carry_move < carry_pos : carry_move > carry_pos;
+        if (!wave::any(odd) && !carry_odd) {
+          const u32 bI_in = wave::shfl_up1(id);
+          const u32 bId = lane > 0 ? bI_in : carry_id;
+          const u32 carry_land = FWD ? carry_pos + carry_move : carry_pos - carry_move;
+          const u64 lt = lanemask_lt(lane), le = lt | (u64(1) << lane);
+          const u64 starts = pend & ~(pend << 1), ends = pend & ~(pend >> 1);
+          const u32 s = mine ? static_cast<u32>(63 - wave::clz64(starts & le)) : lane;  // start of the lane's run
+          const u32 land = FWD ? P + M : P - M;  // (final for the lanes that are not pending)
+          const u32 lb_in = wave::shfl(land, s > 0 ? s - 1 : 0u);
+          const u32 lb = s > 0 ? lb_in : carry_land;
+          const u32 off = lane - s;
+          const u32 land_prev = FWD ? lb - off : lb + off;  // the blocker's landing while the chain holds
+          const bool geo = FWD ? (P + M >= land_prev) : (P - M <= land_prev);
+          const u64 ngeo = wave::ballot(mine && !geo);
+          const bool alive = mine && ((ngeo & le) >> s) == 0;  // no lane of the run up to here falls short
+          u64 live = wave::ballot(alive);  // lanes that draw unless an "avoid" before them ends their run
+          u64 hits = 0;                    // lanes that collide
+          u32 drawn = 0;                   // raws consumed
+          while (live != 0) {
+            bool outcome = !never_collide;
+            if (trials) {
+              rng_ensure(c.g, drawn + static_cast<u32>(wave::popc64(live)));
+              const u32 tq = drawn + static_cast<u32>(wave::popc64(live & lt));
+              outcome = bernoulli_raw(rng_peek(c.g, c.g.pos + tq), p_collide);
+            }
+            const u64 av = wave::ballot(((live >> lane) & 1u) != 0 && !outcome);
+            if (av == 0) {
+              hits |= live;
+              drawn += static_cast<u32>(wave::popc64(live));
+              break;
+            }
+            const u32 a = static_cast<u32>(wave::ctz64(av));                       // the first "avoid"
+            const u32 e = static_cast<u32>(wave::ctz64(ends & ~lanemask_lt(a)));  // end of its run
+            hits |= live & lanemask_lt(a);
+            drawn += static_cast<u32>(wave::popc64(live & lanemask_lt(a))) + 1;
+            if (lane == a) {
+              C = cw_make(bId, EV_LEF_LEF_SECONDARY);
+              if (n_list < list_cap) list[n_list] = k;
+            }
+            ++n_list;
+            if (n_list > list_cap) overflow = true;
+            live = e >= 63 ? u64(0) : live & ~lanemask_lt(e + 1);
+          }
+          if (trials && drawn != 0) rng_advance(c.g, drawn);
+          if ((hits >> lane) & 1u) {
+            const u32 move = FWD ? land_prev - P : P - land_prev;
+            M = umin(move, move - 1);
+            C = cw_make(bId, EV_COLLISION | EV_LEF_LEF_SECONDARY);
+          }
+          pend = 0;
+        }
+      }
       // Rounds: a pending lane is ready when its blocker (the lane before it) is not pending any
       // more; all ready lanes below the first lane that still waits are resolved together, their
       // Bernoulli draws numbered in lane order (the reference's visiting order).  A batch
