@@ -2542,28 +2542,45 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
     if (base + 128 < n) {
       primary_load_batch(wave::LdRaw{}, ws, n, base + 128, next_pf > 0 ? next_pf - 1 : 0, lane, cur, true);
     }
+    // the partner of each unit (the fwd unit right upstream of it): its five words are read from
+    // the slices together, without branches; partners beyond the slices come from device memory
+    static_assert(PRIMARY_NEAR == STAGE_CAP, "one staged range for all five fwd-side arrays");
     bool cand[2] = {false, false};
-    u32 F[2] = {0, 0}, rev_move[2] = {0, 0}, fwd_move[2] = {0, 0}, fwd_id_s[2] = {0, 0}, fc_s[2] = {0, 0},
-        fbp_s[2] = {0, 0};
+    u32 F[2], rev_move[2], fwd_move[2], fwd_id_s[2], fc_s[2], fbp_s[2];
+    bool has[2], staged[2];
 #pragma unroll
     for (u32 j = 0; j < 2; ++j) {
-      if (act[j] && pf[j] >= 1 && pf[j] < i2) {
-        const u32 kf = pf[j] - 1;
-        const bool staged = kf >= w0 && kf - w0 < STAGE_CAP;
-        const bool near = kf >= w0 && kf - w0 < PRIMARY_NEAR;
-        F[j] = staged ? stage[kf - w0] : ws.f_pos[kf];
-        const u32 Rprev = j == 0 ? Rprev0 : R[0];
-        const bool first_after = (k[j] == first) || Rprev <= F[j];
-        if (first_after) {
-          rev_move[j] = rev_move_k[j];
-          fwd_move[j] = near ? st_move[kf - w0] : ws.f_move[kf];
-          fwd_id_s[j] = near ? st_id[kf - w0] : ws.f_id[kf];
-          fc_s[j] = near ? st_coll[kf - w0] : ws.f_coll[kf];
-          fbp_s[j] = near ? st_bp[kf - w0] : stalling_barrier_positions<true>(ws)[kf];
-          const u32 delta = R[j] - F[j];  // > 0 by construction
-          cand[j] = static_cast<u64>(delta) < static_cast<u64>(rev_move[j]) + fwd_move[j];
+      has[j] = act[j] && pf[j] >= 1 && pf[j] < i2;
+      const u32 kf = pf[j] - 1;
+      staged[j] = has[j] && kf >= w0 && kf - w0 < STAGE_CAP;
+      const u32 e = staged[j] ? kf - w0 : 0u;
+      F[j] = stage[e];
+      fwd_move[j] = st_move[e];
+      fwd_id_s[j] = st_id[e];
+      fc_s[j] = st_coll[e];
+      fbp_s[j] = st_bp[e];
+      rev_move[j] = rev_move_k[j];
+    }
+    wave::sched_fence();
+    if (wave::any((has[0] && !staged[0]) || (has[1] && !staged[1]))) {
+#pragma unroll
+      for (u32 j = 0; j < 2; ++j) {
+        if (has[j] && !staged[j]) {
+          const u32 kf = pf[j] - 1;
+          F[j] = ws.f_pos[kf];
+          fwd_move[j] = ws.f_move[kf];
+          fwd_id_s[j] = ws.f_id[kf];
+          fc_s[j] = ws.f_coll[kf];
+          fbp_s[j] = stalling_barrier_positions<true>(ws)[kf];
         }
       }
+    }
+#pragma unroll
+    for (u32 j = 0; j < 2; ++j) {
+      const u32 Rprev = j == 0 ? Rprev0 : R[0];
+      const bool first_after = (k[j] == first) || Rprev <= F[j];
+      const u32 delta = R[j] - F[j];  // > 0 by construction (where it is used)
+      cand[j] = has[j] && first_after && static_cast<u64>(delta) < static_cast<u64>(rev_move[j]) + fwd_move[j];
     }
     const u64 cm0 = wave::ballot(cand[0]), cm1 = wave::ballot(cand[1]);
     bool hit[2] = {cand[0] && !never_collide, cand[1] && !never_collide};
