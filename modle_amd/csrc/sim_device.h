@@ -2362,10 +2362,11 @@ MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
 // compute_lef_lef_collision_pos (reference: simulation.cpp:523-551)
 MODLE_DEV void lef_lef_collision_pos(u32 rev_p, u32 fwd_p, u32 rev_move, u32 fwd_move,
                                      u32& out_rev, u32& out_fwd) {
-  const u64 relative_speed = static_cast<u64>(rev_move) + fwd_move;
-  const f64 ttc = static_cast<f64>(static_cast<u64>(rev_p - fwd_p)) / static_cast<f64>(relative_speed);
-  const u32 cpos = fwd_p + static_cast<u32>(static_cast<u64>(
-                               wave::f_round(static_cast<f64>(static_cast<u64>(fwd_move)) * ttc)));
+  // (all operands are below 2^32: the sum of the two converted moves is exact and equals the
+  // converted 64-bit sum, and the rounded product is at most fwd_move: 32-bit conversions)
+  const f64 relative_speed = static_cast<f64>(rev_move) + static_cast<f64>(fwd_move);
+  const f64 ttc = static_cast<f64>(rev_p - fwd_p) / relative_speed;
+  const u32 cpos = fwd_p + static_cast<u32>(wave::f_round(static_cast<f64>(fwd_move) * ttc));
   if (cpos == fwd_p) {
     out_rev = cpos + 1;
     out_fwd = cpos;
@@ -2573,6 +2574,13 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
           fc_s[j] = ws.f_coll[kf];
           fbp_s[j] = stalling_barrier_positions<true>(ws)[kf];
         }
+        // (the loads end HERE: where values loaded on a rare path merge with the common path the
+        // compiler waits for everything in flight -- the next block's loads -- on both)
+        wave::pin(F[j]);
+        wave::pin(fwd_move[j]);
+        wave::pin(fwd_id_s[j]);
+        wave::pin(fc_s[j]);
+        wave::pin(fbp_s[j]);
       }
     }
 #pragma unroll
@@ -2596,46 +2604,73 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
       hit[1] = cand[1] && bernoulli_raw(rng_peek(c.g, c.g.pos + t1), p_collide);
       rng_advance(c.g, cnt);
     }
-#pragma unroll
-    for (u32 j = 0; j < 2; ++j) {
-      if (hit[j]) {
-        const u32 kf = pf[j] - 1;
-        const u32 rev_id = rev_id_k[j], fwd_id = fwd_id_s[j];
-        u32 cpos_rev, cpos_fwd;
-        lef_lef_collision_pos(R[j], F[j], rev_move[j], fwd_move[j], cpos_rev, cpos_fwd);
-        const u32 rc = rc_k[j], fc = fc_s[j];
-        const bool rev_occ = cw_occurred(rc), fwd_occ = cw_occurred(fc);
-        bool both = false;
-        if (!rev_occ && !fwd_occ) {
-          ws.r_coll[k[j]] = cw_make(fwd_id, prim);
+    // The collisions are rare (a few units per block) and their handling is long divergent code:
+    // it runs once for the lane's unit that collided, and a second time only when both units of a
+    // lane did.
+    const auto handle_hit = [&](u32 pf_h, u32 k_h, u32 R_h, u32 F_h, u32 rev_move_h, u32 fwd_move_h, u32 rev_id_k_h,
+                                u32 fwd_id_s_h, u32 rc_k_h, u32 fc_s_h, u32 rbp_k_h, u32 fbp_s_h) {
+      const u32 kf = pf_h - 1;
+      const u32 rev_id = rev_id_k_h, fwd_id = fwd_id_s_h;
+      u32 cpos_rev, cpos_fwd;
+      lef_lef_collision_pos(R_h, F_h, rev_move_h, fwd_move_h, cpos_rev, cpos_fwd);
+      const u32 rc = rc_k_h, fc = fc_s_h;
+      const bool rev_occ = cw_occurred(rc), fwd_occ = cw_occurred(fc);
+      u32 rev_other = 0, fwd_other = 0;
+      const bool rev_odd = rev_occ && !cw_occurred_as(rc, EV_LEF_BAR);
+      const bool fwd_odd = fwd_occ && !cw_occurred_as(fc, EV_LEF_BAR);
+      // a stalled unit whose word is not a LEF-BAR collision (flagged at the interval boundary):
+      // the barrier its index points at is read on a path of its own, and the load ends there
+      // (see above)
+      if (rev_odd || fwd_odd) {
+        if (rev_odd) rev_other = stalling_barrier_pos(iv, rc);
+        if (fwd_odd) fwd_other = stalling_barrier_pos(iv, fc);
+        wave::pin(rev_other);
+        wave::pin(fwd_other);
+      }
+      bool both = false;
+      if (!rev_occ && !fwd_occ) {
+        ws.r_coll[k_h] = cw_make(fwd_id, prim);
+        ws.f_coll[kf] = cw_make(rev_id, prim);
+        both = true;
+      } else if (rev_occ && !fwd_occ) {
+        const u32 barrier_pos = rev_odd ? rev_other : rbp_k_h;
+        ws.f_coll[kf] = cw_make(rev_id, prim);
+        if (cpos_fwd > barrier_pos) {
+          // the LEF-LEF collision happens before the predicted LEF-BAR one
+          ws.r_coll[k_h] = cw_make(fwd_id, prim);
+          both = true;
+        } else if (fuse_correct && cw_occurred_as(rc, EV_LEF_BAR)) {
+          // fwd unit runs into a rev unit that stays stalled 1 bp downstream of its barrier
+          const u32 rev_move_stalled = (R_h - barrier_pos) - 1;
+          ws.f_move[kf] = (R_h - rev_move_stalled) - F_h - 1;
+        }
+      } else if (!rev_occ && fwd_occ) {
+        const u32 barrier_pos = fwd_odd ? fwd_other : fbp_s_h;
+        ws.r_coll[k_h] = cw_make(fwd_id, prim);
+        if (cpos_rev < barrier_pos) {
           ws.f_coll[kf] = cw_make(rev_id, prim);
           both = true;
-        } else if (rev_occ && !fwd_occ) {
-          const u32 barrier_pos = cw_occurred_as(rc, EV_LEF_BAR) ? rbp_k[j] : stalling_barrier_pos(iv, rc);
-          ws.f_coll[kf] = cw_make(rev_id, prim);
-          if (cpos_fwd > barrier_pos) {
-            // the LEF-LEF collision happens before the predicted LEF-BAR one
-            ws.r_coll[k[j]] = cw_make(fwd_id, prim);
-            both = true;
-          } else if (fuse_correct && cw_occurred_as(rc, EV_LEF_BAR)) {
-            // fwd unit runs into a rev unit that stays stalled 1 bp downstream of its barrier
-            const u32 rev_move_stalled = (R[j] - barrier_pos) - 1;
-            ws.f_move[kf] = (R[j] - rev_move_stalled) - F[j] - 1;
-          }
-        } else if (!rev_occ && fwd_occ) {
-          const u32 barrier_pos = cw_occurred_as(fc, EV_LEF_BAR) ? fbp_s[j] : stalling_barrier_pos(iv, fc);
-          ws.r_coll[k[j]] = cw_make(fwd_id, prim);
-          if (cpos_rev < barrier_pos) {
-            ws.f_coll[kf] = cw_make(rev_id, prim);
-            both = true;
-          } else if (fuse_correct && cw_occurred_as(fc, EV_LEF_BAR)) {
-            const u32 fwd_move_stalled = (barrier_pos - F[j]) - 1;
-            ws.r_move[k[j]] = R[j] - (F[j] + fwd_move_stalled) - 1;
-          }
+        } else if (fuse_correct && cw_occurred_as(fc, EV_LEF_BAR)) {
+          const u32 fwd_move_stalled = (barrier_pos - F_h) - 1;
+          ws.r_move[k_h] = R_h - (F_h + fwd_move_stalled) - 1;
         }
-        if (both && fuse_correct) {
-          ws.r_move[k[j]] = R[j] - cpos_rev;
-          ws.f_move[kf] = cpos_fwd - F[j];
+      }
+      if (both && fuse_correct) {
+        ws.r_move[k_h] = R_h - cpos_rev;
+        ws.f_move[kf] = cpos_fwd - F_h;
+      }
+    };
+    if (wave::any(hit[0] || hit[1])) {
+      const u32 h = hit[0] ? 0u : 1u;
+      if (hit[0] || hit[1]) {
+        handle_hit(h ? pf[1] : pf[0], h ? k[1] : k[0], h ? R[1] : R[0], h ? F[1] : F[0], h ? rev_move[1] : rev_move[0],
+                   h ? fwd_move[1] : fwd_move[0], h ? rev_id_k[1] : rev_id_k[0], h ? fwd_id_s[1] : fwd_id_s[0],
+                   h ? rc_k[1] : rc_k[0], h ? fc_s[1] : fc_s[0], h ? rbp_k[1] : rbp_k[0], h ? fbp_s[1] : fbp_s[0]);
+      }
+      if (wave::any(hit[0] && hit[1])) {
+        if (hit[0] && hit[1]) {
+          handle_hit(pf[1], k[1], R[1], F[1], rev_move[1], fwd_move[1], rev_id_k[1], fwd_id_s[1], rc_k[1], fc_s[1],
+                     rbp_k[1], fbp_s[1]);
         }
       }
     }
