@@ -2122,6 +2122,12 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
         bool edge = false;
         if (bnd[j]) lef_bar_window<FWD, false>(v, nb, 0, lo_key[j], hi_key[j], b_lo, b_hi, edge);
         winner[j] = lef_bar_pick<FWD, false>(v, p, c.g, b_lo, b_hi, 0, hard[j], bpos[j]);
+        // (the loads of this rare path end here: see detect_primary)
+        wave::pin(winner[j]);
+        wave::pin(bpos[j]);
+        u32 hd = hard[j] ? 1u : 0u;
+        wave::pin(hd);
+        hard[j] = hd != 0;
       }
       // the staged entries stay valid, but the next block must not trust the anchor
       lo_cover = 1;
