@@ -3597,14 +3597,22 @@ MODLE_DEV LoopStats loop_size_stats(Cell& c) {
   // pass B, LEF-id order: strictly sequential accumulation like std::accumulate: every lane
   // computes its term, the terms of a batch are folded in lane order through broadcasts
   f64 ssd = 0.0;
-  for (u32 group = 0; group < n; group += 64 * UX) {
+  struct SizeRegs {
     u32 lf[UX], lr[UX];
+  };
+  const auto load_sizes = [&](u32 group, SizeRegs& r) {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 i = group + 64 * u + lane;
-      lf[u] = i < n ? by_id_fwd[i] : 0;
-      lr[u] = i < n ? by_id_rev[i] : 0;
+      r.lf[u] = wave::LdRaw{}(by_id_fwd, i, i < n, 0, 0u);
+      r.lr[u] = wave::LdRaw{}(by_id_rev, i, i < n, 0, 0u);
     }
+  };
+  SizeRegs scur;
+  load_sizes(0, scur);
+  for (u32 group = 0; group < n; group += 64 * UX) {
+    const SizeRegs sg = scur;  // (the next group's loads are in flight during the fold)
+    if (group + 64 * UX < n) load_sizes(group + 64 * UX, scur);
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 base = group + 64 * u;
@@ -3612,7 +3620,7 @@ MODLE_DEV LoopStats loop_size_stats(Cell& c) {
       const u32 i = base + lane;
       f64 term = 0.0;
       if (i < n) {
-        const u32 ls = lf[u] - lr[u];
+        const u32 ls = sg.lf[u] - sg.lr[u];
         const f64 d = static_cast<f64>(static_cast<u64>(ls)) - avg;
         term = d * d;
       }
