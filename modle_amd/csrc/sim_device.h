@@ -571,10 +571,13 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
     r.I = wave::ld4(ids, wq);
     r.K = wave::ld4(marks, wq);
   };
+  // (the block's registers are taken over at the BOTTOM of the loop, behind the stores: there the
+  // compiler can count what was issued after the loads and waits for the loads alone; at the top,
+  // where the first iteration and the back edge meet, it would wait for the stores as well)
   Blk cur;
   load_blk(0, cur);
+  Blk g = cur;
   for (u32 t = 0; t < nblk; ++t) {
-    const Blk g = cur;
     if (t + 1 < nblk) load_blk(t + 1, cur);
     const u32 w = 256 * t + 4 * lane;
     u32 pp[4], oid[4], mx[4], nb[4];
@@ -695,17 +698,20 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
         tie_lo = umin(tie_lo, slot[j]);
         tie_hi = umax(tie_hi, slot[j]);
       }
-      if (carried[j]) {
-        out_pos[slot[j]] = pp[j];
-        out_id[slot[j]] = oid[j];
-        where_new[oid[j]] = slot[j];
-      }
+      // (unconditional stores: the lanes that have nothing to store hit a scratch word.  With the
+      // stores under a branch the compiler cannot count them, and the wait for the next block's
+      // loads at the top of the loop becomes a wait for these stores as well)
+      u32* const dump = reinterpret_cast<u32*>(ws.sort_keys) + lane;
+      *(carried[j] ? &out_pos[slot[j]] : dump) = pp[j];
+      *(carried[j] ? &out_id[slot[j]] : dump) = oid[j];
+      *(carried[j] ? &where_new[oid[j]] : dump) = slot[j];
     }
     if (wave::any(tie)) {
       ties = true;
       t_lo = umin(t_lo, ~wave::bcast(wave_prefix_max_u32(~tie_lo), 63));
       t_hi = umax(t_hi, wave::bcast(wave_prefix_max_u32(tie_hi), 63));
     }
+    if (t + 1 < nblk) g = cur;
   }
   if (seen_new != n_new) return false;  // (the marks and the list disagree: cannot happen)
   wave::sync_lds();
