@@ -3288,12 +3288,13 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
       for (u32 q = 0; q < 4; ++q) {
         if (rel[q]) {
           const u32 i = w + q;
-          ws.epoch[i] = UNBOUND;
           const u32 j = lane_slot + rel_before[q];
           if (j < REL_CAP) {
-            list[j] = i;
+            list[j] = i;  // (its epoch and units are marked from the list, after the sweep: no
+                          // store here that the wait for the next block's loads would include)
           } else {
             // more releases than the list holds (the next bind then sweeps the LEFs instead)
+            ws.epoch[i] = UNBOUND;
             ws.r_pos[ws.r_rank[i]] = UNBOUND;
             ws.f_pos[ws.f_rank[i]] = UNBOUND;
           }
@@ -3310,6 +3311,7 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
     const u32 e = base + lane;
     if (e < n_listed) {
       const u32 id = list[e];
+      ws.epoch[id] = UNBOUND;
       ws.r_pos[ws.r_rank[id]] = UNBOUND;
       ws.f_pos[ws.f_rank[id]] = UNBOUND;
     }
