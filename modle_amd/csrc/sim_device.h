@@ -1078,52 +1078,66 @@ MODLE_DEV_NOINLINE void generate_moves_by_id(Cell& c, f64 speed, f64 std, u32* m
 // downwards, so that the suffix scan over ranks is again a prefix scan over (lane, unit).
 // Returns the rank the sequential replay has to start from (adjust_moves_rev / _fwd), or -1.
 template <bool FWD>
-MODLE_DEV_NOINLINE i64 adjust_moves_x4(Cell& c, bool do_adjust, bool do_clamp, const u32* mv_by_id) {
-  Workspace& ws = c.ws;
-  const u32 n = wave::uniform(c.n_active);
-  const u32 lane = wave::lane();
-  const u32 start = c.iv->start;
-  const u32 last = c.iv->end - 1;
-  const u32* pos = FWD ? ws.f_pos : ws.r_pos;
-  const u32* uid = FWD ? ws.f_id : ws.r_id;
-  const u32* mv_in = FWD ? ws.f_move : ws.r_move;
-  u32* mv_out = ws.tmp[0];
-  const bool by_id = mv_by_id != nullptr;
-  const u32 nblk = (n + 255) / 256;
-  i32 carry_d = 0;
-  bool carry_ok = false, carry_cross = false;
-  i64 viol_rank = -1;
-  // first rank of this lane in block t of the sweep (t = 0 is the block the sweep starts with)
-  const auto word0 = [&](u32 t) { return (FWD ? t : nblk - 1 - t) * 256 + 4 * (FWD ? lane : 63 - lane); };
+struct AdjustSweepX4 {
   struct Blk {
     wave::U32x4 P, M;
   };
-  // the ids of a block are requested one block ahead of its positions and (gathered) moves
-  const auto load_ids = [&](u32 t, wave::U32x4& I) {
-    const u32 w = word0(t);
-    I = wave::ld4(uid, (by_id && t < nblk && w < n) ? w : 0u);
-  };
-  const auto load_blk = [&](u32 t, const wave::U32x4& I, Blk& r) {
-    const u32 w = word0(t);
-    const bool in = t < nblk && w < n;
-    r.P = wave::ld4(pos, in ? w : 0u);
-    if (by_id) {
-#pragma unroll
-      for (u32 q = 0; q < 4; ++q) r.M.v[q] = wave::LdRaw{}(mv_by_id, I.v[q], in && w + q < n, 0, 0u);
-    } else {
-      r.M = wave::ld4(mv_in, in ? w : 0u);
-    }
-  };
+  const u32 *pos, *uid, *mv_in, *mv_by_id;
+  u32* mv_out;
+  u32 n, lane, start, last, nblk;
+  bool by_id, do_adjust, do_clamp;
+  i32 carry_d;
+  bool carry_ok, carry_cross;
+  i64 viol_rank;
   wave::U32x4 ids;
   Blk cur;
-  load_ids(0, ids);
-  load_blk(0, ids, cur);
-  if (1 < nblk) load_ids(1, ids);
-  for (u32 t = 0; t < nblk; ++t) {
+
+  // first rank of this lane in block t of the sweep (t = 0 is the block the sweep starts with)
+  MODLE_DEV_MEMBER u32 word0(u32 t) const { return (FWD ? t : nblk - 1 - t) * 256 + 4 * (FWD ? lane : 63 - lane); }
+  // the ids of a block are requested one block ahead of its positions and (gathered) moves
+  MODLE_DEV_MEMBER void load_ids(u32 t) {
+    const u32 w = word0(t);
+    ids = wave::ld4(uid, (by_id && t < nblk && w < n) ? w : 0u);
+  }
+  MODLE_DEV_MEMBER void load_blk(u32 t) {
+    const u32 w = word0(t);
+    const bool in = t < nblk && w < n;
+    cur.P = wave::ld4(pos, in ? w : 0u);
+    if (by_id) {
+#pragma unroll
+      for (u32 q = 0; q < 4; ++q) cur.M.v[q] = wave::LdRaw{}(mv_by_id, ids.v[q], in && w + q < n, 0, 0u);
+    } else {
+      cur.M = wave::ld4(mv_in, in ? w : 0u);
+    }
+  }
+  MODLE_DEV_MEMBER void init(Cell& c, bool adjust, bool clamp, const u32* by_id_moves, u32* out) {
+    Workspace& ws = c.ws;
+    n = wave::uniform(c.n_active);
+    lane = wave::lane();
+    start = c.iv->start;
+    last = c.iv->end - 1;
+    pos = FWD ? ws.f_pos : ws.r_pos;
+    uid = FWD ? ws.f_id : ws.r_id;
+    mv_in = FWD ? ws.f_move : ws.r_move;
+    mv_by_id = by_id_moves;
+    mv_out = out;
+    by_id = by_id_moves != nullptr;
+    do_adjust = adjust;
+    do_clamp = clamp;
+    nblk = (n + 255) / 256;
+    carry_d = 0;
+    carry_ok = false;
+    carry_cross = false;
+    viol_rank = -1;
+    load_ids(0);
+    load_blk(0);
+    if (1 < nblk) load_ids(1);
+  }
+  MODLE_DEV_MEMBER void step(u32 t) {
     const Blk g = cur;
     if (t + 1 < nblk) {
-      load_blk(t + 1, ids, cur);
-      if (t + 2 < nblk) load_ids(t + 2, ids);
+      load_blk(t + 1);
+      if (t + 2 < nblk) load_ids(t + 2);
     }
     const u32 w = word0(t);
     u32 P[4], M[4], k[4];
@@ -1198,13 +1212,23 @@ MODLE_DEV_NOINLINE i64 adjust_moves_x4(Cell& c, bool do_adjust, bool do_clamp, c
     carry_ok = wave::bcast(ok[3], 63);
     carry_cross = wave::bcast(cross[3], 63);
   }
-  return viol_rank;
+};
+
+template <bool FWD>
+MODLE_DEV_NOINLINE i64 adjust_moves_x4(Cell& c, bool do_adjust, bool do_clamp, const u32* mv_by_id) {
+  AdjustSweepX4<FWD> sw;
+  sw.init(c, do_adjust, do_clamp, mv_by_id, c.ws.tmp[0]);
+  for (u32 t = 0; t < sw.nblk; ++t) sw.step(t);
+  return sw.viol_rank;
 }
 
 // `mv_by_id`: moves in LEF-id order (generate_moves_by_id) or nullptr when they already sit in
 // r_move in rank order (phase-level test entry point).
+// `out_slot` / `swept`: the scratch array the sweep writes (ws.tmp[out_slot]) and, when the sweep
+// has been done already (adjust_moves_both_x4), the rank its replay starts from
 MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp,
-                                         const u32* mv_by_id = nullptr) {
+                                         const u32* mv_by_id = nullptr, u32 out_slot = 0,
+                                         const i64* swept = nullptr) {
   Workspace& ws = c.ws;
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
@@ -1212,7 +1236,7 @@ MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp,
   // landing positions minus ranks fit 32 bits on every real chromosome: scans at half the cost
   const bool narrow = wave::uniform(c.iv->end) < 0x7F000000u;
   const u32* mv_in = ws.r_move;
-  u32* mv_out = ws.tmp[0];
+  u32* mv_out = ws.tmp[out_slot];
   const u32 nbatch = (n + 63) / 64;
   const bool by_id = mv_by_id != nullptr;
   i64 carry_d = 0;
@@ -1220,7 +1244,9 @@ MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp,
   i64 viol_rank = -1;
   // lanes hold the ranks of a batch in DESCENDING order (lane 0 = highest rank), so that the
   // suffix scan over ranks is a prefix scan over lanes
-  if (narrow) {
+  if (swept != nullptr) {
+    viol_rank = *swept;
+  } else if (narrow) {
     viol_rank = adjust_moves_x4<false>(c, do_adjust, do_clamp, mv_by_id);
   } else {
   constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
@@ -1320,24 +1346,29 @@ MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp,
     }
     wave::sync_mem();
   }
-  swap_ptr(ws.r_move, ws.tmp[0]);
+  swap_ptr(ws.r_move, ws.tmp[out_slot]);
 }
 
+// `out_slot` / `swept`: the scratch array the sweep writes (ws.tmp[out_slot]) and, when the sweep
+// has been done already (adjust_moves_both_x4), the rank its replay starts from
 MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp,
-                                         const u32* mv_by_id = nullptr) {
+                                         const u32* mv_by_id = nullptr, u32 out_slot = 0,
+                                         const i64* swept = nullptr) {
   Workspace& ws = c.ws;
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
   const u64 last = static_cast<u64>(c.iv->end) - 1;
   const bool narrow = wave::uniform(c.iv->end) < 0x7F000000u;  // see adjust_moves_rev
   const u32* mv_in = ws.f_move;
-  u32* mv_out = ws.tmp[0];
+  u32* mv_out = ws.tmp[out_slot];
   const u32 nbatch = (n + 63) / 64;
   const bool by_id = mv_by_id != nullptr;
   i64 carry_d = 0;
   bool carry_ok = false, carry_cross = false;
   i64 viol_rank = -1;
-  if (narrow) {
+  if (swept != nullptr) {
+    viol_rank = *swept;
+  } else if (narrow) {
     viol_rank = adjust_moves_x4<true>(c, do_adjust, do_clamp, mv_by_id);
   } else {
   constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
@@ -1432,7 +1463,23 @@ MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp,
     }
     wave::sync_mem();
   }
-  swap_ptr(ws.f_move, ws.tmp[0]);
+  swap_ptr(ws.f_move, ws.tmp[out_slot]);
+}
+
+// Both sweeps in one loop: they are independent of each other (rev walks the blocks downwards, fwd
+// upwards), so every iteration carries two dependency chains instead of one.
+MODLE_DEV_NOINLINE void adjust_moves_both_x4(Cell& c, const u32* mv_rev, const u32* mv_fwd, i64& viol_rev,
+                                             i64& viol_fwd) {
+  AdjustSweepX4<false> r;
+  AdjustSweepX4<true> f;
+  r.init(c, true, true, mv_rev, c.ws.tmp[0]);
+  f.init(c, true, true, mv_fwd, c.ws.tmp[1]);
+  for (u32 t = 0; t < r.nblk; ++t) {
+    r.step(t);
+    f.step(t);
+  }
+  viol_rev = r.viol_rank;
+  viol_fwd = f.viol_rank;
 }
 
 // `all_bound`: every active LEF is bound (the epoch loop's invariant at this point)
@@ -1452,7 +1499,13 @@ MODLE_DEV void phase_generate_moves(Cell& c, bool burnin_completed, bool all_bou
   PHASE(c, 5, generate_moves_by_id(c, burnin_completed ? p.rev_speed : p.rev_speed_burnin, p.rev_std, mv_rev);
         generate_moves_by_id(c, burnin_completed ? p.fwd_speed : p.fwd_speed_burnin, p.fwd_std, mv_fwd);
         wave::sync_mem());
-  PHASE(c, 6, adjust_moves_rev(c, true, true, mv_rev); adjust_moves_fwd(c, true, true, mv_fwd));
+  if (wave::uniform(c.iv->end) < 0x7F000000u) {  // (the 32-bit scans apply: see adjust_moves_rev)
+    PHASE(c, 6, i64 vr; i64 vf; adjust_moves_both_x4(c, mv_rev, mv_fwd, vr, vf);
+          wave::sync_mem();
+          adjust_moves_rev(c, true, true, mv_rev, 0, &vr); adjust_moves_fwd(c, true, true, mv_fwd, 1, &vf));
+  } else {
+    PHASE(c, 6, adjust_moves_rev(c, true, true, mv_rev); adjust_moves_fwd(c, true, true, mv_fwd));
+  }
 }
 
 // =============================================================================================
