@@ -36,6 +36,12 @@ struct Cell {
   // set per direction, in ws.tmp[2..3] / ws.tmp[4..5]) for the two rank updates that follow it
   u32 n_keys;
   bool keys_valid;
+  // ws.r_rank / ws.f_rank ([0] rev, [1] fwd) hold the complete inverse permutation.  The rank
+  // update of the epoch loop does not write it (one scattered store per unit and epoch): the
+  // sparse consumers -- bind, release, fix_secondary -- get the ranks of the few LEFs they need
+  // from sweeps that pass over the id arrays anyway (RankFilter below), everything else
+  // (contact sampling, the general rank update, the phase-level hooks) calls ensure_inverse.
+  bool inv_valid[2];
 #ifdef MODLE_PHASE_TIMERS
   u64 ph[16];     // profiling build: time spent per phase (wave::clock ticks)
 #endif
@@ -87,12 +93,76 @@ MODLE_DEV u32 lower_bound_u32(const u32* a, u32 n, u32 key) {  // first index wi
   return lo;
 }
 
+// Rebuilds the inverse permutation of one direction from the id array (one scattered store per
+// unit: only where the complete permutation is really needed).
+template <bool FWD>
+MODLE_DEV_NOINLINE void ensure_inverse(Cell& c) {
+  if (c.inv_valid[FWD ? 1 : 0]) return;
+  Workspace& ws = c.ws;
+  const u32 n = wave::uniform(c.n_active);
+  const u32 lane = wave::lane();
+  const u32* ids = FWD ? ws.f_id : ws.r_id;
+  u32* rank = FWD ? ws.f_rank : ws.r_rank;
+  const u32 nblk = (n + 255) / 256;
+  for (u32 t = 0; t < nblk; ++t) {
+    const u32 w = 256 * t + 4 * lane;
+    const wave::U32x4 I = wave::ld4(ids, w < n ? w : 0u);
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+      if (w + q < n) rank[I.v[q]] = w + q;
+    }
+  }
+  wave::sync_mem();
+  c.inv_valid[FWD ? 1 : 0] = true;
+}
+MODLE_DEV void ensure_inverse_both(Cell& c) {
+  ensure_inverse<false>(c);
+  ensure_inverse<true>(c);
+}
+
+// A set of LEF ids as a bitmap in LDS (the sort buffer, idle outside the rank update and the
+// collision passes that stage windows there): RANK_FILTER_BITS bits indexed by id modulo that
+// size.  Up to 32768 LEFs the test is exact; beyond, ids that share a bit with a member pass as
+// well, which only costs the sweeps that use the filter a few useless stores.
+constexpr u32 RANK_HARD = 0x80000000u;  // flag on a rank reported by the extrusion sweep: hard stall
+constexpr u32 RANK_FILTER_WORDS = SORT_LDS_CAP;  // 64-bit words
+constexpr u32 RANK_FILTER_BITS = 64 * RANK_FILTER_WORDS;
+MODLE_DEV void rank_filter_clear(Cell& c, u32 n_ids) {
+  u64* bm = c.lds.sort_lds;
+  const u32 nw = umin(RANK_FILTER_WORDS, (n_ids + 63) / 64);
+  wave::lockstep();
+  for (u32 k = wave::lane(); k < nw; k += 64) bm[k] = 0;
+  wave::sync_lds();
+}
+// adds the ids [first, first + 64) whose bit is set in `members` (uniform)
+MODLE_DEV void rank_filter_add_mask(Cell& c, u32 first, u64 members) {
+  u64* bm = c.lds.sort_lds;
+  if (wave::lane() == 0) bm[(first / 64) % RANK_FILTER_WORDS] |= members;
+}
+// adds one id per lane (where `valid`)
+MODLE_DEV void rank_filter_add_ids(Cell& c, u32 id, bool valid) {
+  u32* bm = reinterpret_cast<u32*>(c.lds.sort_lds);
+  const u32 lane = wave::lane();
+  u64 m = wave::ballot(valid);
+  while (m != 0) {
+    const u32 l = static_cast<u32>(wave::ctz64(m));
+    m &= m - 1;
+    const u32 x = wave::bcast(id, l);
+    if (lane == 0) bm[(x % RANK_FILTER_BITS) >> 5] |= 1u << (x & 31u);
+  }
+}
+MODLE_DEV bool rank_filter_test(const Cell& c, u32 id) {
+  const u32* bm = reinterpret_cast<const u32*>(c.lds.sort_lds);
+  return ((bm[(id % RANK_FILTER_BITS) >> 5] >> (id & 31u)) & 1u) != 0;
+}
+
 // =============================================================================================
 // select_and_bind_lefs (reference: simulation.cpp:988-993, simulation_impl.hpp:30-91)
 // =============================================================================================
 MODLE_DEV_NOINLINE void phase_bind(Cell& c, u32 epoch_now) {
   const Interval& iv = *c.iv;
   c.keys_valid = false;
+  ensure_inverse_both(c);
   Workspace& ws = c.ws;
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
@@ -416,7 +486,12 @@ MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_
 // Steps 4 and 5 of a rank update: order equal positions, make the new arrays current.
 // Every pair of neighbours with equal positions lies inside the output slots [t_lo, t_hi] (the
 // sweeps flag at least one member of every such pair): the transposition passes stay inside that
-// range (one slot of margin on both sides) and keep the inverse permutation up to date as they go.
+// range (one slot of margin on both sides).
+// `where` != nullptr (general update): the previous ranks by LEF id are the last tie-break and the
+// new inverse permutation (ws.tmp[7]) is kept up to date and made current.
+// `where` == nullptr (update of the epoch loop): the merge has left equal positions in the order
+// of their previous ranks, so a STABLE ordering by binding epoch is the full comparator; no
+// inverse permutation is written.
 template <bool FWD>
 MODLE_DEV void rank_finish(Cell& c, bool ties, const u32* where, u32 t_lo, u32 t_hi) {
   Workspace& ws = c.ws;
@@ -427,6 +502,7 @@ MODLE_DEV void rank_finish(Cell& c, bool ties, const u32* where, u32 t_lo, u32 t
   u32* out_pos = ws.tmp[0];
   u32* out_id = ws.tmp[1];
   u32* where_new = ws.tmp[7];
+  const bool by_epoch_only = where == nullptr;
   if (ties) {
     // 4. order equal positions (epoch rule, then previous rank) with a stable odd-even
     //    transposition
@@ -443,11 +519,20 @@ MODLE_DEV void rank_finish(Cell& c, bool ties, const u32* where, u32 t_lo, u32 t
             const u32 pa = out_pos[k], pb = out_pos[k + 1];
             if (pa == pb) {
               const u32 ia = out_id[k], ib = out_id[k + 1];
-              if (rank_pair_out_of_order<FWD>(ws, where, pa, ia, pb, ib)) {
+              bool ooo;
+              if (by_epoch_only) {
+                const u32 ea = ws.epoch[ia], eb = ws.epoch[ib];
+                ooo = FWD ? ea < eb : ea > eb;
+              } else {
+                ooo = rank_pair_out_of_order<FWD>(ws, where, pa, ia, pb, ib);
+              }
+              if (ooo) {
                 out_id[k] = ib;
                 out_id[k + 1] = ia;
-                where_new[ib] = k;
-                where_new[ia] = k + 1;
+                if (!by_epoch_only) {
+                  where_new[ib] = k;
+                  where_new[ia] = k + 1;
+                }
                 sw = true;
               }
             }
@@ -461,7 +546,10 @@ MODLE_DEV void rank_finish(Cell& c, bool ties, const u32* where, u32 t_lo, u32 t
   // 5. the new arrays become current
   swap_ptr(pos, ws.tmp[0]);
   swap_ptr(ids, ws.tmp[1]);
-  if (FWD) swap_ptr(ws.f_rank, ws.tmp[7]); else swap_ptr(ws.r_rank, ws.tmp[7]);
+  if (!by_epoch_only) {
+    if (FWD) swap_ptr(ws.f_rank, ws.tmp[7]); else swap_ptr(ws.r_rank, ws.tmp[7]);
+  }
+  c.inv_valid[FWD ? 1 : 0] = !by_epoch_only;
 }
 
 // The rank update of the epoch loop when phase_bind_listed has left the keys of the units it bound
@@ -490,7 +578,6 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
   const u64* src = reinterpret_cast<const u64*>(FWD ? ws.tmp[4] : ws.tmp[2]);
   u32* out_pos = ws.tmp[0];
   u32* out_id = ws.tmp[1];
-  u32* where_new = ws.tmp[7];
   const u32 nblk = (n + 255) / 256;
   wave::lockstep();
   for (u32 base = 0; base < n_listed; base += 64) {
@@ -614,7 +701,9 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
 #pragma unroll
     for (u32 j = 0; j < 4; ++j) {
       lo[j] = carried[j] ? carry_lo : 0u;
-      thr[j] = FWD ? ((static_cast<u64>(pp[j]) + 1) << 32) : (static_cast<u64>(pp[j]) << 32);
+      // (position, previous rank): units and keys with equal positions merge in the order of their
+      // previous ranks, which is what lets rank_finish order them by binding epoch alone
+      thr[j] = (static_cast<u64>(pp[j]) << 32) | (w + j);
     }
 #pragma unroll
     for (u32 sft = 8; sft >= 1; sft >>= 1) {
@@ -665,34 +754,36 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
     bool tie = false;
     u32 tie_lo = 0xFFFFFFFFu, tie_hi = 0;
     u32 slot[4], lo_prev[4];
-    // the key next to each unit (fwd: the last key before it, rev: the first key after it), read
-    // together: equal positions are flagged for the final ordering
-    u64 nk[4];
-    bool nk_in[4];
     bool gaps = false;  // keys lie between a unit and the carried-over unit before it
 #pragma unroll
     for (u32 j = 0; j < 4; ++j) {
       slot[j] = w + j - (lane_before + nb[j]) + lo[j];
       lo_prev[j] = j == 0 ? lane_lo : umax(lane_lo, lmx[j - 1]);
       gaps = gaps || (carried[j] && lo_prev[j] < lo[j]);
-      nk_in[j] = carried[j] & (FWD ? lo[j] > 0 : lo[j] < n_new);
-      nk[j] = keys[nk_in[j] ? (FWD ? lo[j] - 1 : lo[j]) : 0];
     }
-    wave::sched_fence();
     if (wave::any(gaps)) {
 #pragma unroll
       for (u32 j = 0; j < 4; ++j) {
         if (carried[j]) {
-          // keys [lo of the carried-over unit before, lo) lie between that unit and this one
-          for (u32 q = lo_prev[j]; q < lo[j]; ++q) cnt_lds[q] = slot[j] - lo[j];
+          // keys [lo of the carried-over unit before, lo) lie between that unit and this one; a
+          // key at the position of either neighbour is flagged for the final ordering
+          const u32 a = slot[j] - lo[j];
+          for (u32 q = lo_prev[j]; q < lo[j]; ++q) {
+            cnt_lds[q] = a;
+            const u32 kp = static_cast<u32>(keys[q] >> 32);
+            if (kp != UNBOUND && (kp == pp[j] || (a > 0 && kp == excl[j]))) {
+              tie = true;
+              tie_lo = umin(tie_lo, q + a);
+              tie_hi = umax(tie_hi, q + a);
+            }
+          }
         }
       }
     }
 #pragma unroll
     for (u32 j = 0; j < 4; ++j) {
       const u32 a = slot[j] - lo[j];
-      const bool tj = carried[j] && pp[j] != UNBOUND &&
-                      ((nk_in[j] && static_cast<u32>(nk[j] >> 32) == pp[j]) || (a > 0 && excl[j] == pp[j]));
+      const bool tj = carried[j] && pp[j] != UNBOUND && a > 0 && excl[j] == pp[j];
       if (tj) {
         tie = true;
         tie_lo = umin(tie_lo, slot[j]);
@@ -704,7 +795,6 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
       u32* const dump = reinterpret_cast<u32*>(ws.sort_keys) + lane;
       *(carried[j] ? &out_pos[slot[j]] : dump) = pp[j];
       *(carried[j] ? &out_id[slot[j]] : dump) = oid[j];
-      *(carried[j] ? &where_new[oid[j]] : dump) = slot[j];
     }
     if (wave::any(tie)) {
       ties = true;
@@ -725,8 +815,10 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
       const u32 nid = ids[static_cast<u32>(key)];  // the slot the unit was bound in
       wave::st_stream(&out_pos[bq + lo], pp);
       wave::st_stream(&out_id[bq + lo], nid);
-      where_new[nid] = bq + lo;
       tie = bq + 1 < n_new && static_cast<u32>(keys[bq + 1] >> 32) == pp;
+      // (a key behind the last carried-over unit, at its position: no unit follows to flag it)
+      tie = tie || (lo == n_old && n_old != 0 && pp == run_max);
+      tie = tie && pp != UNBOUND;
     }
     if (wave::any(tie)) {
       ties = true;
@@ -736,7 +828,7 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
     }
   }
   wave::sync_mem();
-  rank_finish<FWD>(c, ties, FWD ? ws.f_rank : ws.r_rank, t_lo, t_hi);
+  rank_finish<FWD>(c, ties, nullptr, t_lo, t_hi);
   return true;
 }
 
@@ -754,6 +846,7 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
     }
     c.keys_valid = false;  // (the general update below overwrites the arrays that hold them)
   }
+  ensure_inverse<FWD>(c);  // the previous ranks by LEF id are the last tie-break
   const u32 lane = wave::lane();
   const u32* pos = FWD ? ws.f_pos : ws.r_pos;
   const u32* ids = FWD ? ws.f_id : ws.r_id;
@@ -965,6 +1058,7 @@ MODLE_DEV_NOINLINE void generate_moves_dir(Cell& c, f64 speed, f64 std) {
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
   u32* moves = FWD ? ws.f_move : ws.r_move;
+  ensure_inverse<FWD>(c);
   const u32* rank = FWD ? ws.f_rank : ws.r_rank;
   if (std == 0.0) {
     const u32 move_int = static_cast<u32>(static_cast<u64>(wave::f_round(speed)));
@@ -2353,10 +2447,6 @@ MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
         // one block; a single unit with more trials than that is replayed sequentially.
         u64 pend = wave::ballot(bnd);
         u32 base_tr = 0;  // trials consumed by the lanes resolved so far
-#ifdef MODLE_TRACE
-        if (wave::lane() == 0 && getenv("MO_TRACE_TRIALS"))
-          fprintf(stderr, "trial rounds: %u trials in one batch\n", total);
-#endif
         while (pend != 0) {
           const bool mine_pending = ((pend >> lane) & 1u) != 0;
           const bool fits = mine_pending && (off + ntr - base_tr <= RNG_BLOCK);
@@ -2365,10 +2455,6 @@ MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
             const u32 l = static_cast<u32>(wave::ctz64(pend));
             const u32 lo = wave::bcast(b_lo, l), hi = wave::bcast(b_hi, l);
             const u32 major_dir = FWD ? DIR_FWD : DIR_REV;
-#ifdef MODLE_TRACE
-            if (wave::lane() == 0 && getenv("MO_TRACE_TRIALS"))
-              fprintf(stderr, "  sequential unit: %u barriers in its window\n", hi - lo);
-#endif
             u32 w = 0xFFFFFFFFu;
             bool h = false;
             for (u32 q = lo; q < hi; ++q) {
@@ -2749,6 +2835,7 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
 // as a stand-alone pass; only used by the phase-level test entry point when the reference's
 // hook sequence runs it separately from detection.
 MODLE_DEV_NOINLINE void correct_moves_primary_standalone(Cell& c) {
+  ensure_inverse_both(c);
   Workspace& ws = c.ws;
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
@@ -3173,6 +3260,48 @@ MODLE_DEV_NOINLINE void fix_secondary_fwd(Cell& c, const u32* list, u32 n_list) 
   wave::sync_mem();
 }
 
+// fix_secondary needs the OTHER unit of the two LEFs of every list entry.  Without a complete
+// inverse permutation their ranks come from one sweep over the other direction's id array (four
+// ranks per lane) against a bitmap of the wanted ids in LDS: ws.f_rank (FWD_LIST false: entries of
+// the rev list) / ws.r_rank then hold valid entries for exactly those LEFs.
+template <bool FWD_LIST>
+MODLE_DEV_NOINLINE void lookup_partner_ranks(Cell& c, const u32* list, u32 n_list) {
+  if (c.inv_valid[FWD_LIST ? 0 : 1]) return;
+  Workspace& ws = c.ws;
+  const u32 n = wave::uniform(c.n_active);
+  const u32 lane = wave::lane();
+  const u32* own_ids = FWD_LIST ? ws.f_id : ws.r_id;
+  const u32* ids = FWD_LIST ? ws.r_id : ws.f_id;
+  u32* rank = FWD_LIST ? ws.r_rank : ws.f_rank;
+  rank_filter_clear(c, n);
+  for (u32 base = 0; base < n_list; base += 64) {
+    const u32 q = base + lane;
+    const bool act = q < n_list;
+    const u32 i = wave::ld_sel(list, q, act, 1u);
+    // (entries touch the slots {i-1, i} of the rev order / {i, i+1} of the fwd order)
+    const u32 a = wave::ld_sel(own_ids, FWD_LIST ? i : i - 1, act, 0u);
+    const u32 b = wave::ld_sel(own_ids, FWD_LIST ? i + 1 : i, act, 0u);
+    rank_filter_add_ids(c, a, act);
+    rank_filter_add_ids(c, b, act);
+  }
+  wave::sync_lds();
+  const u32 nblk = (n + 255) / 256;
+  wave::U32x4 cur = wave::ld4(ids, 4 * lane < n ? 4 * lane : 0u);
+  for (u32 t = 0; t < nblk; ++t) {
+    const wave::U32x4 I = cur;
+    if (t + 1 < nblk) {
+      const u32 wn = 256 * (t + 1) + 4 * lane;
+      cur = wave::ld4(ids, wn < n ? wn : 0u);
+    }
+    const u32 w = 256 * t + 4 * lane;
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+      if (w + q < n && rank_filter_test(c, I.v[q])) rank[I.v[q]] = w + q;
+    }
+  }
+  wave::sync_mem();
+}
+
 // returns false when an internal capacity was exceeded (the cell is then flagged as failed)
 MODLE_DEV bool phase_process_collisions(Cell& c) {
   BoundaryCounts bc;
@@ -3189,8 +3318,15 @@ MODLE_DEV bool phase_process_collisions(Cell& c) {
         nf = process_secondary<true>(c, bc, list_fwd, cap, overflow, true, true));
   if (overflow) c.error = ERR_LIST_OVERFLOW;
   if (c.error != 0) return false;
-  PHASE(c, 12, if (nr != 0) fix_secondary_rev(c, list_rev, nr);
-        if (nf != 0) fix_secondary_fwd(c, list_fwd, nf));
+  // (the rev fix re-orders rev units: the ranks the fwd fix needs are looked up after it)
+  PHASE(c, 12, if (nr != 0) {
+          lookup_partner_ranks<false>(c, list_rev, nr);
+          fix_secondary_rev(c, list_rev, nr);
+        }
+        if (nf != 0) {
+          lookup_partner_ranks<true>(c, list_fwd, nf);
+          fix_secondary_fwd(c, list_fwd, nf);
+        });
   return true;
 }
 
@@ -3203,13 +3339,58 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
   const f64 base_p = burnin_completed ? p.p_release : p.p_release_burnin;
-  // extrude in rank order, four consecutive ranks per lane (128-bit accesses; rev and fwd units of
-  // the same ranks in one step: their loads are independent); units stalled by a barrier that
-  // blocks their own direction ("hard" stalls) are reported to their LEF through stall[id].  The
-  // collision words are consumed here, so they are cleared on the way (the next epoch starts with
-  // clean arrays).  The loads of the next block are issued before the stores of the current one: a
-  // wait for a load also waits for every store issued before it.
+  const f64 affinity_soft = 1.0 / p.soft_stall_mult, affinity_hard = 1.0 / p.hard_stall_mult;
   const u32 nblk = (n + 255) / 256;
+  // release_lefs draws one Bernoulli per bound LEF in LEF-id order, with a probability that
+  // depends on how many of the LEF's two units are stalled by a barrier blocking their own
+  // direction ("hard" stalls: 0, 1 or 2).  Every active LEF is bound at this point of the epoch, so
+  // when none of the three probabilities is 0 (a zero probability consumes no draw) the draw of
+  // LEF i is the raw at (stream position) + i whatever the stalls are: the three possible outcomes
+  // of every LEF are evaluated FIRST, from the stream alone, and only the LEFs that are released
+  // under at least one of them (a few per cent: the candidates) need their stall count.  The
+  // extrusion sweep below, which passes over the ids of all units anyway, reports rank and hard
+  // stall of the candidates' units (ws.r_rank / ws.f_rank, bit 31 = hard stall), found with a
+  // bitmap of the candidate ids in LDS.  No per-LEF stall counters, no sweep over the LEFs, and the
+  // ranks of the released LEFs -- all that select_and_bind_lefs needs in the next epoch -- come out
+  // of it as well.
+  const f64 prob_by_stalls[3] = {1.0 * base_p, affinity_soft * base_p, affinity_hard * base_p};
+  const bool fast = prob_by_stalls[0] != 0.0 && prob_by_stalls[1] != 0.0 && prob_by_stalls[2] != 0.0;
+  u32* cand = ws.tmp[2];  // candidates in id order: id | outcomes << 24 (bit s: released with s stalls)
+  u32 n_cand = 0;
+  if (fast) {
+    const f64 thr0 = wave::uniform(prob_by_stalls[0] * TWO64), thr1 = wave::uniform(prob_by_stalls[1] * TWO64),
+              thr2 = wave::uniform(prob_by_stalls[2] * TWO64);
+    rank_filter_clear(c, n);
+    for (u32 t = 0; t < nblk; ++t) {
+      const u32 first = 256 * t;
+      const u32 cnt = umin(256u, n - first);
+      rng_ensure(c.g, cnt);
+#pragma unroll
+      for (u32 q = 0; q < 4; ++q) {
+        if (first + 64 * q >= n) break;
+        const u32 i = first + 64 * q + lane;
+        const u64 raw = rng_peek(c.g, c.g.pos + 64 * q + lane);
+        u32 code = 0;
+        if (i < n) {
+          const f64 x = static_cast<f64>(raw);  // bernoulli_raw with the products kept in scalar registers
+          code = (x <= thr0 ? 1u : 0u) | (x <= thr1 ? 2u : 0u) | (x <= thr2 ? 4u : 0u);
+        }
+        const u64 m = wave::ballot(code != 0);
+        if (m != 0) {
+          rank_filter_add_mask(c, first + 64 * q, m);
+          if (code != 0) cand[n_cand + static_cast<u32>(wave::popc64(m & lanemask_lt(lane)))] = i | (code << 24);
+          n_cand += static_cast<u32>(wave::popc64(m));
+        }
+      }
+      rng_advance(c.g, cnt);
+    }
+    wave::sync_lds();
+  }
+  // extrude in rank order, four consecutive ranks per lane (128-bit accesses; rev and fwd units of
+  // the same ranks in one step: their loads are independent).  The collision words are consumed
+  // here, so they are cleared on the way (the next epoch starts with clean arrays).  The loads of
+  // the next block are issued before the stores of the current one: a wait for a load also waits
+  // for every store issued before it.
   struct UnitRegs {
     wave::U32x4 rP, rM, rc, rI, fP, fM, fc, fI;
   };
@@ -3243,10 +3424,16 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
           nf.v[q] = fb ? g.fP.v[q] + g.fM.v[q] : g.fP.v[q];
           rc_any = rc_any || (act && g.rc.v[q] != 0);
           fc_any = fc_any || (act && g.fc.v[q] != 0);
-          if (rb && cw_occurred_as(g.rc.v[q], EV_LEF_BAR) && (g.rc.v[q] & CW_HARD))
-            wave::atomic_inc_u32(&ws.stall[g.rI.v[q]]);
-          if (fb && cw_occurred_as(g.fc.v[q], EV_LEF_BAR) && (g.fc.v[q] & CW_HARD))
-            wave::atomic_inc_u32(&ws.stall[g.fI.v[q]]);
+          const bool r_hard = rb && cw_occurred_as(g.rc.v[q], EV_LEF_BAR) && (g.rc.v[q] & CW_HARD);
+          const bool f_hard = fb && cw_occurred_as(g.fc.v[q], EV_LEF_BAR) && (g.fc.v[q] & CW_HARD);
+          if (fast) {
+            if (act && rank_filter_test(c, g.rI.v[q])) ws.r_rank[g.rI.v[q]] = (w + q) | (r_hard ? RANK_HARD : 0u);
+            if (act && rank_filter_test(c, g.fI.v[q])) ws.f_rank[g.fI.v[q]] = (w + q) | (f_hard ? RANK_HARD : 0u);
+          } else {
+            // general form: hard stalls are counted per LEF (the sweep over the LEFs below reads them)
+            if (r_hard) wave::atomic_inc_u32(&ws.stall[g.rI.v[q]]);
+            if (f_hard) wave::atomic_inc_u32(&ws.stall[g.fI.v[q]]);
+          }
         }
         if (w + 3 < n) {
           wave::st4(ws.r_pos, w, nr);
@@ -3269,12 +3456,48 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
     }
   }
   wave::sync_mem();
-  const f64 affinity_soft = 1.0 / p.soft_stall_mult, affinity_hard = 1.0 / p.hard_stall_mult;
-  // Release draws in LEF-id order, four consecutive ids per lane: the draw of a LEF is the raw at
-  // (stream position) + (bound LEFs with a non-zero probability before it).  The released LEFs (a
-  // few per cent) are listed in LDS; their units are marked afterwards from the list (the only
-  // place their ranks are needed), and the next epoch's select_and_bind_lefs binds from the same
-  // list.
+  u32* list = reinterpret_cast<u32*>(c.lds.sort_lds);
+  u32 n_rel = 0;
+  if (fast) {
+    // the candidates whose outcome for their number of stalls is "released", in id order: listed
+    // in LDS for the next epoch's select_and_bind_lefs, units and binding epoch marked
+    wave::lockstep();
+    for (u32 base = 0; base < n_cand; base += 64) {
+      const u32 e = base + lane;
+      const bool act = e < n_cand;
+      const u32 cw = wave::ld_sel(cand, e, act, 0u);
+      const u32 id = cw & 0x00FFFFFFu;
+      const u32 rw = wave::ld_sel(ws.r_rank, id, act, 0u), fw = wave::ld_sel(ws.f_rank, id, act, 0u);
+      const u32 stalls = (rw >> 31) + (fw >> 31);
+      const bool rel = act && (((cw >> 24) >> stalls) & 1u) != 0;
+      const u64 rm = wave::ballot(rel);
+      const u32 kr = rw & ~RANK_HARD, kf = fw & ~RANK_HARD;
+      if (act) {
+        // (without the stall flag: the entries stay valid ranks -- the next bind reads those of the
+        // released LEFs, and a complete inverse permutation stays complete)
+        ws.r_rank[id] = kr;
+        ws.f_rank[id] = kf;
+      }
+      if (rel) {
+        const u32 j = n_rel + static_cast<u32>(wave::popc64(rm & lanemask_lt(lane)));
+        if (j < REL_CAP) list[j] = id;
+        ws.epoch[id] = UNBOUND;
+        ws.r_pos[kr] = UNBOUND;
+        ws.f_pos[kf] = UNBOUND;
+      }
+      n_rel += static_cast<u32>(wave::popc64(rm));
+    }
+    wave::sync_lds();
+    c.rel_valid = n_rel <= REL_CAP;
+    c.n_rel = c.rel_valid ? n_rel : 0;
+    wave::sync_mem();
+    return;
+  }
+  // General form (a release probability of zero): draws in LEF-id order, four consecutive ids per
+  // lane: the draw of a LEF is the raw at (stream position) + (bound LEFs with a non-zero
+  // probability before it).  The released LEFs are listed in LDS; their units are marked afterwards
+  // from the list, and the next epoch's select_and_bind_lefs binds from the same list.
+  ensure_inverse_both(c);
   struct LefRegs {
     wave::U32x4 E, H;
   };
@@ -3284,8 +3507,6 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
     r.E = wave::ld4(ws.epoch, wq);
     r.H = wave::ld4(ws.stall, wq);
   };
-  u32* list = reinterpret_cast<u32*>(c.lds.sort_lds);
-  u32 n_rel = 0;
   wave::lockstep();
   LefRegs lcur;
   load_lefs(0, lcur);
@@ -3580,6 +3801,7 @@ MODLE_DEV u64 phase_sample_contacts(Cell& c, u64 events_per_epoch, u64 num_targe
   if (p.target_contact_density > 0.0)
     n_events = umin64(n_events, num_target_contacts - num_contacts);
   if (n_events == 0) return 0;
+  ensure_inverse_both(c);  // events pick LEFs by id
   events_done += n_events;
   u64 n_loop;
   if (p.tad_to_loop_ratio == 0) {
@@ -3826,6 +4048,8 @@ MODLE_DEV void init_cell(Cell& c, const Params& p, const Interval& iv, const Wor
   c.keys_valid = false;
   c.n_keys = 0;
   c.n_bound = 0;
+  c.inv_valid[0] = true;  // (reset_cell_buffers / run_test_phases write complete permutations)
+  c.inv_valid[1] = true;
 #ifdef MODLE_PHASE_TIMERS
   for (int i = 0; i < 16; ++i) c.ph[i] = 0;
 #endif
@@ -4038,33 +4262,9 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
       status = c.error;
       break;
     }
-#ifdef MODLE_TRACE
-    if (wave::lane() == 0 && getenv("MO_TRACE_EPOCH") &&
-        static_cast<u64>(atoll(getenv("MO_TRACE_EPOCH"))) == epoch) {
-      for (u32 i = 0; i < c.n_active; ++i) {
-        const u32 kr = c.ws.r_rank[i], kf = c.ws.f_rank[i];
-        fprintf(stderr, "D %u %u %u %u %u %u:%u %u:%u\n", i, c.ws.r_pos[kr], c.ws.f_pos[kf],
-                c.ws.r_move[kr], c.ws.f_move[kf], cw_event(c.ws.r_coll[kr]),
-                cw_index(c.ws.r_coll[kr]), cw_event(c.ws.f_coll[kf]), cw_index(c.ws.f_coll[kf]));
-      }
-    }
-#endif
     log_internal_state(c, epoch, !burnin_completed);
     PHASE(c, 13, phase_extrude_and_release(c, burnin_completed));
     trace_stage(c, epoch, 4);
-#ifdef MODLE_TRACE
-    {
-      u64 sr = 0, sf = 0;
-      for (u32 i = 0; i < c.n_active; ++i) {
-        sr += c.ws.r_pos[i];
-        sf += c.ws.f_pos[i];
-      }
-      if (wave::lane() == 0 && getenv("MO_TRACE"))
-        fprintf(stderr, "T %llu %llu %llu %llu %u %llu\n", (unsigned long long)epoch,
-                (unsigned long long)c.g.pos, (unsigned long long)sr, (unsigned long long)sf,
-                c.n_active, (unsigned long long)num_contacts);
-    }
-#endif
   }
 
   trace_stage(c, epoch, 6);

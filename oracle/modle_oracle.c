@@ -19,13 +19,6 @@
  * depends on them is identical on both sides by construction; sqrt is IEEE-exact everywhere. */
 #include "../modle_amd/csrc/modle_math.h"
 
-/* debugging aid: MO_TRACE=1 prints one line per epoch (epoch, raws drawn, position sums) */
-static int mo_trace_enabled(void) {
-  static int v = -1;
-  if (v < 0) v = getenv("MO_TRACE") != NULL;
-  return v;
-}
-
 #define MIN(a, b) ((a) < (b) ? (a) : (b))
 #define MAX(a, b) ((a) > (b) ? (a) : (b))
 
@@ -1136,13 +1129,6 @@ void mo_fix_secondary_lef_lef_collisions(uint64_t start, uint64_t end, size_t n,
     const uint64_t idx1 = fwd_rank[i];
     if (coll_avoided_as(fwd_coll[idx1], sec)) {
       const uint64_t idx2 = fwd_rank[i + 1];
-      if (getenv("MO_TRACE_FIX"))
-        fprintf(stderr, "FIXF i=%zu idx1=%u idx2=%u c1=%x c2=%x p1=%u p2=%u m1=%u m2=%u\n", i,
-                (unsigned)idx1, (unsigned)idx2,
-                (unsigned)((fwd_coll[idx1] >> 32) | (fwd_coll[idx1] & 0xFFFFFF)),
-                (unsigned)((fwd_coll[idx2] >> 32) | (fwd_coll[idx2] & 0xFFFFFF)),
-                (unsigned)fwd_pos[idx1], (unsigned)fwd_pos[idx2], (unsigned)fwd_moves[idx1],
-                (unsigned)fwd_moves[idx2]);
       const uint64_t pos2 = fwd_pos[idx2] + fwd_moves[idx2];
       if (pos2 > fwd_pos[idx1] + 1) {
         fwd_moves[idx1] = pos2 - (fwd_pos[idx1] + 1);
@@ -1701,14 +1687,6 @@ static int simulate_cell_sorted(const mo_params_t* p, uint64_t start, uint64_t e
     mo_process_collisions(p, start, end, n, s.rev_pos, s.fwd_pos, s.epoch, s.rev_rank, s.fwd_rank,
                           s.rev_moves, s.fwd_moves, nb, bar_pos, bar_dir, s.bar_active, s.rev_coll,
                           s.fwd_coll, &s.g, 1);
-    if (mo_trace_enabled() && getenv("MO_TRACE_EPOCH") &&
-        (uint64_t)atoll(getenv("MO_TRACE_EPOCH")) == epoch) {
-      for (size_t i = 0; i < n; ++i)
-        fprintf(stderr, "D %zu %u %u %u %u %u:%u %u:%u\n", i, (uint32_t)s.rev_pos[i],
-                (uint32_t)s.fwd_pos[i], (uint32_t)s.rev_moves[i], (uint32_t)s.fwd_moves[i],
-                (unsigned)(s.rev_coll[i] >> 56), (unsigned)(s.rev_coll[i] & 0xFFFFFF),
-                (unsigned)(s.fwd_coll[i] >> 56), (unsigned)(s.fwd_coll[i] & 0xFFFFFF));
-    }
     /* extrude (simulation.cpp:498-521) */
     for (size_t i = 0; i < n; ++i) {
       if (!bound(s.epoch, i)) continue;
@@ -1718,16 +1696,6 @@ static int simulate_cell_sorted(const mo_params_t* p, uint64_t start, uint64_t e
     dump_stats(epoch, !burnin_completed, n, s.rev_pos, s.fwd_pos, s.epoch, s.rev_coll, s.fwd_coll, nb,
                s.bar_active);
     release_lefs(&s, burnin_completed);
-    if (mo_trace_enabled()) {
-      uint64_t sr = 0, sf = 0;
-      for (size_t i = 0; i < n; ++i) {
-        sr += (uint32_t)s.rev_pos[i];
-        sf += (uint32_t)s.fwd_pos[i];
-      }
-      fprintf(stderr, "T %llu %llu %llu %llu %zu %llu\n", (unsigned long long)epoch,
-              (unsigned long long)s.g.count, (unsigned long long)sr, (unsigned long long)sf, n,
-              (unsigned long long)num_contacts);
-    }
   }
 
   if (res) {
