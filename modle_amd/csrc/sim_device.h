@@ -42,6 +42,9 @@ struct Cell {
   // from sweeps that pass over the id arrays anyway (RankFilter below), everything else
   // (contact sampling, the general rank update, the phase-level hooks) calls ensure_inverse.
   bool inv_valid[2];
+  // the secondary pass collects the LEFs of its avoided collisions in the LDS id filter (for the
+  // rank lookups of fix_secondary)
+  bool filter_on;
 #ifdef MODLE_PHASE_TIMERS
   u64 ph[16];     // profiling build: time spent per phase (wave::clock ticks)
 #endif
@@ -139,17 +142,10 @@ MODLE_DEV void rank_filter_add_mask(Cell& c, u32 first, u64 members) {
   u64* bm = c.lds.sort_lds;
   if (wave::lane() == 0) bm[(first / 64) % RANK_FILTER_WORDS] |= members;
 }
-// adds one id per lane (where `valid`)
-MODLE_DEV void rank_filter_add_ids(Cell& c, u32 id, bool valid) {
+// adds the id of the calling lane (any subset of the lanes may call)
+MODLE_DEV void rank_filter_add_id(Cell& c, u32 id) {
   u32* bm = reinterpret_cast<u32*>(c.lds.sort_lds);
-  const u32 lane = wave::lane();
-  u64 m = wave::ballot(valid);
-  while (m != 0) {
-    const u32 l = static_cast<u32>(wave::ctz64(m));
-    m &= m - 1;
-    const u32 x = wave::bcast(id, l);
-    if (lane == 0) bm[(x % RANK_FILTER_BITS) >> 5] |= 1u << (x & 31u);
-  }
+  wave::lds_or_u32(&bm[(id % RANK_FILTER_BITS) >> 5], 1u << (id & 31u));
 }
 MODLE_DEV bool rank_filter_test(const Cell& c, u32 id) {
   const u32* bm = reinterpret_cast<const u32*>(c.lds.sort_lds);
@@ -3026,6 +3022,10 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
             if (lane == a) {
               C = cw_make(bId, EV_LEF_LEF_SECONDARY);
               if (n_list < list_cap) list[n_list] = k;
+              if (c.filter_on) {
+                rank_filter_add_id(c, id);
+                rank_filter_add_id(c, bId);
+              }
             }
             ++n_list;
             if (n_list > list_cap) overflow = true;
@@ -3079,6 +3079,10 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
           C = cw_make(bId, EV_LEF_LEF_SECONDARY);
           const u32 j = n_list + static_cast<u32>(wave::popc64(am & lanemask_lt(lane)));
           if (j < list_cap) list[j] = k;
+          if (c.filter_on) {
+            rank_filter_add_id(c, id);
+            rank_filter_add_id(c, bId);
+          }
         }
         n_list += static_cast<u32>(wave::popc64(am));
         if (n_list > list_cap) overflow = true;
@@ -3260,43 +3264,40 @@ MODLE_DEV_NOINLINE void fix_secondary_fwd(Cell& c, const u32* list, u32 n_list) 
   wave::sync_mem();
 }
 
-// fix_secondary needs the OTHER unit of the two LEFs of every list entry.  Without a complete
-// inverse permutation their ranks come from one sweep over the other direction's id array (four
-// ranks per lane) against a bitmap of the wanted ids in LDS: ws.f_rank (FWD_LIST false: entries of
-// the rev list) / ws.r_rank then hold valid entries for exactly those LEFs.
-template <bool FWD_LIST>
-MODLE_DEV_NOINLINE void lookup_partner_ranks(Cell& c, const u32* list, u32 n_list) {
-  if (c.inv_valid[FWD_LIST ? 0 : 1]) return;
+// fix_secondary needs the OTHER unit of the two LEFs of every list entry: entries of the rev list
+// the fwd units, entries of the fwd list the rev units.  Without a complete inverse permutation
+// their ranks come from ONE sweep over both id arrays (four ranks per lane, four blocks of loads in
+// flight per direction) against the bitmap of LEF ids the secondary pass has collected in LDS:
+// ws.r_rank / ws.f_rank then hold valid entries for those LEFs.  (The rev fix re-orders rev units
+// before the fwd fix looks at them, but it updates ws.r_rank for every unit it moves; the ids on
+// the slots a cascade of fixes touches are the ids of its entries, whatever their order.)
+MODLE_DEV_NOINLINE void lookup_partner_ranks(Cell& c, bool want_r, bool want_f) {
+  want_r = want_r && !c.inv_valid[0];
+  want_f = want_f && !c.inv_valid[1];
+  if (!want_f && !want_r) return;
   Workspace& ws = c.ws;
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
-  const u32* own_ids = FWD_LIST ? ws.f_id : ws.r_id;
-  const u32* ids = FWD_LIST ? ws.r_id : ws.f_id;
-  u32* rank = FWD_LIST ? ws.r_rank : ws.f_rank;
-  rank_filter_clear(c, n);
-  for (u32 base = 0; base < n_list; base += 64) {
-    const u32 q = base + lane;
-    const bool act = q < n_list;
-    const u32 i = wave::ld_sel(list, q, act, 1u);
-    // (entries touch the slots {i-1, i} of the rev order / {i, i+1} of the fwd order)
-    const u32 a = wave::ld_sel(own_ids, FWD_LIST ? i : i - 1, act, 0u);
-    const u32 b = wave::ld_sel(own_ids, FWD_LIST ? i + 1 : i, act, 0u);
-    rank_filter_add_ids(c, a, act);
-    rank_filter_add_ids(c, b, act);
-  }
   wave::sync_lds();
+  constexpr u32 GB = 4;  // blocks of 256 ranks per group of loads
   const u32 nblk = (n + 255) / 256;
-  wave::U32x4 cur = wave::ld4(ids, 4 * lane < n ? 4 * lane : 0u);
-  for (u32 t = 0; t < nblk; ++t) {
-    const wave::U32x4 I = cur;
-    if (t + 1 < nblk) {
-      const u32 wn = 256 * (t + 1) + 4 * lane;
-      cur = wave::ld4(ids, wn < n ? wn : 0u);
-    }
-    const u32 w = 256 * t + 4 * lane;
+  for (u32 t0 = 0; t0 < nblk; t0 += GB) {
+    wave::U32x4 R[GB], F[GB];
 #pragma unroll
-    for (u32 q = 0; q < 4; ++q) {
-      if (w + q < n && rank_filter_test(c, I.v[q])) rank[I.v[q]] = w + q;
+    for (u32 g = 0; g < GB; ++g) {
+      const u32 w = 256 * (t0 + g) + 4 * lane;
+      R[g] = wave::ld4(ws.r_id, (want_r && w < n) ? w : 0u);
+      F[g] = wave::ld4(ws.f_id, (want_f && w < n) ? w : 0u);
+    }
+#pragma unroll
+    for (u32 g = 0; g < GB; ++g) {
+      const u32 w = 256 * (t0 + g) + 4 * lane;
+#pragma unroll
+      for (u32 q = 0; q < 4; ++q) {
+        const bool in = w + q < n;
+        if (want_r && in && rank_filter_test(c, R[g].v[q])) ws.r_rank[R[g].v[q]] = w + q;
+        if (want_f && in && rank_filter_test(c, F[g].v[q])) ws.f_rank[F[g].v[q]] = w + q;
+      }
     }
   }
   wave::sync_mem();
@@ -3314,19 +3315,17 @@ MODLE_DEV bool phase_process_collisions(Cell& c) {
   u32* list_fwd = c.ws.tmp[6];
   const u32 cap = c.ws.capacity_lefs;
   u32 nr = 0, nf = 0;
+  // (the LDS sort buffer is idle from here to the release: it holds the id filter)
+  c.filter_on = !(c.inv_valid[0] && c.inv_valid[1]);
+  if (c.filter_on) rank_filter_clear(c, c.n_active);
   PHASE(c, 11, nr = process_secondary<false>(c, bc, list_rev, cap, overflow, true, true);
         nf = process_secondary<true>(c, bc, list_fwd, cap, overflow, true, true));
+  c.filter_on = false;
   if (overflow) c.error = ERR_LIST_OVERFLOW;
   if (c.error != 0) return false;
-  // (the rev fix re-orders rev units: the ranks the fwd fix needs are looked up after it)
-  PHASE(c, 12, if (nr != 0) {
-          lookup_partner_ranks<false>(c, list_rev, nr);
-          fix_secondary_rev(c, list_rev, nr);
-        }
-        if (nf != 0) {
-          lookup_partner_ranks<true>(c, list_fwd, nf);
-          fix_secondary_fwd(c, list_fwd, nf);
-        });
+  PHASE(c, 12, if ((nr | nf) != 0) lookup_partner_ranks(c, nf != 0, nr != 0);
+        if (nr != 0) fix_secondary_rev(c, list_rev, nr);
+        if (nf != 0) fix_secondary_fwd(c, list_fwd, nf));
   return true;
 }
 
@@ -4050,6 +4049,7 @@ MODLE_DEV void init_cell(Cell& c, const Params& p, const Interval& iv, const Wor
   c.n_bound = 0;
   c.inv_valid[0] = true;  // (reset_cell_buffers / run_test_phases write complete permutations)
   c.inv_valid[1] = true;
+  c.filter_on = false;
 #ifdef MODLE_PHASE_TIMERS
   for (int i = 0; i < 16; ++i) c.ph[i] = 0;
 #endif
