@@ -3405,12 +3405,7 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
     r.fc = wave::ld4(ws.f_coll, wq);
     r.fI = wave::ld4(ws.f_id, wq);
   };
-  {
-    UnitRegs cur;
-    load_units(0, cur);
-    for (u32 t = 0; t < nblk; ++t) {
-      const UnitRegs g = cur;
-      if (t + 1 < nblk) load_units(t + 1, cur);
+  const auto process_block = [&](const UnitRegs& g, u32 t) {
       const u32 w = 256 * t + 4 * lane;
       if (w < n) {
         wave::U32x4 nr, nf;
@@ -3451,6 +3446,24 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
             }
           }
         }
+      }
+  };
+  {
+    // two blocks of loads in flight: the sweep is bound by the latency of its loads, not by what it
+    // does with them
+    UnitRegs ra, rb;
+    load_units(0, ra);
+    if (1 < nblk) load_units(1, rb);
+    for (u32 t = 0; t < nblk; t += 2) {
+      {
+        const UnitRegs g = ra;
+        if (t + 2 < nblk) load_units(t + 2, ra);
+        process_block(g, t);
+      }
+      if (t + 1 < nblk) {
+        const UnitRegs g = rb;
+        if (t + 3 < nblk) load_units(t + 3, rb);
+        process_block(g, t + 1);
       }
     }
   }

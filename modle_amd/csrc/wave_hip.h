@@ -205,12 +205,25 @@ MODLE_DEV T known_uniform(T v) { return uniform(v); }
 struct alignas(8) U32x2 {
   uint32_t v[2];
 };
-MODLE_DEV U32x2 ld2(const uint32_t* p, uint32_t k) { return *reinterpret_cast<const U32x2*>(p + k); }
+// (Element k of an array is addressed as base + a 32-BIT byte offset: written `p[k]` the byte offset
+// is a 64-bit value -- k * sizeof(T) may exceed 2^32 for all the compiler knows -- and every access
+// costs a 64-bit shift-and-add into a pair of address registers; with the 32-bit offset the
+// instruction takes the scalar base and one offset register that all the arrays of a sweep share.
+// Arrays of the workspace hold at most 2^24 elements of 8 bytes.)
+template <class T>
+MODLE_DEV const T* at(const T* p, uint32_t k) {
+  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + static_cast<uint32_t>(k * static_cast<uint32_t>(sizeof(T))));
+}
+template <class T>
+MODLE_DEV T* at(T* p, uint32_t k) {
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(p) + static_cast<uint32_t>(k * static_cast<uint32_t>(sizeof(T))));
+}
+MODLE_DEV U32x2 ld2(const uint32_t* p, uint32_t k) { return *reinterpret_cast<const U32x2*>(at(p, k)); }
 struct alignas(16) U32x4 {
   uint32_t v[4];
 };
-MODLE_DEV U32x4 ld4(const uint32_t* p, uint32_t k) { return *reinterpret_cast<const U32x4*>(p + k); }
-MODLE_DEV void st4(uint32_t* p, uint32_t k, const U32x4& x) { *reinterpret_cast<U32x4*>(p + k) = x; }
+MODLE_DEV U32x4 ld4(const uint32_t* p, uint32_t k) { return *reinterpret_cast<const U32x4*>(at(p, k)); }
+MODLE_DEV void st4(uint32_t* p, uint32_t k, const U32x4& x) { *reinterpret_cast<U32x4*>(at(p, k)) = x; }
 // The two halves of ld_sel for loads that are requested one group ahead of their use: LdRaw at
 // the request (no select, hence no wait, behind the load), LdMask where the values are consumed.
 // A loader written as `r.x = op(p, k, ok, dflt, r.x)` serves both.
@@ -218,7 +231,7 @@ struct LdRaw {
   template <class T, class D>
   MODLE_DEV T operator()(const T* p, uint32_t k, bool ok, D dflt, T) const {
     (void)dflt;
-    return ld_stream(p + (ok ? k : 0u));
+    return ld_stream(at(p, ok ? k : 0u));
   }
 };
 struct LdMask {
@@ -229,7 +242,7 @@ struct LdMask {
 };
 template <class T, class D>
 MODLE_DEV T ld_sel(const T* p, uint32_t k, bool ok, D dflt) {
-  const T v = ld_stream(p + (ok ? k : 0u));
+  const T v = ld_stream(at(p, ok ? k : 0u));
   return ok ? v : static_cast<T>(dflt);
 }
 // word written by another agent (the host) while the kernel runs: bypasses this CU's L1
