@@ -65,6 +65,15 @@ def parse_args():
                     help="exact: the reference's xoshiro256++ stream (default, every parity claim); "
                          "philox: the counter-based generator policy, a separate line that is not "
                          "bit-comparable with the reference")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl (= RCCL, default): the matrices are reduced on the GPUs over xGMI.  gloo: "
+                         "the same per-interval ordering with the reduce done on host copies -- for "
+                         "rehearsing the N > 1 path with several ranks on ONE GPU (tests)")
+    ap.add_argument("--checksum-out", default=None,
+                    help="rank 0 writes {interval: [sum, position-weighted sum]} of the final (reduced) "
+                         "matrices and occupancy tracks of the last step to this JSON file")
+    ap.add_argument("--poll-timeout", type=float, default=1800.0,
+                    help="seconds to wait for an interval of the launch in flight before giving up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=None)
     return ap.parse_args()
@@ -156,6 +165,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if args.dist_backend == "gloo":
+        local_rank %= torch.cuda.device_count()  # (rehearsal: the ranks may share a GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # under torch.distributed.run the RCCL path runs even with one rank (same code as N > 1)
@@ -163,7 +174,22 @@ def main():
     if use_dist:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+
+    coll_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # small collectives
+
+    def reduce_to_rank0(t):
+        """sum of the ranks' tensors into rank 0's (issued on the current stream)"""
+        if args.dist_backend == "nccl":
+            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+        else:
+            h = t.cpu()  # (synchronises the current stream: the interval's cells have finished)
+            dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                t.copy_(h)
 
     default_cells = 2048 if args.workload == "grch38" else 512
     if args.scaling == "strong":
@@ -247,14 +273,20 @@ def main():
             # Collectives must be issued in the same order on every rank: the order is fixed (the
             # launch order of the tasks, largest interval first, which is also roughly the order
             # in which the intervals complete) and each rank waits for the next interval in it.
+            deadline = time.monotonic() + args.poll_timeout
             for k in reduce_order:
                 while not sim.interval_done(ids[k]):
+                    if time.monotonic() > deadline:
+                        # a faulted kernel never counts its intervals down: fail instead of spinning
+                        # (the peers then fail in their collective instead of waiting for ever)
+                        raise SystemExit(f"rank {rank}: interval {plan[k]['interval']['name']} not "
+                                         f"finished after {args.poll_timeout:.0f} s")
                     time.sleep(0.0005)
                 with torch.cuda.stream(reduce_stream):
                     if last:
                         own_sums(k)
-                    dist.reduce(tensors[k][0], dst=0, op=dist.ReduceOp.SUM)
-                    dist.reduce(tensors[k][1], dst=0, op=dist.ReduceOp.SUM)
+                    reduce_to_rank0(tensors[k][0])
+                    reduce_to_rank0(tensors[k][1])
             sim.wait()
             stream.wait_stream(reduce_stream)
         else:
@@ -288,7 +320,7 @@ def main():
     if use_dist:
         import torch.distributed as dist
 
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -321,11 +353,26 @@ def main():
     if use_dist:
         import torch.distributed as dist
 
-        tot = torch.tensor([epochs, n_tasks], dtype=torch.int64, device=dev)
+        tot = torch.tensor([epochs, n_tasks], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(tot)
         job_epochs, job_tasks = int(tot[0].item()), int(tot[1].item())
     else:
         job_epochs, job_tasks = epochs, n_tasks
+
+    if rank == 0 and args.checksum_out:
+        sums = {}
+        for entry, t in zip(plan, tensors):
+            if t is None:
+                continue
+            iv = entry["interval"]
+            words = []
+            for x in t:
+                x64 = x.to(torch.int64)
+                weights = torch.arange(1, x64.numel() + 1, dtype=torch.int64, device=dev) % 1000003
+                words += [int(x64.sum().item()), int((x64 * weights).sum().item())]
+            sums[f"{iv['name']}:{iv['start']}-{iv['end']}"] = words
+        with open(args.checksum_out, "w") as f:
+            json.dump(sums, f)
 
     if rank == 0:
         out = {
@@ -353,8 +400,9 @@ def main():
                        "total_cells": total_cells, "tasks_per_gpu": n_tasks,
                        "cell_epochs_per_gpu_step": epochs,
                        "longest_cell_epochs": longest, "mean_cell_epochs": epochs / max(n_tasks, 1), "seed": 0,
-                       "parallelism": f"cells sharded over {world} GPU(s); per-interval RCCL sum-reduce "
-                                      "issued on a side stream as intervals complete"},
+                       "parallelism": f"cells sharded over {world} GPU(s); per-interval "
+                                      + ("RCCL" if args.dist_backend == "nccl" else "gloo (host copies)")
+                                      + " sum-reduce issued on a side stream as intervals complete"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(f"{args.workload}:{cells_per_gpu}"),

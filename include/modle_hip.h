@@ -289,6 +289,11 @@ int modle_hip_test_phases(modle_hip_handle* h, uint32_t phase_mask, uint64_t sta
  *                     comparison with the oracle's (both compile modle_amd/csrc/modle_math.h) */
 #define MODLE_HIP_UNIT_MATH_LOG_EXP 4u
 #define MODLE_HIP_UNIT_MATH_POW_SQRT 5u
+/*   PHILOX            two pairs per vector: (counter words 0..1 | 2..3 as two 64-bit values), (key
+ *                     words 0..1 as one 64-bit value, unused); out = the four output words of
+ *                     Philox4x32-10 as two 64-bit values, then two zeros -- the round function of the
+ *                     PHILOX generator policy, for the Random123 known-answer vectors */
+#define MODLE_HIP_UNIT_PHILOX 6u
 int modle_hip_test_units(modle_hip_handle* h, uint32_t what, const uint64_t* in, size_t n,
                          uint64_t nrows, uint64_t ncols, uint32_t* contacts,
                          uint64_t* missed_updates, uint64_t* out, char* err, size_t errlen);

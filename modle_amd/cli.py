@@ -28,6 +28,41 @@ STRATEGIES = {  # cli.hpp:63-72
 }
 
 
+_DISTANCE_UNITS = {"bp": 1, "k": 10**3, "kb": 10**3, "kbp": 10**3, "m": 10**6, "mb": 10**6,
+                   "mbp": 10**6, "g": 10**9, "gb": 10**9, "gbp": 10**9}  # cli_utils.hpp:86-96
+
+
+def genomic_distance(text):
+    """`20kb`, `1.5Mbp`, `3000000`: a number of base pairs with an optional unit, the reference's
+    AsGenomicDistance transform (src/common/cli_utils_impl.hpp:304-362; the unit is case
+    insensitive and the product must be a whole number)"""
+    k = len(text)
+    while k > 0 and text[k - 1].isalpha():
+        k -= 1
+    num, unit = text[:k], text[k:].lower()
+    if not num:
+        raise argparse.ArgumentTypeError(f"value {text} could not be converted")
+    if not unit:
+        try:
+            v = int(num)
+        except ValueError:
+            raise argparse.ArgumentTypeError(f"unable to convert {text} to a number")
+        if v < 0:
+            raise argparse.ArgumentTypeError(f"unable to convert {text} to a number")
+        return v
+    if unit not in _DISTANCE_UNITS:
+        raise argparse.ArgumentTypeError(f"{text[k:]} unit not recognized; valid units: "
+                                         + ", ".join(sorted(_DISTANCE_UNITS)))
+    try:
+        m = float(num) * _DISTANCE_UNITS[unit]
+    except ValueError:
+        raise argparse.ArgumentTypeError(f"unable to convert {num} to a number")
+    if m != int(m) or m < 0:
+        raise argparse.ArgumentTypeError(f"Unable to convert {text} to a number of base-pairs "
+                                         f"({m} is not an integral number)")
+    return int(m)
+
+
 def build_parser():
     ap = argparse.ArgumentParser(prog="modle_amd", description=__doc__,
                                  formatter_class=argparse.RawDescriptionHelpFormatter)
@@ -41,6 +76,7 @@ def build_parser():
     io.add_argument("-o", "--output-prefix", required=True)
     io.add_argument("--assembly-name", default="unknown")
     io.add_argument("-q", "--quiet", action="store_true")
+    io.add_argument("-v", "--verbose", action="store_true", help="accepted (the log is short anyway)")
     io.add_argument("--skip-output", action="store_true")
     io.add_argument("--log-model-internal-state", action="store_true",
                     help="write <prefix>_internal_state.log.gz: one line of statistics per task and "
@@ -54,22 +90,22 @@ def build_parser():
     g = p.add_argument_group("model parameters (reference names; omitted => reference default)")
     for flags, dest, typ in [
         (("--lef-density", "--lefs-per-mbp"), "number_of_lefs_per_mbp", float),
-        (("--avg-lef-processivity",), "avg_lef_processivity", int),
+        (("--avg-lef-processivity",), "avg_lef_processivity", genomic_distance),
         (("--probability-of-lef-bypass",), "probability_of_extrusion_unit_bypass", float),
         (("--extrusion-barrier-occupancy",), "extrusion_barrier_occupancy", float),
         (("--hard-stall-lef-stability-multiplier",), "hard_stall_lef_stability_multiplier", float),
         (("--soft-stall-lef-stability-multiplier",), "soft_stall_lef_stability_multiplier", float),
-        (("--fwd-extrusion-speed",), "fwd_extrusion_speed", int),
-        (("--rev-extrusion-speed",), "rev_extrusion_speed", int),
+        (("--fwd-extrusion-speed",), "fwd_extrusion_speed", genomic_distance),
+        (("--rev-extrusion-speed",), "rev_extrusion_speed", genomic_distance),
         (("--fwd-extrusion-speed-std",), "fwd_extrusion_speed_std", float),
         (("--rev-extrusion-speed-std",), "rev_extrusion_speed_std", float),
         (("--lef-bar-major-collision-prob",), "lef_bar_major_collision_pblock", float),
         (("--lef-bar-minor-collision-prob",), "lef_bar_minor_collision_pblock", float),
         (("--extrusion-barrier-bound-stp",), "barrier_occupied_stp", float),
         (("--extrusion-barrier-not-bound-stp",), "barrier_not_occupied_stp", float),
-        (("--contact-sampling-interval",), "contact_sampling_interval", int),
-        (("-r", "--resolution"), "bin_size", int),
-        (("-w", "--diagonal-width"), "diagonal_width", int),
+        (("--contact-sampling-interval",), "contact_sampling_interval", genomic_distance),
+        (("-r", "--resolution"), "bin_size", genomic_distance),
+        (("-w", "--diagonal-width"), "diagonal_width", genomic_distance),
         (("--tad-to-loop-contact-ratio",), "tad_to_loop_contact_ratio", float),
         (("--mu", "--genextr-location"), "genextreme_mu", float),
         (("--sigma", "--genextr-scale"), "genextreme_sigma", float),
@@ -84,7 +120,7 @@ def build_parser():
         (("--min-burnin-epochs",), "min_burnin_epochs", int),
         (("--max-burnin-epochs",), "max_burnin_epochs", int),
         (("--burnin-extr-speed-coefficient",), "burnin_speed_coefficient", float),
-        (("--probability-normalization-factor",), "probability_normalization_factor", int),
+        (("--probability-normalization-factor",), "probability_normalization_factor", genomic_distance),
     ]:
         g.add_argument(*flags, dest=dest, type=typ, default=None)
     g.add_argument("--contact-sampling-strategy", choices=sorted(STRATEGIES), default=None)
@@ -184,7 +220,9 @@ def simulate(a, log=print):
         dist.init_process_group("nccl", device_id=torch.device("cuda", device))
     sim = api.Simulator(cfg, device)
     try:
-        if a.log_model_internal_state:
+        if a.log_model_internal_state and not a.skip_output:
+            # (with --skip-output the log would not be written: nothing is recorded, and the
+            # default build of the library serves, like the reference accepts the combination)
             sim.enable_state_log(a.internal_state_max_epochs)
         ids = driver.enqueue_plan(sim, cfg, plan)
         n_tasks = sum(len(e["tasks"]) for e in plan if not e["skipped"])
@@ -238,7 +276,7 @@ def simulate(a, log=print):
                           sort_keys=True)
         driver.write_cooler(cool_path, cfg, plan, matrices, assembly=a.assembly_name,
                             generated_by="modle_amd (MI355X)", metadata_json=meta,
-                            force_overwrite=a.force)
+                            force_overwrite=a.force, chroms=chroms)
         log(f"written {cool_path}")
         if cfg.track_1d_lef_position:
             driver.write_bigwig(bw_path, cfg, plan, occupancies, chroms, force_overwrite=a.force)

@@ -15,6 +15,9 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -346,7 +349,12 @@ struct modle_hip_handle {
   u32* d_remaining = nullptr;
   size_t remaining_cap = 0;
   hipStream_t cancel_stream = nullptr;  // non-blocking: raises the abort word beside the kernel
-  bool cancelled = false;
+  // read / written by modle_hip_cancel and modle_hip_interval_done, which may run on another host
+  // thread than the one that launches and waits
+  std::atomic<bool> cancelled{false};
+  // orders the reset of the abort word at a launch against modle_hip_cancel raising it
+  std::mutex abort_mu;
+  bool timing_valid = false;  // both events of the last launch were recorded
   void* trace_host = nullptr;           // MODLE_HIP_TRACE_SHM mapping, registered once per handle
   size_t trace_bytes = 0;
   u64* trace_dev = nullptr;
@@ -358,7 +366,7 @@ struct modle_hip_handle {
   u32 state_log_cap = 0;  // epochs logged per task (0 = off)
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   hipStream_t stream = nullptr;
-  bool in_flight = false;
+  std::atomic<bool> in_flight{false};
   size_t n_launched = 0;
   std::vector<std::pair<int, size_t>> launch_map;  // launch task -> (interval, submission idx)
   float last_ms = 0.0f;
@@ -654,11 +662,9 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
   HIP_TRY(hipMemcpyAsync(h->d_tasks.p, sorted.data(), sorted.size() * sizeof(Task),
                          hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemsetAsync(h->d_counter.p, 0, 4, h->stream));
-  HIP_TRY(hipMemsetAsync(h->d_abort.p, 0, 4, h->stream));
   HIP_TRY(hipMemsetAsync(h->d_status.p, 0xFF, sorted.size() * 4, h->stream));
   // the source vectors must outlive the async copies
   HIP_TRY(hipStreamSynchronize(h->stream));
-  h->cancelled = false;
 
   SimArgs a;
   a.params = h->params;
@@ -729,24 +735,38 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
     const int v = std::atoi(aw);
     if (v >= 1 && v <= kWavesPerBlock) a.active_waves = static_cast<u32>(v);
   }
-  HIP_TRY(hipEventRecord(h->ev_start, h->stream));
-  hipLaunchKernelGGL(modle_simulate_cells, dim3(grid), dim3(kThreadsPerBlock), 0, h->stream, a);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
-  // enqueued: commit the bookkeeping
-  for (auto& recp : h->intervals) {
-    IntervalRec& rec = *recp;
-    rec.results.resize(rec.results.size() + rec.pending.size());
-    rec.pending.clear();
+  {
+    // The abort word is cleared, the kernel enqueued and the launch marked as in flight under the
+    // lock modle_hip_cancel takes: a cancel from another thread either finds nothing in flight
+    // (it came before this launch) or raises the word after the reset -- never in between, where
+    // the reset would swallow it.
+    std::lock_guard<std::mutex> lock(h->abort_mu);
+    HIP_TRY(hipMemsetAsync(h->d_abort.p, 0, 4, h->stream));
+    h->cancelled = false;
+    const bool ev0 = hipEventRecord(h->ev_start, h->stream) == hipSuccess;
+    hipLaunchKernelGGL(modle_simulate_cells, dim3(grid), dim3(kThreadsPerBlock), 0, h->stream, a);
+    HIP_TRY(hipGetLastError());
+    // The kernel is enqueued: commit the bookkeeping NOW.  Nothing after this point may make the
+    // call fail -- a caller that sees an error retries, and the same tasks would then be simulated
+    // twice into the same matrices.  A failed event record only costs the timing of this launch.
+    for (auto& recp : h->intervals) {
+      IntervalRec& rec = *recp;
+      rec.results.resize(rec.results.size() + rec.pending.size());
+      rec.pending.clear();
+    }
+    h->launch_map.swap(sorted_map);
+    h->n_launched = sorted.size();
+    h->in_flight = true;
+    const bool ev1 = hipEventRecord(h->ev_stop, h->stream) == hipSuccess;
+    h->timing_valid = ev0 && ev1;
+    if (!h->timing_valid) (void)hipGetLastError();  // (clears the sticky error of the failed record)
   }
-  h->launch_map.swap(sorted_map);
-  h->n_launched = sorted.size();
-  h->in_flight = true;
   return MODLE_HIP_OK;
 }
 
 int modle_hip_cancel(modle_hip_handle* h, char* err, size_t errlen) {
   if (h == nullptr) return MODLE_HIP_ERR_ARG;
+  std::lock_guard<std::mutex> lock(h->abort_mu);
   if (!h->in_flight) return MODLE_HIP_OK;
   HIP_TRY(hipSetDevice(h->device));
   // every wave reads the word at the top of its next epoch and stops pulling tasks
@@ -762,7 +782,10 @@ int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen) {
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->in_flight = false;
-  HIP_TRY(hipEventElapsedTime(&h->last_ms, h->ev_start, h->ev_stop));
+  if (!h->timing_valid || hipEventElapsedTime(&h->last_ms, h->ev_start, h->ev_stop) != hipSuccess) {
+    (void)hipGetLastError();
+    h->last_ms = std::nanf("");  // (an event could not be recorded: the launch itself is fine)
+  }
 #ifdef MODLE_PHASE_TIMERS
   {
     static const char* names[16] = {"burnin_stats", "bind", "rank_rev", "rank_fwd", "sample", "gen_moves",
@@ -851,7 +874,8 @@ int modle_hip_get_state_log(modle_hip_handle* h, int interval_id, size_t task_in
   // a record sits at its epoch's index; epochs whose move / collision phase did not run (the
   // epoch in which the contact target is reached) have none
   size_t out = 0;
-  for (size_t e = 0; e < h->state_log_cap && out < max_epochs; ++e) {
+  // (records == NULL counts: max_epochs does not bound the answer then)
+  for (size_t e = 0; e < h->state_log_cap && (records == nullptr || out < max_epochs); ++e) {
     if (all[e * STATE_LOG_WORDS] == ~uint64_t(0)) continue;
     if (records != nullptr)
       std::memcpy(records + out * STATE_LOG_WORDS, all.data() + e * STATE_LOG_WORDS, STATE_LOG_WORDS * 8);

@@ -4476,7 +4476,7 @@ MODLE_DEV u32 run_test_phases(const Params& p, const Interval& iv, const Workspa
 // test/units/simulation_cpu/collision_encoding_test.cpp), run by the device code itself.
 // =============================================================================================
 constexpr u32 UNIT_LOOP_STATS = 1, UNIT_MATRIX_INCREMENT = 2, UNIT_COLLISION_WORDS = 3,
-              UNIT_MATH_LOG_EXP = 4, UNIT_MATH_POW_SQRT = 5;
+              UNIT_MATH_LOG_EXP = 4, UNIT_MATH_POW_SQRT = 5, UNIT_PHILOX = 6;
 
 // predicates of one collision word, packed: bit 0 collision_occurred(), bit 1 collision_avoided(),
 // bits 2..5 collision_occurred(CHROM_BOUNDARY / LEF_BAR / LEF_LEF_PRIMARY / LEF_LEF_SECONDARY),
@@ -4545,6 +4545,22 @@ MODLE_DEV u32 run_test_units(const Params& p, const Interval& iv, const Workspac
         const f64 b = what == UNIT_MATH_LOG_EXP ? wave::f_exp(y) : wave::f_sqrt(x);
         out[2 * k] = __builtin_bit_cast(u64, a);
         out[2 * k + 1] = __builtin_bit_cast(u64, b);
+      }
+    }
+  } else if (what == UNIT_PHILOX) {
+    // pairs (counter words 0..1 | 2..3 as two 64-bit values) followed by (key words 0..1, unused):
+    // two pairs per vector; out = the four output words as two 64-bit values, then zeros
+    for (u32 base = 0; base < n / 2; base += 64) {
+      const u32 v = base + lane;
+      if (v < n / 2) {
+        const u64 c_lo = in[4 * v], c_hi = in[4 * v + 1], key = in[4 * v + 2];
+        u32 x[4];
+        philox4x32_10(static_cast<u32>(c_lo), static_cast<u32>(c_lo >> 32), static_cast<u32>(c_hi),
+                      static_cast<u32>(c_hi >> 32), static_cast<u32>(key), static_cast<u32>(key >> 32), x);
+        out[4 * v] = (static_cast<u64>(x[1]) << 32) | x[0];
+        out[4 * v + 1] = (static_cast<u64>(x[3]) << 32) | x[2];
+        out[4 * v + 2] = 0;
+        out[4 * v + 3] = 0;
       }
     }
   } else {

@@ -216,6 +216,30 @@ MODLE_DEV_CALL void rng_gen_block_call(MODLE_LDS u64* ring, const MODLE_LDS u64*
   state[3 * 64 + lane] = j3;
 }
 
+// Philox4x32-10 (the round function of the PHILOX generator policy below; compiled into every
+// build so that the known-answer vectors run against the default library too)
+MODLE_DEV void philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1, u32 out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const u64 p0 = static_cast<u64>(0xD2511F53u) * c0;
+    const u64 p1 = static_cast<u64>(0xCD9E8D57u) * c2;
+    const u32 n0 = static_cast<u32>(p1 >> 32) ^ c1 ^ k0;
+    const u32 n1 = static_cast<u32>(p1);
+    const u32 n2 = static_cast<u32>(p0 >> 32) ^ c3 ^ k1;
+    const u32 n3 = static_cast<u32>(p0);
+    c0 = n0;
+    c1 = n1;
+    c2 = n2;
+    c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0;
+  out[1] = c1;
+  out[2] = c2;
+  out[3] = c3;
+}
+
 #ifndef MODLE_RNG_PHILOX
 MODLE_DEV void rng_gen_block(Rng& g) {
   wave::lockstep();  // other lanes may still be reading the block that is about to be replaced
@@ -255,28 +279,6 @@ MODLE_DEV void rng_init(Rng& g, const u64 state[4]) {
 // "Parallel random numbers: as easy as 1, 2, 3" (SC'11), as implemented by rocRAND's
 // philox4x32_10.
 // ---------------------------------------------------------------------------------------------
-MODLE_DEV void philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1, u32 out[4]) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const u64 p0 = static_cast<u64>(0xD2511F53u) * c0;
-    const u64 p1 = static_cast<u64>(0xCD9E8D57u) * c2;
-    const u32 n0 = static_cast<u32>(p1 >> 32) ^ c1 ^ k0;
-    const u32 n1 = static_cast<u32>(p1);
-    const u32 n2 = static_cast<u32>(p0 >> 32) ^ c3 ^ k1;
-    const u32 n3 = static_cast<u32>(p0);
-    c0 = n0;
-    c1 = n1;
-    c2 = n2;
-    c3 = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  out[0] = c0;
-  out[1] = c1;
-  out[2] = c2;
-  out[3] = c3;
-}
-
 // one block of the stream; a real call like the xoshiro block generator (it is reached from every
 // phase that draws)
 MODLE_DEV_CALL void rng_philox_block_call(MODLE_LDS u64* ring, u64 key, u64 hi, u64 block_start,

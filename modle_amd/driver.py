@@ -128,20 +128,30 @@ def verify_outputs(sim, cfg, plan, ids, matrix_sums, missed_delta, occupancy_sum
     return {"tasks": n_tasks, "contacts": n_contacts, "missed_updates": n_missed}
 
 
-def write_cooler(path, cfg, plan, matrices, assembly="unknown", generated_by="modle-hip",
-                 metadata_json="", force_overwrite=False):
-    """Writes the (reduced) contact matrices of a plan to a cooler file the way the reference's
-    IO thread does (simulation.cpp:117-168, 217-269): every chromosome of the genome is in the
-    file, intervals are appended in genome order, skipped intervals and intervals without a
-    matrix contribute no pixels.  `matrices[k]`: band matrix of plan entry k (uint32,
-    nrows * ncols [+1] words, layout of modle_hip_interval_outputs) or None."""
-    from . import cooler
-
+def _chroms_of_plan(plan):
     chroms = []
     for entry in plan:
         iv = entry["interval"]
         if not chroms or chroms[-1][0] != iv["name"]:
             chroms.append((iv["name"], int(iv["size"])))
+    return chroms
+
+
+def write_cooler(path, cfg, plan, matrices, assembly="unknown", generated_by="modle-hip",
+                 metadata_json="", force_overwrite=False, chroms=None):
+    """Writes the (reduced) contact matrices of a plan to a cooler file the way the reference's
+    IO thread does (simulation.cpp:117-168, 217-269): every chromosome of the genome is in the
+    file, intervals are appended in genome order, skipped intervals and intervals without a
+    matrix contribute no pixels.  `matrices[k]`: band matrix of plan entry k (uint32,
+    nrows * ncols [+1] words, layout of modle_hip_interval_outputs) or None.
+    `chroms`: [(name, size)] of the WHOLE genome (chrom.sizes order).  The reference creates the
+    file from genome.chromosomes() (init_cooler_file, simulation.cpp:205-214), so a chromosome that
+    --genomic-intervals leaves out still has its bins; without `chroms` only the chromosomes of
+    the plan are known."""
+    from . import cooler
+
+    if chroms is None:
+        chroms = _chroms_of_plan(plan)
     with cooler.CoolerWriter(path, chroms, int(cfg.bin_size), assembly=assembly,
                              generated_by=generated_by, metadata_json=metadata_json,
                              force_overwrite=force_overwrite) as w:
@@ -160,11 +170,7 @@ def write_bigwig(path, cfg, plan, occupancies, chroms=None, force_overwrite=Fals
     from . import bigwig
 
     if chroms is None:
-        chroms = []
-        for entry in plan:
-            iv = entry["interval"]
-            if not chroms or chroms[-1][0] != iv["name"]:
-                chroms.append((iv["name"], int(iv["size"])))
+        chroms = _chroms_of_plan(plan)
     with bigwig.BigWigWriter(path, chroms, force_overwrite=force_overwrite) as w:
         for entry, occ in zip(plan, occupancies):
             if entry["skipped"] or occ is None or entry["ncols"] == 0:

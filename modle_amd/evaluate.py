@@ -70,6 +70,64 @@ def _weighted_pcc(a, b, w):
         return np.clip(cov / np.sqrt(va * vb), -1.0, 1.0)
 
 
+def weighted_ranks(v, w):
+    """compute_weighted_element_ranks (reference: src/stats/correlation_impl.hpp:265-324): the
+    rank of an element is the sum of the weights of the elements up to and including it in sorted
+    order; t tied elements share (weights before them) + (t + 1) / 2 * (their mean weight)"""
+    v = np.asarray(v, dtype=np.float64)
+    w = np.asarray(w, dtype=np.float64)
+    order = np.argsort(v, kind="stable")
+    sv, sw = v[order], w[order]
+    n = len(v)
+    starts = np.flatnonzero(np.r_[True, sv[1:] != sv[:-1]]) if n else np.zeros(0, dtype=np.int64)
+    ends = np.r_[starts[1:], n]
+    group_w = np.add.reduceat(sw, starts) if n else sw
+    before = np.r_[0.0, np.cumsum(group_w)[:-1]] if n else sw
+    size = (ends - starts).astype(np.float64)
+    # (a single element: weights before it + its own weight = the same formula with t = 1)
+    rank_of_group = before + (size + 1.0) / 2.0 * (group_w / size)
+    ranks = np.empty(n, dtype=np.float64)
+    ranks[order] = np.repeat(rank_of_group, ends - starts)
+    return ranks
+
+
+def pearson(v1, v2, weights=None):
+    """(pcc, p-value) like stats::Pearson<> (reference: src/stats/correlation_impl.hpp:29-116):
+    weighted form when `weights` is given (its p-value is NaN)"""
+    a = np.asarray(v1, dtype=np.float64)[None, :]
+    b = np.asarray(v2, dtype=np.float64)[None, :]
+    w = np.ones_like(a) if weights is None else np.asarray(weights, dtype=np.float64)[None, :]
+    pcc = float(_weighted_pcc(a, b, w)[0])
+    if weights is not None or np.isnan(pcc):
+        return pcc, float("nan")
+    from scipy import stats
+
+    ab = a.shape[1] / 2.0 - 1.0
+    return pcc, float(2.0 * stats.beta.cdf(0.5 * (1.0 - abs(pcc)), ab, ab))
+
+
+def spearman(v1, v2, weights=None):
+    """(rho, p-value) like stats::Spearman<> (reference: src/stats/correlation_impl.hpp:118-205):
+    1 when either vector is all zeros; average ranks for ties; weighted ranks with `weights`"""
+    a = np.asarray(v1, dtype=np.float64)
+    b = np.asarray(v2, dtype=np.float64)
+    if not a.any() or not b.any():
+        rho = 1.0
+    elif weights is None:
+        rho = float(_weighted_pcc(_rank_rows(a[None, :]), _rank_rows(b[None, :]), np.ones((1, len(a))))[0])
+    else:
+        w = np.asarray(weights, dtype=np.float64)
+        rho = float(_weighted_pcc(weighted_ranks(a, w)[None, :], weighted_ranks(b, w)[None, :], w[None, :])[0])
+    if weights is not None or np.isnan(rho):
+        return rho, float("nan")
+    from scipy import stats
+
+    dof = len(a) - 2.0
+    with np.errstate(divide="ignore"):
+        t = rho * np.sqrt(dof / ((1.0 + rho) * (1.0 - rho)))
+    return rho, float(2.0 * stats.t.sf(abs(t), dof))
+
+
 def compare(ref_band, tgt_band, nrows, ncols, metric="pearson", direction="vertical",
             mask_zero_pixels=False):
     """per-bin metric between two band matrices of the same shape; returns (values, pvalues)
@@ -91,10 +149,12 @@ def compare(ref_band, tgt_band, nrows, ncols, metric="pearson", direction="verti
     if metric == "spearman":
         degenerate = (a == 0).all(axis=1) | (b == 0).all(axis=1)
         if mask_zero_pixels:
-            # ranks of the unmasked pixels only (masked ones carry weight 0 anyway)
-            a = np.where(w > 0, a, np.inf)
-            b = np.where(w > 0, b, np.inf)
-        val = _weighted_pcc(_rank_rows(a), _rank_rows(b), w)
+            # the reference's weighted ranks with weights 0 / 1 (eval.cpp:331-344, 449-453)
+            ra = np.stack([weighted_ranks(a[r], w[r]) for r in range(a.shape[0])])
+            rb = np.stack([weighted_ranks(b[r], w[r]) for r in range(b.shape[0])])
+            val = _weighted_pcc(ra, rb, w)
+        else:
+            val = _weighted_pcc(_rank_rows(a), _rank_rows(b), w)
         val[degenerate] = 1.0
     else:
         val = _weighted_pcc(a, b, w)

@@ -67,6 +67,13 @@ static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
   }
 }
 
+/* the round function on its own, for the Random123 known-answer vectors */
+void mo_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c[4] = {counter[0], counter[1], counter[2], counter[3]};
+  philox4x32_10(c, key[0], key[1]);
+  for (int i = 0; i < 4; ++i) out[i] = c[i];
+}
+
 uint64_t mo_prng_next(mo_prng_t* g) {
   uint64_t* s = g->s;
   if (g_rng_policy == 1) {

@@ -223,6 +223,7 @@ void mo_generate_moves(const mo_params_t* p, uint64_t start, uint64_t end, size_
 /* contacts: nrows*ncols+1 uint32 (band layout), accumulated into with atomic adds;
  * missed: updates that fell outside the band; occupancy: ncols uint64 or NULL. */
 /* generator policy of the in-cell stream: 0 = xoshiro256++ (reference), 1 = PHILOX (see .c) */
+void mo_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
 void mo_set_rng_policy(int philox);
 int mo_get_rng_policy(void);
 /* software log / exp / pow shared with the device code (modle_amd/csrc/modle_math.h) */

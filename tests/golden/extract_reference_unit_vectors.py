@@ -11,6 +11,10 @@ names are stored -- no reference source text.
     test/units/simulation_cpu/simulation_simple_unit_test.cpp:27-128, 198-238
                                                              Bind LEFs 001-003, Generate LEF moves 001
                                                              (property tests: their parameters)
+    test/units/stats/correlation_test.cpp:124-222            Pearson / Spearman, ties, weights
+                                                             (values and p-values)
+    test/units/libmodle_io/bed_parser_test.cpp:71-122        BED "strip quotes" valid / invalid, CRLF
+    test/units/libmodle_io/bigwig_test.cpp:100-135           bigwig::Writer (two chromosomes, iota)
 """
 import json
 import os
@@ -164,10 +168,84 @@ def property_tests():
     return out
 
 
+def _c_string(expr):
+    """concatenation of adjacent C string literals -> the string they denote"""
+    parts = re.findall(r'"((?:[^"\\]|\\.)*)"', expr)
+    txt = "".join(parts)
+    return txt.encode().decode("unicode_escape")
+
+
+def correlation_vectors():
+    out = []
+    path = "stats/correlation_test.cpp"
+    for name, line, body in cases_of(path):
+        if "data_dir()" in body or "v1{" not in body:
+            continue  # (the cases that read the Zenodo data files)
+        v1 = [int(x) for x in re.search(r"v1\{([^}]*)\}", body).group(1).split(",")]
+        v2 = [int(x) for x in re.search(r"v2\{([^}]*)\}", body).group(1).split(",")]
+        w = re.search(r"\bw\{([^}]*)\}", body)
+        checks = [float(x) for x in re.findall(r"WithinRel\((-?[\d.]+),", body)]
+        c = {"name": name, "source": f"test/units/{path}:{line}",
+             "method": "spearman" if "Spearman<>" in body else "pearson", "v1": v1, "v2": v2,
+             "weights": [float(x) for x in w.group(1).split(",")] if w else None,
+             "expected": checks[0],
+             # weighted forms: CHECK(std::isnan(pv))
+             "expected_pvalue": checks[1] if len(checks) > 1 else None,
+             # DEFAULT_FP_TOLERANCE (correlation_test.cpp:28-30): float epsilon * 100
+             "rel_tolerance": 1.1920928955078125e-07 * 100}
+        out.append(c)
+    return out
+
+
+def bed_vectors():
+    out = []
+    path = "libmodle_io/bed_parser_test.cpp"
+    for name, line, body in cases_of(path):
+        if name == "BED: strip quotes":
+            valid, invalid = body.split('SECTION("invalid")')
+            m = re.search(r"line\{(.*?)\};", valid, re.S)
+            rec = {"line": _c_string(m.group(1))}
+            for field, pat in (("chrom", r'record\.chrom == "([^"]*)"'), ("chrom_start", r"chrom_start == (\d+)"),
+                               ("chrom_end", r"chrom_end == (\d+)"), ("name", r'record\.name == "([^"]*)"'),
+                               ("score", r"record\.score == ([\d.]+)"), ("strand", r"record\.strand == '(.)'"),
+                               ("thick_start", r"thick_start == (\d+)"), ("thick_end", r"thick_end == (\d+)")):
+                v = re.search(pat, valid).group(1)
+                rec[field] = v if field in ("chrom", "name", "strand") else float(v) if field == "score" else int(v)
+            m = re.search(r'bed::BED\((".*?")\)\.chrom == (".*?")\);', valid)
+            out.append({"name": name + " / valid", "source": f"test/units/{path}:{line}", "record": rec,
+                        "unbalanced_quote": {"line": _c_string(m.group(1)), "chrom": _c_string(m.group(2))},
+                        "must_throw": [_c_string(x) for x in re.findall(r"CHECK_THROWS\(bed::BED\((.*?)\)\);", invalid)]})
+        elif name == "BED Parser CRLF":
+            n = int(re.search(r"num_records = (\d+);", body).group(1))
+            fmt_w = _c_string(re.search(r'w\.write\(fmt::format\((".*?"), i\)\);', body).group(1))
+            fmt_r = _c_string(re.search(r'bed::BED\(fmt::format\((".*?"), i\)\)', body).group(1))
+            out.append({"name": name, "source": f"test/units/{path}:{line}",
+                        "file_lines": [fmt_w.replace("{}", str(i)) for i in range(n)],
+                        "expected_records": [fmt_r.replace("{}", str(i)) for i in range(n)]})
+    return out
+
+
+def bigwig_vectors():
+    out = []
+    path = "libmodle_io/bigwig_test.cpp"
+    for name, line, body in cases_of(path):
+        if name != "bigwig::Writer":
+            continue
+        names = re.findall(r'"(chr\w+)"', re.search(r"chrom_names\{([^}]*)\}", body).group(1))
+        sizes = [int(x) for x in re.search(r"chrom_sizes\{([^}]*)\}", body).group(1).split(",")]
+        bin_size = int(re.search(r"bin_size = (\d+);", body).group(1))
+        # values: iota from 0 over size / bin_size bins, written with span = step = bin_size;
+        # read back: interval i = [bin_size * i, bin_size * (i + 1)) with value float(i)
+        out.append({"name": name, "source": f"test/units/{path}:{line}", "chrom_names": names,
+                    "chrom_sizes": sizes, "bin_size": bin_size, "values": "iota"})
+    return out
+
+
 def main(out_path):
     data = {"stats": stats_vectors(), "matrix_internal": matrix_internal_vectors(),
             "matrix_dense": matrix_dense_vectors(), "collision_encoding": collision_vectors(),
-            "property_tests": property_tests()}
+            "property_tests": property_tests(), "correlation": correlation_vectors(),
+            "bed_parser": bed_vectors(), "bigwig_writer": bigwig_vectors()}
     with open(out_path, "w") as fh:
         json.dump(data, fh, indent=1)
     for k, v in data.items():

@@ -58,6 +58,32 @@ def test_two_shards_sum_to_the_single_rank_result():
         assert w[3] == a[3] + b[3]  # per-cell results in cell order: shard 0 then shard 1
 
 
+@pytest.mark.parametrize("world", [4, 8])
+def test_four_and_eight_shards_sum_to_the_single_rank_result(world):
+    """SURVEY.md section 8(d)'s gate "identical results for 1/2/4/8-GPU sharding" (the reference's
+    independence of the thread count, scheduler_simulate.cpp:129-159): the shards an N-GPU run
+    would simulate, one after the other on this GPU, sum to the single-rank outputs word for word,
+    and the per-cell results concatenate in cell order."""
+    from modle_amd import api, synthetic
+
+    genome = [synthetic.synthetic_chromosome("chrA", 5_000_000, seed=11),
+              synthetic.synthetic_chromosome("chrB", 1_500_000, seed=12, with_barriers=False),
+              synthetic.synthetic_chromosome("chrC", 7_000_000, seed=13)]
+    cfg = api.make_config(num_cells=45, seed=5)  # 45 cells: ragged shards for 4 and for 8 ranks
+    whole = _run_plan(cfg, genome, 0, 1)
+    shards = [_run_plan(cfg, genome, r, world) for r in range(world)]
+    for k, w in enumerate(whole):
+        parts = [s[k] for s in shards]
+        if w is None:
+            assert all(p is None for p in parts)
+            continue
+        assert np.array_equal(w[0], sum(p[0] for p in parts))
+        assert w[1] == sum(p[1] for p in parts)
+        assert np.array_equal(w[2], sum(p[2] for p in parts))
+        assert w[3] == [r for p in parts for r in p[3]]
+        assert all(len(p[3]) in (45 // world, 45 // world + 1) for p in parts)
+
+
 def test_chr1_scale_properties():
     from modle_amd import api, synthetic
 
@@ -176,3 +202,45 @@ def test_bench_runs_under_torch_distributed_run_with_one_rank(tmp_path):
     d = json.loads(line)
     assert d["checked"] is True and d["n_gpus"] == 1 and d["value"] > 0
     assert d["check"]["tasks"] == 24 * 16 and "side stream" in d["config"]["parallelism"]
+
+
+def _bench(tmp_path, nproc, port, extra):
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sums = str(tmp_path / f"sums_{nproc}.json")
+    cmd = [sys.executable]
+    if nproc > 1:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+                "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    cmd += [os.path.join(root, "bench.py"), "--gpus", str(nproc), "--steps", "2", "--warmup", "1",
+            "--no-cpu-baseline", "--checksum-out", sums] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    with open(sums) as f:
+        return json.loads(line), json.load(f)
+
+
+def test_bench_with_two_real_ranks_reduces_to_the_single_rank_matrices(tmp_path):
+    """bench.py's N > 1 path at world_size 2: two processes (fresh children of
+    torch.distributed.run) share this GPU, every rank polls modle_hip_interval_done and issues the
+    per-interval reduces in the same fixed order, the reduce itself goes through host copies (gloo:
+    RCCL needs one GPU per rank).  With --scaling strong the job is the same 24 cells per
+    chromosome as the single-process run, so the reduced matrices and occupancy tracks must be
+    identical to it (sums and position-weighted sums of every interval)."""
+    one, sums1 = _bench(tmp_path, 1, 0, ["--scaling", "strong", "--total-cells", "24"])
+    two, sums2 = _bench(tmp_path, 2, 29531, ["--scaling", "strong", "--total-cells", "24",
+                                            "--dist-backend", "gloo"])
+    assert one["checked"] is True and two["checked"] is True
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert two["config"]["total_cells"] == one["config"]["total_cells"] == 24
+    assert two["config"]["cells_per_gpu"] == 12 and "gloo" in two["config"]["parallelism"]
+    assert len(sums1) == 24 and sums1 == sums2
+    # whole-job counters are sums over the ranks
+    assert two["check"]["tasks"] == 24 * 12  # rank 0's shard
+    assert round(two["tasks_per_s"] * two["ms_per_step"] / 1e3) == 24 * 24

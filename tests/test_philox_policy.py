@@ -9,6 +9,8 @@ xoshiro stream, so it is held to two bars of its own:
   matrices (modle_amd/evaluate.py, the method of modle_tools evaluate), compared with the
   correlation between two exact-mode runs with different seeds (the noise floor of the method).
 """
+import ctypes as C
+import json
 import os
 import subprocess
 import sys
@@ -96,3 +98,113 @@ def test_gpu_philox_matches_oracle_with_the_same_policy(oracle, tmp_path, name, 
               "sampling_events", "sim_epochs")
     exp = np.array([[getattr(r, f) for f in fields] + list(r.prng_final) for r in ores], dtype=np.uint64)
     assert np.array_equal(got["results"], exp)
+
+
+# ---------------------------------------------------------------------------------------------
+# Known-answer vectors of the round function (Random123's kat_vectors; rocRAND's philox4x32_10 is
+# the same function): oracle, emulated device code, GPU
+# ---------------------------------------------------------------------------------------------
+UNIT_PHILOX = 6
+with open(os.path.join(ROOT, "tests", "golden", "random123_philox_kats.json")) as _fh:
+    PHILOX_KATS = json.load(_fh)["vectors"]
+
+
+def _kat_pairs():
+    """input of the unit-level hook (MODLE_HIP_UNIT_PHILOX): two pairs of 64-bit words per vector"""
+    words = []
+    for v in PHILOX_KATS:
+        c = [int(x, 16) for x in v["counter"]]
+        k = [int(x, 16) for x in v["key"]]
+        words += [c[0] | (c[1] << 32), c[2] | (c[3] << 32), k[0] | (k[1] << 32), 0]
+    return np.array(words, dtype=np.uint64)
+
+
+def _check_kat_words(out):
+    for i, v in enumerate(PHILOX_KATS):
+        e = [int(x, 16) for x in v["expected"]]
+        assert int(out[4 * i]) == e[0] | (e[1] << 32), (i, hex(int(out[4 * i])))
+        assert int(out[4 * i + 1]) == e[2] | (e[3] << 32), (i, hex(int(out[4 * i + 1])))
+
+
+def test_philox_known_answers_on_the_oracle(oracle):
+    L = oracle.lib()
+    u32x4, u32x2 = C.c_uint32 * 4, C.c_uint32 * 2
+    L.mo_philox4x32_10.argtypes = [u32x4, u32x2, u32x4]
+    L.mo_philox4x32_10.restype = None
+    for v in PHILOX_KATS:
+        out = u32x4()
+        L.mo_philox4x32_10(u32x4(*[int(x, 16) for x in v["counter"]]),
+                           u32x2(*[int(x, 16) for x in v["key"]]), out)
+        assert ["%08x" % x for x in out] == v["expected"]
+    # the stream the policy derives from it: output p = one half of the block of counter p >> 1
+    with oracle.rng_policy(True):
+        g = oracle.Prng()
+        for i in range(4):
+            g.s[i] = 0
+        g.count = 0
+        L.mo_prng_next.argtypes = [C.POINTER(oracle.Prng)]
+        L.mo_prng_next.restype = C.c_uint64
+        first, second = L.mo_prng_next(C.byref(g)), L.mo_prng_next(C.byref(g))
+    e = [int(x, 16) for x in PHILOX_KATS[0]["expected"]]  # counter 0, key 0
+    assert (first, second) == (e[0] | (e[1] << 32), e[2] | (e[3] << 32))
+
+
+@pytest.mark.parametrize("variant", [None, "philox"])
+def test_philox_known_answers_on_the_emulated_device_code(variant):
+    from modle_amd.params import Config
+    from phase_backend import emu_lib
+
+    L = emu_lib(variant)
+    u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+    L.emu_test_units.argtypes = [C.POINTER(Config), C.c_uint32, u64p, C.c_size_t, C.c_uint64,
+                                 C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), u64p]
+    L.emu_test_units.restype = C.c_int
+    pairs = _kat_pairs()
+    out = np.zeros(len(pairs), dtype=np.uint64)
+    m = C.c_uint64(0)
+    cfg = api.make_config()
+    assert L.emu_test_units(C.byref(cfg), UNIT_PHILOX, pairs, len(pairs) // 2, 0, 0, None, C.byref(m), out) == 0
+    _check_kat_words(out)
+
+
+@pytest.mark.gpu
+def test_philox_known_answers_on_the_gpu():
+    sim = api.Simulator(api.make_config(), 0)
+    try:
+        out, _, _ = sim.test_units(UNIT_PHILOX, _kat_pairs())
+    finally:
+        sim.close()
+    _check_kat_words(out)
+
+
+@pytest.mark.gpu
+def test_gpu_philox_output_is_statistically_equivalent_to_gpu_exact_output(tmp_path):
+    """Row f4 on the device: the evaluator (the method of `modle_tools evaluate`) cannot tell the
+    PHILOX library's contact matrix from the exact library's -- the per-stripe correlation between
+    the two is as high as between two exact runs over different cells (the acceptance rule of
+    test_philox_is_statistically_equivalent_to_the_exact_mode, with both sides computed by HIP)."""
+    name, n = "chr20mb_barriers", 48
+    case = build_case(name)
+    cfg, chrom = case["cfg"], case["chrom"]
+    nrows, ncols = case["nrows"], case["ncols"]
+
+    def exact(first):
+        sim = api.Simulator(cfg, 0)
+        try:
+            c, _, _, _ = sim.simulate_interval(chrom["start"], chrom["end"], chrom["bar_pos"], chrom["bar_dir"],
+                                               case["stp_active"], case["stp_inactive"],
+                                               api.slice_tasks(case["tasks"], first, first + n))
+        finally:
+            sim.close()
+        return c
+
+    e1, e2 = exact(0), exact(n)
+    ph = _philox_child(name, n, str(tmp_path / "philox.npz"))["contacts"]
+    assert int(e1.sum()) == int(ph.sum()) == int(e2.sum())
+    assert not np.array_equal(e1, ph)
+    for metric in ("pearson", "spearman"):
+        for direction in ("vertical", "horizontal"):
+            a = evaluate.summarize(evaluate.compare(e1, ph, nrows, ncols, metric, direction)[0])
+            b = evaluate.summarize(evaluate.compare(e1, e2, nrows, ncols, metric, direction)[0])
+            assert a["n"] > ncols // 2
+            assert a["median"] > 0.2 and abs(a["median"] - b["median"]) < 0.05, (metric, direction, a, b)
