@@ -262,6 +262,15 @@ int modle_genome_import(const char* chrom_sizes, size_t chrom_sizes_len, const c
     for (const Bed& b : bars) {
       const auto it = chrom_index.find(b.chrom);
       if (it == chrom_index.end()) continue;  // not on a chromosome of the genome: no interval overlaps
+      // The reference turns into barriers -- and therefore validates -- only the records its
+      // interval tree returns for some simulated interval (map_barriers_to_intervals,
+      // genome.cpp:470-489: find_overlaps(chrom, interval.start, interval.end)); a record with a
+      // bad score on a stretch that --genomic-intervals leaves out is never looked at.
+      bool overlaps_an_interval = false;
+      for (const Interval& iv : g->intervals)
+        overlaps_an_interval = overlaps_an_interval ||
+                               (iv.chrom_id == it->second && b.start < iv.end && iv.start < std::max(b.end, b.start + 1));
+      if (!overlaps_an_interval) continue;
       try {
         if (b.strand == '.') {
           ++g->dropped;
@@ -284,7 +293,10 @@ int modle_genome_import(const char* chrom_sizes, size_t chrom_sizes_len, const c
         const double sa = b.score != 0.0 ? modle_hip_stp_active_from_occupancy(puu, b.score) : pbb;
         for (Interval& iv : g->intervals) {
           if (iv.chrom_id != it->second) continue;
-          // bed tree overlap query of the interval, then GenomicInterval keeps what falls inside
+          // A barrier belongs to the interval its position (the record's midpoint) falls in.  (A
+          // record that straddles an interval's edge with its midpoint outside trips the assert of
+          // GenomicInterval::add_extrusion_barriers, genome.cpp:288-297, in the reference's debug
+          // builds; it is left out here.)
           if (pos < iv.start || pos >= iv.end) continue;
           iv.pos.push_back(pos);
           iv.dir.push_back(b.strand == '+' ? MODLE_HIP_DIR_REV : MODLE_HIP_DIR_FWD);

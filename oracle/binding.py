@@ -8,7 +8,10 @@ import numpy as np
 from modle_amd.params import CellResult, Config, Task
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libmodle_oracle.so")
+# MODLE_ORACLE_LIB=libmodle_oracle_libm.so selects the build that calls glibc's log / exp / pow
+# (make -C oracle libmodle_oracle_libm.so; tools/libm_flip_rate.py): a measuring instrument, never
+# the parity oracle
+_SO = os.path.join(_HERE, os.environ.get("MODLE_ORACLE_LIB", "libmodle_oracle.so"))
 
 u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
 u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
@@ -25,7 +28,7 @@ class Prng(C.Structure):
 
 def build():
     """(Re)build the oracle shared library with the committed Makefile."""
-    subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
+    subprocess.run(["make", "-C", _HERE, os.path.basename(_SO)], check=True, capture_output=True)
 
 
 _lib = None

@@ -18,6 +18,16 @@
  * SAME software routines (modle_amd/csrc/modle_math.h) so that every decision that
  * depends on them is identical on both sides by construction; sqrt is IEEE-exact everywhere. */
 #include "../modle_amd/csrc/modle_math.h"
+/* -DMO_USE_LIBM (make libmodle_oracle_libm.so): the same restatement calling the C library's
+ * log / exp / pow like the reference does (glibc).  Never the parity oracle -- the device has no
+ * glibc -- but the instrument that MEASURES how often a rejection test or a noise draw decides
+ * differently between the shared routines and glibc (tools/libm_flip_rate.py). */
+#ifdef MO_USE_LIBM
+#include <math.h>
+#define mm_log(x) log(x)
+#define mm_exp(x) exp(x)
+#define mm_pow(x, y) pow((x), (y))
+#endif
 
 #define MIN(a, b) ((a) < (b) ? (a) : (b))
 #define MAX(a, b) ((a) > (b) ? (a) : (b))

@@ -3,7 +3,7 @@ the CPU lane emulator (one cell per set-up: the emulator is slow)."""
 import pytest
 
 import emu_sim
-from fuzz_cases import random_case, random_case_v2, random_case_v3
+from fuzz_cases import random_case, random_case_v2, random_case_v3, random_case_v4
 from modle_amd import api
 from parity_cases import assert_same_outputs, assert_same_results
 
@@ -21,6 +21,12 @@ def test_emulated_device_code_matches_oracle_on_random_setups_v2(oracle, seed):
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_emulated_device_code_matches_oracle_on_random_setups_v3(oracle, seed):
     _compare(oracle, random_case_v3(seed), f"v3 seed {seed}")
+
+
+@pytest.mark.parametrize("seed", [3, 7, 11, 36, 52])
+def test_emulated_device_code_matches_oracle_on_random_setups_v4(oracle, seed):
+    """burn-in parameters, stopping rules, zero release probabilities (fuzz_cases.random_case_v4)"""
+    _compare(oracle, random_case_v4(seed), f"v4 seed {seed}")
 
 
 def _compare(oracle, case, label):

@@ -205,3 +205,23 @@ def test_cli_simulate_end_to_end(oracle, tmp_path):
         assert np.array_equal(vals, (oo.astype(np.float64) / float(oo.max())).astype(np.float32))
         first_bin += nbins
     assert got["attrs"]["assembly"] == "unknown" and "modle_amd" in got["attrs"]["generated-by"]
+
+
+def test_records_outside_the_simulated_intervals_are_not_validated():
+    """the reference validates score / name only for the records its interval tree returns for a
+    simulated interval (genome.cpp:470-489): a bad score on a stretch that --genomic-intervals
+    leaves out does not stop the import"""
+    sizes = "chr1\t100000\nchr2\t50000\n"
+    bad_outside = "chr1\t100\t120\tx\t0.5\t+\nchr1\t60000\t60020\ty\t7.5\t-\nchr2\t10\t20\tz\t3\t+\n"
+    chroms, ivs, stats = genome.import_genome_text(cfg(), sizes, bad_outside, "chr1\t0\t50000\n")
+    assert [(i["name"], i["start"], i["end"], i["bar_pos"].tolist()) for i in ivs] == [("chr1", 0, 50000, [110])]
+    assert stats["barriers_imported"] == 1
+    # the same file with the whole genome simulated: both bad records are looked at
+    with pytest.raises(genome.GenomeError) as e:
+        genome.import_genome_text(cfg(), sizes, bad_outside)
+    assert "invalid score field" in str(e.value)
+    # a record that overlaps the window is validated even though its midpoint lies outside
+    with pytest.raises(genome.GenomeError):
+        genome.import_genome_text(cfg(), sizes, "chr1\t49990\t50030\tq\t9\t+\n", "chr1\t0\t50000\n")
+    _, ivs, stats = genome.import_genome_text(cfg(), sizes, "chr1\t49990\t50030\tq\t0.9\t+\n", "chr1\t0\t50000\n")
+    assert ivs[0]["bar_pos"].tolist() == [] and stats["barriers_imported"] == 0

@@ -3,7 +3,7 @@ probabilities, stall multipliers, sampling strategies, resolutions): every outpu
 per-cell counter of the HIP path must equal the oracle's."""
 import pytest
 
-from fuzz_cases import random_case, random_case_v2, random_case_v3
+from fuzz_cases import random_case, random_case_v2, random_case_v3, random_case_v4
 from parity_cases import assert_same_outputs, assert_same_results
 
 pytestmark = pytest.mark.gpu
@@ -24,6 +24,13 @@ def test_gpu_matches_oracle_on_random_setups_v2(oracle, seed):
 def test_gpu_matches_oracle_on_random_setups_v3(oracle, seed):
     """blocking probabilities in {0, 1}: the compacted-barrier path of LEF-BAR detection"""
     _compare(oracle, random_case_v3(seed), f"v3 seed {seed}")
+
+
+@pytest.mark.parametrize("seed", list(range(1, 17)))
+def test_gpu_matches_oracle_on_random_setups_v4(oracle, seed):
+    """burn-in parameters (minimum length, history, smoothing window, activation ramp), stopping on
+    epochs with burn-in, TAD-to-loop ratio at its extremes, release probabilities of exactly zero"""
+    _compare(oracle, random_case_v4(seed), f"v4 seed {seed}")
 
 
 def _compare(oracle, case, label):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Differential fuzz campaign on the GPU: python tools/fuzz_campaign.py FIRST_SEED N_SEEDS [v2|v3]
+"""Differential fuzz campaign on the GPU: python tools/fuzz_campaign.py FIRST_SEED N_SEEDS [v2|v3|v4]
 (random set-ups of tests/fuzz_cases.py, HIP path vs oracle, all outputs and per-cell counters)."""
 import os
 import sys
@@ -11,12 +11,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 
-from fuzz_cases import random_case, random_case_v2, random_case_v3  # noqa: E402
+from fuzz_cases import random_case, random_case_v2, random_case_v3, random_case_v4  # noqa: E402
 from modle_amd import api  # noqa: E402
 from oracle import binding as oracle  # noqa: E402
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
-gen = {"v2": random_case_v2, "v3": random_case_v3}.get(sys.argv[3] if len(sys.argv) > 3 else "", random_case)
+gen = {"v2": random_case_v2, "v3": random_case_v3, "v4": random_case_v4}.get(sys.argv[3] if len(sys.argv) > 3 else "", random_case)
 bad = 0
 skipped = 0
 t0 = time.time()
