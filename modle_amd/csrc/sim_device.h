@@ -3892,6 +3892,8 @@ MODLE_DEV LoopStats loop_size_stats(Cell& c) {
   // pass B, LEF-id order: strictly sequential accumulation like std::accumulate: every lane
   // computes its term, the terms of a batch are folded in lane order through broadcasts
   f64 ssd = 0.0;
+  f64* terms = reinterpret_cast<f64*>(c.lds.stage);  // 2 x 64 terms (the buffer is idle here)
+  static_assert(STAGE_CAP * sizeof(u32) >= 128 * sizeof(f64), "stage buffer too small for the fold");
   struct SizeRegs {
     u32 lf[UX], lr[UX];
   };
@@ -3920,9 +3922,16 @@ MODLE_DEV LoopStats loop_size_stats(Cell& c) {
         term = d * d;
       }
       // lanes past the end hold +0.0, which leaves the (non-negative) running sum unchanged, so
-      // all 64 terms are folded with constant lane indices (no loop control in the chain)
+      // all 64 terms are folded with constant indices (no loop control in the chain).  The terms
+      // go through LDS: every lane reads them back in order (one address for the whole wave: a
+      // broadcast) and keeps its own copy of the running sum.  Two lane broadcasts per term plus
+      // the wait states between a broadcast and the addition that uses it had been two thirds of
+      // the chain.
+      wave::lockstep();
+      terms[64 * (u & 1u) + lane] = term;
+      wave::sync_lds();
 #pragma unroll
-      for (u32 l = 0; l < 64; ++l) ssd = ssd + wave::bcast(term, l);
+      for (u32 l = 0; l < 64; ++l) ssd = ssd + terms[64 * (u & 1u) + l];
     }
   }
   return LoopStats{avg, wave::f_sqrt(ssd / static_cast<f64>(n))};
