@@ -2879,7 +2879,7 @@ MODLE_DEV_NOINLINE void correct_moves_primary_standalone(Cell& c) {
 // into the load: a unit stalled by a barrier gets move = distance - 1.  (It has to come after
 // primary detection, which tests the uncorrected moves.)
 template <bool FWD>
-MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, u32 list_cap,
+MODLE_DEV_NOINLINE u32 process_secondary_dense(Cell& c, BoundaryCounts bc, u32* list, u32 list_cap,
                                 bool& overflow, bool correct_lef_bar, bool do_secondary) {
   Workspace& ws = c.ws;
   const Params& p = *c.p;
@@ -3097,6 +3097,325 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
       carry_coll = wave::bcast(C, 63);
       carry_id = wave::bcast(id, 63);
     }
+  }
+  wave::sync_mem();
+  return n_list;
+}
+
+// The same in two passes.  Nearly every batch of 64 consecutive ranks holds a few candidates (units
+// queued behind a stalled unit try again in every epoch), so the dense form above runs its chain
+// resolution -- a long dependent sequence of ballots, scalar bit operations, LDS reads and draws --
+// once per batch for a handful of useful lanes.  Here the first pass only corrects the LEF-BAR
+// moves and FILTERS: the candidates (a superset: units that can reach their blocker's position and
+// whose blocker is, or may become, stalled) are appended in visiting order to a compact list of
+// ranks in device scratch.  The second pass resolves 64 CANDIDATES at a time: it gathers their
+// units and their blockers (the unit of the adjacent rank) and runs the chain logic once for 64
+// useful lanes.  A candidate whose blocker is a candidate too (`cont`) finds it in the lane before
+// it (or in the carry of the previous group): runs of such lanes are the chains.  Draw order =
+// list order = visiting order.  The Bernoulli outcomes of a group are evaluated up front for the
+// first 64 outputs of the stream; which unit takes which output follows from masks, with one
+// round per avoided collision that cuts a chain short (not per avoided collision).
+constexpr u32 SEC_CONT = 0x40000000u;  // on the rank word of a list entry: the blocker is the entry before
+constexpr u32 SEC_BOCC = 0x80000000u;  // ... the blocker (not a candidate) is stalled
+
+template <bool FWD>
+MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, u32 list_cap,
+                                         bool& overflow, bool correct_lef_bar, bool do_secondary) {
+  Workspace& ws = c.ws;
+  const Params& p = *c.p;
+  const u32 n = wave::uniform(c.n_active);
+  const u32 lane = wave::lane();
+  const u32* pos = FWD ? ws.f_pos : ws.r_pos;
+  const u32* ids = FWD ? ws.f_id : ws.r_id;
+  const u32* barpos = stalling_barrier_positions<FWD>(ws);
+  u32* moves = FWD ? ws.f_move : ws.r_move;
+  u32* coll = FWD ? ws.f_coll : ws.r_coll;
+  const f64 p_collide = 1.0 - p.p_bypass;
+  const bool never_collide = p.p_bypass != 0.0 && p_collide == 0.0;
+  const bool trials = p.p_bypass != 0.0 && !never_collide;
+  const i32 f_first = FWD ? static_cast<i32>(bc.n3 == 0 ? n - 1 : n - bc.n3) - 1
+                          : static_cast<i32>(umax(1u, bc.n5));
+  // the candidate list (rank | flags) lives in a scratch array that is idle during the collision
+  // passes; lanes with nothing to store hit a scratch word of their own (stores under a branch
+  // cannot be counted by the compiler, and the wait for the next group's loads then becomes a wait
+  // for every store in flight)
+  u32* const q_k = ws.tmp[0];
+  u32* const dump = reinterpret_cast<u32*>(ws.sort_keys) + lane;
+  u32 n_cand = 0;
+
+  // ---- pass 1: LEF-BAR moves, candidates -------------------------------------------------------
+#ifdef MODLE_PHASE_TIMERS
+  const u64 t_pass1 = wave::clock();
+#endif
+  u32 carry_pos = 0, carry_coll = 0;
+  bool carry_pending = false;
+  const u32 nbatch = (n + 63) / 64;
+  constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
+  struct UnitRegs {
+    u32 P[UX], M[UX], C[UX], B[UX];
+  };
+  const auto load_units = [&](auto op, u32 bg, UnitRegs& r) {
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 bi = bg + u;
+      const i32 kk = FWD ? static_cast<i32>(n) - 1 - static_cast<i32>(bi * 64 + lane)
+                         : static_cast<i32>(bi * 64 + lane);
+      const bool act = kk >= 0 && static_cast<u32>(kk) < n;
+      const u32 k = act ? static_cast<u32>(kk) : 0;
+      r.P[u] = op(pos, k, act, 0, r.P[u]);
+      r.M[u] = op(moves, k, act, 0, r.M[u]);
+      r.C[u] = op(coll, k, act, 0, r.C[u]);
+      r.B[u] = op(barpos, k, act, 0, r.B[u]);
+    }
+  };
+  UnitRegs cur;
+  load_units(wave::LdRaw{}, 0, cur);
+  for (u32 bg = 0; bg < nbatch; bg += UX) {
+    UnitRegs g = cur;
+    load_units(wave::LdMask{}, bg, g);  // (defaults of the lanes outside the range)
+    if (bg + UX < nbatch) load_units(wave::LdRaw{}, bg + UX, cur);
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 bi = bg + u;
+      if (bi >= nbatch) break;
+      const i32 kk = FWD ? static_cast<i32>(n) - 1 - static_cast<i32>(bi * 64 + lane)
+                         : static_cast<i32>(bi * 64 + lane);
+      const bool act = kk >= 0 && static_cast<u32>(kk) < n;
+      const u32 k = act ? static_cast<u32>(kk) : 0;
+      const u32 P = g.P[u], M0 = g.M[u], C = g.C[u];
+      u32 M = M0;
+      if (correct_lef_bar && act && cw_occurred_as(C, EV_LEF_BAR)) {
+        const u32 bp = g.B[u];
+        M = (FWD ? bp - P : P - bp) - 1;
+      }
+      *((act && M != M0) ? &moves[k] : dump) = M;
+      const bool follower = do_secondary && act && (FWD ? (kk <= f_first) : (kk >= f_first));
+      // the blocker: the unit visited before this one
+      const u32 bP_in = wave::shfl_up1(P), bC_in = wave::shfl_up1(C);
+      const u32 bP = lane > 0 ? bP_in : carry_pos, bC = lane > 0 ? bC_in : carry_coll;
+      const bool pot = follower && !cw_occurred(C) &&
+                       (FWD ? static_cast<u64>(P) + M >= bP : static_cast<u64>(P) - M <= bP);
+      const u64 potm = wave::ballot(pot);
+      // blocker stalled already, or itself a candidate (then it may become stalled in pass 2):
+      // propagate along runs of consecutive candidates.  The unit before lane 0 counts as "may be
+      // stalled" when it is a candidate (its outcome is not known in this pass).
+      const u64 occm = wave::ballot(cw_occurred(bC)) | (carry_pending ? u64(1) : u64(0));
+      u64 pend = potm & occm;
+      for (;;) {
+        const u64 grown = pend | (potm & (pend << 1));
+        if (grown == pend) break;
+        pend = grown;
+      }
+      {
+        const bool mine = ((pend >> lane) & 1u) != 0;
+        const u32 e = n_cand + static_cast<u32>(wave::popc64(pend & lanemask_lt(lane)));
+        const bool cont = lane > 0 ? ((pend >> (lane - 1)) & 1u) != 0 : carry_pending;
+        *((mine && e < list_cap) ? &q_k[e] : dump) =
+            k | (cont ? SEC_CONT : 0u) | (cw_occurred(bC) ? SEC_BOCC : 0u);
+      }
+      n_cand += static_cast<u32>(wave::popc64(pend));
+      carry_pending = (pend >> 63) != 0;
+      carry_pos = wave::bcast(P, 63);
+      carry_coll = wave::bcast(C, 63);
+    }
+  }
+  wave::sync_mem();
+  if (n_cand == 0) return 0;
+  if (n_cand > list_cap) {
+    // (more candidates than the scratch holds: the dense form redoes the pass -- the LEF-BAR
+    // correction is idempotent, nothing else has been written)
+    return process_secondary_dense<FWD>(c, bc, list, list_cap, overflow, correct_lef_bar, do_secondary);
+  }
+
+  // ---- pass 2: 64 candidates at a time ---------------------------------------------------------
+#ifdef MODLE_PHASE_TIMERS
+  c.ph[14] += wave::clock() - t_pass1;  // (sub_a: the filter pass; the rest of the phase is pass 2)
+#endif
+  u32 n_list = 0;
+  u32 fin_pos = 0, fin_move = 0, fin_coll = 0, fin_id = 0;  // the candidate before this group, resolved
+  // the units of a group and their blockers (the unit visited before: the adjacent rank) are
+  // gathered through the list; the next group's list entries and units are requested one group
+  // ahead.  (A blocker's move is final here: blockers that are candidates are taken from the lane
+  // before, and everything else was settled by pass 1.)
+  struct CandRegs {
+    u32 K, P, M, C, I, bP, bM, bI;
+  };
+  const auto load_units_of = [&](u32 base, u32 kword, CandRegs& r) {
+    const bool in = base + lane < n_cand;
+    const u32 k = in ? (kword & CW_INDEX_MASK) : 0u;
+    // (the first unit in visiting order is never a candidate: the adjacent rank exists)
+    const u32 kb = in ? (FWD ? k + 1 : k - 1) : 0u;
+    r.K = kword;
+    r.P = wave::LdRaw{}(pos, k, true, 0, 0u);
+    r.M = wave::LdRaw{}(moves, k, true, 0, 0u);
+    r.C = wave::LdRaw{}(coll, k, true, 0, 0u);
+    r.I = wave::LdRaw{}(ids, k, true, 0, 0u);
+    r.bP = wave::LdRaw{}(pos, kb, true, 0, 0u);
+    r.bM = wave::LdRaw{}(moves, kb, true, 0, 0u);
+    r.bI = wave::LdRaw{}(ids, kb, true, 0, 0u);
+  };
+  const auto load_kword = [&](u32 base) { return wave::ld_sel(q_k, base + lane, base + lane < n_cand, 0u); };
+  CandRegs ccur;
+  load_units_of(0, load_kword(0), ccur);
+  u32 kword_next = 64 < n_cand ? load_kword(64) : 0u;
+  for (u32 base = 0; base < n_cand; base += 64) {
+    const CandRegs q = ccur;
+    if (base + 64 < n_cand) {
+      load_units_of(base + 64, kword_next, ccur);
+      if (base + 128 < n_cand) kword_next = load_kword(base + 128);
+    }
+    const u32 m = umin(64u, n_cand - base);
+    const bool valid = lane < m;
+    const u64 vmask = m == 64 ? ~u64(0) : lanemask_lt(m);
+    const u32 k = q.K & CW_INDEX_MASK;
+    const u32 P = q.P, id = q.I, M0 = q.M, C0 = q.C;
+    u32 M = M0, C = C0;
+    // blocker of the first lane when it is the last candidate of the previous group: resolved now
+    bool cont = valid && (q.K & SEC_CONT) != 0;
+    bool bocc = (q.K & SEC_BOCC) != 0;
+    u32 xP = q.bP, xM = q.bM, xI = q.bI;  // explicit blocker (lanes that do not continue a chain)
+    if (lane == 0 && cont) {
+      xP = fin_pos;
+      xM = fin_move;
+      xI = fin_id;
+      bocc = cw_occurred(fin_coll);
+      cont = false;
+    }
+    const u64 contm = wave::ballot(cont);
+    const u64 lt = lanemask_lt(lane), le = lt | (u64(1) << lane);
+    const u64 starts = vmask & ~contm, ends = vmask & ~(contm >> 1);
+    const u32 pP_in = wave::shfl_up1(P);
+    const u32 blocker_pos = cont ? pP_in : xP;
+    const auto wraps = [](u32 pp, u32 mm) { return FWD ? pp + mm < pp : mm > pp; };
+    const bool odd = valid && (P == blocker_pos || wraps(P, M) || (!cont && wraps(xP, xM)));
+    u64 pend = vmask;
+    if (!wave::any(odd)) {
+      const u32 bI_in = wave::shfl_up1(id);
+      const u32 bId = cont ? bI_in : xI;
+      const u32 s = valid ? static_cast<u32>(63 - wave::clz64(starts & le)) : lane;  // start of the lane's run
+      // landing position and state of the run's own blocker (explicit at the run's first lane)
+      const u32 xland = FWD ? xP + xM : xP - xM;
+      const u32 lb = wave::shfl(xland, s);
+      const bool head_ok = wave::shfl(static_cast<u32>(bocc), s) != 0;
+      const u32 off = lane - s;
+      const u32 land_prev = FWD ? lb - off : lb + off;  // the blocker's landing while the chain holds
+      const bool geo = FWD ? (P + M >= land_prev) : (P - M <= land_prev);
+      // a run whose first blocker is not stalled does nothing at all
+      const u64 ngeo = wave::ballot(valid && (!geo || (lane == s && !head_ok)));
+      const bool alive = valid && ((ngeo & le) >> s) == 0;
+      // the lanes that draw unless an "avoid" before them ends their chain: in every run a
+      // prefix of its lanes
+      const u64 live = wave::ballot(alive);
+      // outcome of stream output t, for the first 64 outputs (at most popc(live) are consumed)
+      u64 outcomes = never_collide ? u64(0) : ~u64(0);
+      if (trials && live != 0) {
+        rng_ensure(c.g, static_cast<u32>(wave::popc64(live)));
+        outcomes = wave::ballot(bernoulli_raw(rng_peek(c.g, c.g.pos + lane), p_collide));
+      }
+      u64 hits = 0, avoids = 0;  // lanes that collide / whose collision is avoided
+      u32 drawn = 0;             // outputs consumed
+#ifdef MODLE_PHASE_TIMERS
+      const u64 t_walk = wave::clock();
+#endif
+      // Every lane takes the output its position among the drawing lanes gives it.  That is final
+      // up to the first "avoid" that ends a chain with lanes still to draw behind it (those lanes
+      // drop out, and every later lane moves to an earlier output): one round per such avoid, and
+      // most avoids are the last lane of their chain.
+      const u64 has_successor = (live >> 1) & (contm >> 1);  // the next lane draws after this one, same chain
+      for (u64 rem = live; rem != 0;) {
+        const u32 t = drawn + static_cast<u32>(wave::popc64(rem & lt));
+        const bool collide = ((outcomes >> (t & 63u)) & 1u) != 0;
+        const u64 av = wave::ballot(((rem >> lane) & 1u) != 0 && !collide);
+        const u64 cut = av & has_successor;
+        if (cut == 0) {
+          hits |= rem & ~av;
+          avoids |= av;
+          drawn += static_cast<u32>(wave::popc64(rem));
+          break;
+        }
+        const u32 a = static_cast<u32>(wave::ctz64(cut));
+        const u32 e = static_cast<u32>(wave::ctz64(ends & ~lanemask_lt(a)));  // end of its run
+        const u64 upto = lanemask_lt(a) | (u64(1) << a);
+        hits |= rem & upto & ~av;
+        avoids |= av & upto;
+        drawn += static_cast<u32>(wave::popc64(rem & upto));
+        rem = e >= 63 ? u64(0) : rem & ~lanemask_lt(e + 1);
+      }
+#ifdef MODLE_PHASE_TIMERS
+      c.ph[15] += wave::clock() - t_walk;
+#endif
+      if (trials && drawn != 0) rng_advance(c.g, drawn);
+      if ((avoids >> lane) & 1u) {
+        C = cw_make(bId, EV_LEF_LEF_SECONDARY);
+        const u32 j = n_list + static_cast<u32>(wave::popc64(avoids & lt));
+        if (j < list_cap) list[j] = k;
+        if (c.filter_on) {
+          rank_filter_add_id(c, id);
+          rank_filter_add_id(c, bId);
+        }
+      }
+      n_list += static_cast<u32>(wave::popc64(avoids));
+      if (n_list > list_cap) overflow = true;
+      if ((hits >> lane) & 1u) {
+        const u32 move = FWD ? land_prev - P : P - land_prev;
+        M = umin(move, move - 1);
+        C = cw_make(bId, EV_COLLISION | EV_LEF_LEF_SECONDARY);
+      }
+      pend = 0;
+    }
+    // Rounds (a candidate AT its blocker's position, moves that wrap): a lane is ready when its
+    // blocker -- the lane before it for a chain lane -- is resolved; all ready lanes below the first
+    // lane that still waits are resolved together, their draws numbered in lane order.
+    while (pend != 0) {
+      const u32 pP = wave::shfl_up1(P), pM = wave::shfl_up1(M);
+      const u32 pC = wave::shfl_up1(C), pI = wave::shfl_up1(id);
+      const u32 bP = cont ? pP : xP, bM = cont ? pM : xM, bId = cont ? pI : xI;
+      const bool b_stalled = cont ? cw_occurred(pC) : bocc;
+      const u64 ready = pend & ~((pend << 1) & contm);
+      const u64 waiting = pend & ~ready;
+      const u64 now =
+          waiting != 0 ? (ready & lanemask_lt(static_cast<u32>(wave::ctz64(waiting)))) : ready;
+      const bool mine = ((now >> lane) & 1u) != 0;
+      const bool geo = FWD ? (static_cast<u64>(P) + M >= static_cast<u64>(bP) + bM)
+                           : (static_cast<u64>(P) - M <= static_cast<u64>(bP) - bM);
+      const bool draws = mine && b_stalled && geo;
+      const u64 dm = wave::ballot(draws);
+      bool collide = draws && !never_collide;
+      if (trials && dm != 0) {
+        const u32 cnt = static_cast<u32>(wave::popc64(dm));
+        rng_ensure(c.g, cnt);
+        const u32 t = static_cast<u32>(wave::popc64(dm & lanemask_lt(lane)));
+        collide = draws && bernoulli_raw(rng_peek(c.g, c.g.pos + t), p_collide);
+        rng_advance(c.g, cnt);
+      }
+      const bool avoided = draws && !collide;
+      if (collide) {
+        const u32 move = FWD ? (bP + bM) - P : P - (bP - bM);
+        M = umin(move, move - 1);
+        C = cw_make(bId, EV_COLLISION | EV_LEF_LEF_SECONDARY);
+      }
+      const u64 am = wave::ballot(avoided);
+      if (avoided) {
+        C = cw_make(bId, EV_LEF_LEF_SECONDARY);
+        const u32 j = n_list + static_cast<u32>(wave::popc64(am & lanemask_lt(lane)));
+        if (j < list_cap) list[j] = k;
+        if (c.filter_on) {
+          rank_filter_add_id(c, id);
+          rank_filter_add_id(c, bId);
+        }
+      }
+      n_list += static_cast<u32>(wave::popc64(am));
+      if (n_list > list_cap) overflow = true;
+      pend &= ~now;
+    }
+    if (valid && (M != M0 || C != C0)) {
+      moves[k] = M;
+      coll[k] = C;
+    }
+    fin_pos = wave::bcast(P, m - 1);
+    fin_move = wave::bcast(M, m - 1);
+    fin_coll = wave::bcast(C, m - 1);
+    fin_id = wave::bcast(id, m - 1);
   }
   wave::sync_mem();
   return n_list;
