@@ -3118,62 +3118,77 @@ MODLE_DEV_NOINLINE u32 process_secondary_dense(Cell& c, BoundaryCounts bc, u32* 
 constexpr u32 SEC_CONT = 0x40000000u;  // on the rank word of a list entry: the blocker is the entry before
 constexpr u32 SEC_BOCC = 0x80000000u;  // ... the blocker (not a candidate) is stalled
 
+// Pass 1 as a stepper, so that the rev and the fwd instance can share one loop (they are
+// independent: no draws, each reads and writes its own direction's arrays): two dependency chains
+// per iteration instead of one.
 template <bool FWD>
-MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, u32 list_cap,
-                                         bool& overflow, bool correct_lef_bar, bool do_secondary) {
-  Workspace& ws = c.ws;
-  const Params& p = *c.p;
-  const u32 n = wave::uniform(c.n_active);
-  const u32 lane = wave::lane();
-  const u32* pos = FWD ? ws.f_pos : ws.r_pos;
-  const u32* ids = FWD ? ws.f_id : ws.r_id;
-  const u32* barpos = stalling_barrier_positions<FWD>(ws);
-  u32* moves = FWD ? ws.f_move : ws.r_move;
-  u32* coll = FWD ? ws.f_coll : ws.r_coll;
-  const f64 p_collide = 1.0 - p.p_bypass;
-  const bool never_collide = p.p_bypass != 0.0 && p_collide == 0.0;
-  const bool trials = p.p_bypass != 0.0 && !never_collide;
-  const i32 f_first = FWD ? static_cast<i32>(bc.n3 == 0 ? n - 1 : n - bc.n3) - 1
-                          : static_cast<i32>(umax(1u, bc.n5));
-  // the candidate list (rank | flags) lives in a scratch array that is idle during the collision
-  // passes; lanes with nothing to store hit a scratch word of their own (stores under a branch
-  // cannot be counted by the compiler, and the wait for the next group's loads then becomes a wait
-  // for every store in flight)
-  u32* const q_k = ws.tmp[0];
-  u32* const dump = reinterpret_cast<u32*>(ws.sort_keys) + lane;
-  u32 n_cand = 0;
-
-  // ---- pass 1: LEF-BAR moves, candidates -------------------------------------------------------
-#ifdef MODLE_PHASE_TIMERS
-  const u64 t_pass1 = wave::clock();
-#endif
-  u32 carry_pos = 0, carry_coll = 0;
-  bool carry_pending = false;
-  const u32 nbatch = (n + 63) / 64;
-  constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
+struct SecondaryFilter {
+  static constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
   struct UnitRegs {
     u32 P[UX], M[UX], C[UX], B[UX];
   };
-  const auto load_units = [&](auto op, u32 bg, UnitRegs& r) {
+  const u32 *pos, *coll, *barpos;
+  u32 *moves, *q_k, *dump;
+  u32 n, lane, nbatch, cap, n_cand, carry_pos, carry_coll;
+  i32 f_first;
+  bool correct_lef_bar, do_secondary, carry_pending;
+  UnitRegs cur;
+
+  MODLE_DEV_MEMBER void load_units(bool raw, u32 bg, UnitRegs& r) const {
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 bi = bg + u;
+      // (ranks stay far below 2^31: 32-bit index arithmetic)
       const i32 kk = FWD ? static_cast<i32>(n) - 1 - static_cast<i32>(bi * 64 + lane)
                          : static_cast<i32>(bi * 64 + lane);
       const bool act = kk >= 0 && static_cast<u32>(kk) < n;
       const u32 k = act ? static_cast<u32>(kk) : 0;
-      r.P[u] = op(pos, k, act, 0, r.P[u]);
-      r.M[u] = op(moves, k, act, 0, r.M[u]);
-      r.C[u] = op(coll, k, act, 0, r.C[u]);
-      r.B[u] = op(barpos, k, act, 0, r.B[u]);
+      if (raw) {
+        r.P[u] = wave::LdRaw{}(pos, k, act, 0, r.P[u]);
+        r.M[u] = wave::LdRaw{}(moves, k, act, 0, r.M[u]);
+        r.C[u] = wave::LdRaw{}(coll, k, act, 0, r.C[u]);
+        r.B[u] = wave::LdRaw{}(barpos, k, act, 0, r.B[u]);
+      } else {
+        r.P[u] = wave::LdMask{}(pos, k, act, 0, r.P[u]);
+        r.M[u] = wave::LdMask{}(moves, k, act, 0, r.M[u]);
+        r.C[u] = wave::LdMask{}(coll, k, act, 0, r.C[u]);
+        r.B[u] = wave::LdMask{}(barpos, k, act, 0, r.B[u]);
+      }
     }
-  };
-  UnitRegs cur;
-  load_units(wave::LdRaw{}, 0, cur);
-  for (u32 bg = 0; bg < nbatch; bg += UX) {
+  }
+  MODLE_DEV_MEMBER void init(Cell& c, BoundaryCounts bc, u32 list_cap, bool lef_bar, bool secondary) {
+    Workspace& ws = c.ws;
+    n = wave::uniform(c.n_active);
+    lane = wave::lane();
+    pos = FWD ? ws.f_pos : ws.r_pos;
+    coll = FWD ? ws.f_coll : ws.r_coll;
+    barpos = stalling_barrier_positions<FWD>(ws);
+    moves = FWD ? ws.f_move : ws.r_move;
+    // the candidate list (rank | flags) lives in a scratch array that is idle during the collision
+    // passes; lanes with nothing to store hit a scratch word of their own (stores under a branch
+    // cannot be counted by the compiler, and the wait for the next group's loads then becomes a
+    // wait for every store in flight)
+    q_k = FWD ? ws.tmp[1] : ws.tmp[0];
+    dump = reinterpret_cast<u32*>(ws.sort_keys) + 2 * lane + (FWD ? 1 : 0);
+    cap = list_cap;
+    correct_lef_bar = lef_bar;
+    do_secondary = secondary;
+    // rev: followers i = max(1, n5) .. n-1 ascending, blocker = rank i-1
+    // fwd: followers i-1 for i = (n - min(n3, n3-1) - 1) .. 1 descending, blocker = rank i
+    f_first = FWD ? static_cast<i32>(bc.n3 == 0 ? n - 1 : n - bc.n3) - 1
+                  : static_cast<i32>(umax(1u, bc.n5));
+    nbatch = (n + 63) / 64;
+    n_cand = 0;
+    carry_pos = 0;
+    carry_coll = 0;
+    carry_pending = false;
+    load_units(true, 0, cur);
+  }
+  // one group of UX batches (bg = first batch of the group)
+  MODLE_DEV_MEMBER void step(u32 bg) {
     UnitRegs g = cur;
-    load_units(wave::LdMask{}, bg, g);  // (defaults of the lanes outside the range)
-    if (bg + UX < nbatch) load_units(wave::LdRaw{}, bg + UX, cur);
+    load_units(false, bg, g);  // (defaults of the lanes outside the range)
+    if (bg + UX < nbatch) load_units(true, bg + UX, cur);
 #pragma unroll
     for (u32 u = 0; u < UX; ++u) {
       const u32 bi = bg + u;
@@ -3210,7 +3225,7 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
         const bool mine = ((pend >> lane) & 1u) != 0;
         const u32 e = n_cand + static_cast<u32>(wave::popc64(pend & lanemask_lt(lane)));
         const bool cont = lane > 0 ? ((pend >> (lane - 1)) & 1u) != 0 : carry_pending;
-        *((mine && e < list_cap) ? &q_k[e] : dump) =
+        *((mine && e < cap) ? &q_k[e] : dump) =
             k | (cont ? SEC_CONT : 0u) | (cw_occurred(bC) ? SEC_BOCC : 0u);
       }
       n_cand += static_cast<u32>(wave::popc64(pend));
@@ -3219,7 +3234,27 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
       carry_coll = wave::bcast(C, 63);
     }
   }
-  wave::sync_mem();
+};
+
+// Pass 2 of one direction over the `n_cand` candidates pass 1 listed in ws.tmp[0] (rev) /
+// ws.tmp[1] (fwd).
+template <bool FWD>
+MODLE_DEV_NOINLINE u32 secondary_resolve(Cell& c, BoundaryCounts bc, u32 n_cand, u32* list, u32 list_cap,
+                                         bool& overflow, bool correct_lef_bar, bool do_secondary) {
+  Workspace& ws = c.ws;
+  const Params& p = *c.p;
+  const u32 lane = wave::lane();
+  const u32* pos = FWD ? ws.f_pos : ws.r_pos;
+  const u32* ids = FWD ? ws.f_id : ws.r_id;
+  u32* moves = FWD ? ws.f_move : ws.r_move;
+  u32* coll = FWD ? ws.f_coll : ws.r_coll;
+  const u32* const q_k = FWD ? ws.tmp[1] : ws.tmp[0];
+  // run_lef_lef_collision_trial (simulation_impl.hpp:93-96): no draw when the bypass probability
+  // is 0 (always collide) -- and none when it is 1: bernoulli_distribution(0) returns false
+  // without touching the engine
+  const f64 p_collide = 1.0 - p.p_bypass;
+  const bool never_collide = p.p_bypass != 0.0 && p_collide == 0.0;
+  const bool trials = p.p_bypass != 0.0 && !never_collide;
   if (n_cand == 0) return 0;
   if (n_cand > list_cap) {
     // (more candidates than the scratch holds: the dense form redoes the pass -- the LEF-BAR
@@ -3227,10 +3262,6 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
     return process_secondary_dense<FWD>(c, bc, list, list_cap, overflow, correct_lef_bar, do_secondary);
   }
 
-  // ---- pass 2: 64 candidates at a time ---------------------------------------------------------
-#ifdef MODLE_PHASE_TIMERS
-  c.ph[14] += wave::clock() - t_pass1;  // (sub_a: the filter pass; the rest of the phase is pass 2)
-#endif
   u32 n_list = 0;
   u32 fin_pos = 0, fin_move = 0, fin_coll = 0, fin_id = 0;  // the candidate before this group, resolved
   // the units of a group and their blockers (the unit visited before: the adjacent rank) are
@@ -3419,6 +3450,39 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
   }
   wave::sync_mem();
   return n_list;
+}
+
+// one direction: filter, then resolve (phase-level hooks; the epoch loop runs the two filters in one loop)
+template <bool FWD>
+MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, u32 list_cap,
+                                         bool& overflow, bool correct_lef_bar, bool do_secondary) {
+  SecondaryFilter<FWD> f;
+  f.init(c, bc, list_cap, correct_lef_bar, do_secondary);
+  for (u32 bg = 0; bg < f.nbatch; bg += SecondaryFilter<FWD>::UX) f.step(bg);
+  wave::sync_mem();
+  return secondary_resolve<FWD>(c, bc, f.n_cand, list, list_cap, overflow, correct_lef_bar, do_secondary);
+}
+
+// both directions: the two filters in one loop, then the rev and the fwd resolve pass (draw order)
+MODLE_DEV_NOINLINE void process_secondary_both(Cell& c, BoundaryCounts bc, u32* list_rev, u32* list_fwd,
+                                               u32 list_cap, bool& overflow, u32& n_rev, u32& n_fwd) {
+  SecondaryFilter<false> fr;
+  SecondaryFilter<true> ff;
+  fr.init(c, bc, list_cap, true, true);
+  ff.init(c, bc, list_cap, true, true);
+#ifdef MODLE_PHASE_TIMERS
+  const u64 t_pass1 = wave::clock();
+#endif
+  for (u32 bg = 0; bg < fr.nbatch; bg += SecondaryFilter<false>::UX) {
+    fr.step(bg);
+    ff.step(bg);
+  }
+  wave::sync_mem();
+#ifdef MODLE_PHASE_TIMERS
+  c.ph[14] += wave::clock() - t_pass1;  // (sub_a: the filter pass; the rest of the phase is pass 2)
+#endif
+  n_rev = secondary_resolve<false>(c, bc, fr.n_cand, list_rev, list_cap, overflow, true, true);
+  n_fwd = secondary_resolve<true>(c, bc, ff.n_cand, list_fwd, list_cap, overflow, true, true);
 }
 
 // fix_secondary_lef_lef_collisions (reference: simulation_detect_collisions.cpp:517-644).
@@ -3637,8 +3701,7 @@ MODLE_DEV bool phase_process_collisions(Cell& c) {
   // (the LDS sort buffer is idle from here to the release: it holds the id filter)
   c.filter_on = !(c.inv_valid[0] && c.inv_valid[1]);
   if (c.filter_on) rank_filter_clear(c, c.n_active);
-  PHASE(c, 11, nr = process_secondary<false>(c, bc, list_rev, cap, overflow, true, true);
-        nf = process_secondary<true>(c, bc, list_fwd, cap, overflow, true, true));
+  PHASE(c, 11, process_secondary_both(c, bc, list_rev, list_fwd, cap, overflow, nr, nf));
   c.filter_on = false;
   if (overflow) c.error = ERR_LIST_OVERFLOW;
   if (c.error != 0) return false;
