@@ -36,6 +36,12 @@ struct Cell {
   // set per direction, in ws.tmp[2..3] / ws.tmp[4..5]) for the two rank updates that follow it
   u32 n_keys;
   bool keys_valid;
+  // the extrusion sweep lists the units it leaves out of order (their position after the move is
+  // below that of a unit of lower rank: a unit went past another one behind an avoided secondary
+  // collision): sort keys in ws.tmp[6] (rev) / ws.tmp[7] (fwd), DISP_MARK in the move array.  The
+  // rank update re-inserts them like the units bound in between.
+  u32 n_disp[2];
+  bool disp_valid;
   // ws.r_rank / ws.f_rank ([0] rev, [1] fwd) hold the complete inverse permutation.  The rank
   // update of the epoch loop does not write it (one scattered store per unit and epoch): the
   // sparse consumers -- bind, release, fix_secondary -- get the ranks of the few LEFs they need
@@ -556,8 +562,9 @@ MODLE_DEV void rank_finish(Cell& c, bool ties, const u32* where, u32 t_lo, u32 t
 // cross-lane scans (running maximum of the carried-over positions, new units so far, keys so far)
 // and four independent key searches per lane.
 // Carried-over units that are out of order (a unit that went past another one behind an avoided
-// secondary collision; every epoch has a few) are re-inserted like new units: a light sweep
-// (positions and marks only) finds them first and adds their keys.
+// secondary collision; every epoch has a few) are re-inserted like new units: the extrusion sweep
+// of the previous epoch, which has the new positions in registers anyway, has marked them and
+// listed their keys (a separate sweep over positions and marks used to find them here).
 // Returns false -- nothing committed, the caller runs the general update -- when the keys do not
 // fit the LDS buffers.
 template <bool FWD>
@@ -581,54 +588,20 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
     const u64 kv = wave::ld_sel(src, k, k < n_listed, ~u64(0));
     if (k < n_listed) keys[k] = kv;
   }
-  // the out-of-order units: carried-over units below the running maximum of the carried-over
-  // units before them
+  // the out-of-order units the extrusion sweep listed, unless they have been released and bound
+  // again since (their slot then carries the mark of a new unit, and the bind phase's key)
   u32 n_new = n_listed;
   {
-    struct Pre {
-      wave::U32x4 P, K;
-    };
-    const auto load_pre = [&](u32 t, Pre& r) {
-      const u32 w = 256 * t + 4 * lane;
-      const u32 wq = w < n ? w : 0u;
-      r.P = wave::ld4(pos, wq);
-      r.K = wave::ld4(marks, wq);
-    };
-    u32 run_max = 0;
-    Pre cur;
-    load_pre(0, cur);
-    for (u32 t = 0; t < nblk; ++t) {
-      const Pre g = cur;
-      if (t + 1 < nblk) load_pre(t + 1, cur);
-      const u32 w = 256 * t + 4 * lane;
-      u32 mx[4];
-      bool carried[4];
-#pragma unroll
-      for (u32 j = 0; j < 4; ++j) {
-        carried[j] = w + j < n && g.K.v[j] != NEW_MARK;
-        const u32 cp = carried[j] ? g.P.v[j] : 0u;
-        mx[j] = j == 0 ? cp : umax(mx[j - 1], cp);
-      }
-      const u32 pm = wave_prefix_max_u32(mx[3]);
-      const u32 pm_prev = wave::shfl_up1(pm);
-      const u32 lane_excl = umax(run_max, lane > 0 ? pm_prev : 0);
-      run_max = umax(run_max, wave::bcast(pm, 63));
-      bool disp[4];
-      bool any_d = false;
-#pragma unroll
-      for (u32 j = 0; j < 4; ++j) {
-        disp[j] = carried[j] && g.P.v[j] < (j == 0 ? lane_excl : umax(lane_excl, mx[j - 1]));
-        any_d = any_d || disp[j];
-      }
-      if (wave::any(any_d)) {
-#pragma unroll
-        for (u32 j = 0; j < 4; ++j) {
-          const u64 dm = wave::ballot(disp[j]);
-          const u32 e = n_new + static_cast<u32>(wave::popc64(dm & lanemask_lt(lane)));
-          if (disp[j] && e < STAGE_CAP) keys[e] = (static_cast<u64>(g.P.v[j]) << 32) | (w + j);
-          n_new += static_cast<u32>(wave::popc64(dm));
-        }
-      }
+    const u64* dsrc = reinterpret_cast<const u64*>(FWD ? ws.tmp[7] : ws.tmp[6]);
+    const u32 nd = wave::uniform(c.n_disp[FWD ? 1 : 0]);
+    for (u32 base = 0; base < nd; base += 64) {
+      const u32 e = base + lane;
+      const u64 kv = wave::ld_sel(dsrc, e, e < nd, ~u64(0));
+      const bool still = e < nd && wave::ld_sel(marks, static_cast<u32>(kv), e < nd, 0u) == DISP_MARK;
+      const u64 dm = wave::ballot(still);
+      const u32 j = n_new + static_cast<u32>(wave::popc64(dm & lanemask_lt(lane)));
+      if (still && j < STAGE_CAP) keys[j] = kv;
+      n_new += static_cast<u32>(wave::popc64(dm));
     }
   }
   if (n_new > STAGE_CAP) return false;
@@ -671,7 +644,7 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
       act4[j] = w + j < n;
       pp[j] = g.P.v[j];
       oid[j] = g.I.v[j];
-      carried[j] = act4[j] && g.K.v[j] != NEW_MARK;
+      carried[j] = act4[j] && g.K.v[j] != NEW_MARK && g.K.v[j] != DISP_MARK;
       const u32 cp = carried[j] ? pp[j] : 0u;
       mx[j] = j == 0 ? cp : umax(mx[j - 1], cp);  // running max of the carried-over positions
     }
@@ -684,7 +657,10 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
 #pragma unroll
     for (u32 j = 0; j < 4; ++j) {
       excl[j] = j == 0 ? lane_excl : umax(lane_excl, mx[j - 1]);
-      carried[j] = carried[j] && !(pp[j] < excl[j]);  // (an out-of-order unit never raises the maximum)
+      // (every out-of-order unit carries DISP_MARK: the extrusion sweep compares against ALL units
+      // of lower rank, this maximum runs over fewer.  Should one slip through, the count at the end
+      // does not add up and the general update takes over.)
+      carried[j] = carried[j] && !(pp[j] < excl[j]);
       nb[j] = lane_new;  // re-inserted units of this lane before unit j
       lane_new += (act4[j] && !carried[j]) ? 1u : 0u;
     }
@@ -835,7 +811,7 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
   const u32 n = wave::uniform(c.n_active);
   if (n < 2) return;
   {
-    const bool listed = !all_new && c.keys_valid && c.n_keys <= STAGE_CAP;
+    const bool listed = !all_new && c.keys_valid && c.disp_valid && c.n_keys <= STAGE_CAP;
     if (listed && rank_update_listed<FWD>(c)) {
       if (FWD) c.keys_valid = false;  // (the keys serve the rev update, then the fwd update)
       return;
@@ -3787,9 +3763,14 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
     r.fc = wave::ld4(ws.f_coll, wq);
     r.fI = wave::ld4(ws.f_id, wq);
   };
+  u32 run_max_r = 0, run_max_f = 0;  // highest position after the move among the units of lower rank
+  u32 n_disp_r = 0, n_disp_f = 0;
+  u64* const disp_keys_r = reinterpret_cast<u64*>(ws.tmp[6]);
+  u64* const disp_keys_f = reinterpret_cast<u64*>(ws.tmp[7]);
+  const u32 disp_cap = umin(STAGE_CAP, ws.capacity_lefs / 2);
   const auto process_block = [&](const UnitRegs& g, u32 t) {
       const u32 w = 256 * t + 4 * lane;
-      if (w < n) {
+      {
         wave::U32x4 nr, nf;
         bool rc_any = false, fc_any = false;
 #pragma unroll
@@ -3828,6 +3809,47 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
             }
           }
         }
+        // units that end up below a unit of lower rank: marked and listed for the next rank update
+        u32 mr[4], mf[4];
+#pragma unroll
+        for (u32 q = 0; q < 4; ++q) {
+          const bool act = w + q < n;
+          const u32 pr = (act && nr.v[q] != UNBOUND) ? nr.v[q] : 0u, pf = (act && nf.v[q] != UNBOUND) ? nf.v[q] : 0u;
+          mr[q] = q == 0 ? pr : umax(mr[q - 1], pr);
+          mf[q] = q == 0 ? pf : umax(mf[q - 1], pf);
+        }
+        const u32 sr = wave_prefix_max_u32(mr[3]), sf = wave_prefix_max_u32(mf[3]);
+        const u32 sr_prev = wave::shfl_up1(sr), sf_prev = wave::shfl_up1(sf);
+        const u32 excl_r = umax(run_max_r, lane > 0 ? sr_prev : 0u), excl_f = umax(run_max_f, lane > 0 ? sf_prev : 0u);
+        run_max_r = umax(run_max_r, wave::bcast(sr, 63));
+        run_max_f = umax(run_max_f, wave::bcast(sf, 63));
+        bool dr[4], df[4];
+        bool any_d = false;
+#pragma unroll
+        for (u32 q = 0; q < 4; ++q) {
+          const bool act = w + q < n;
+          dr[q] = act && nr.v[q] != UNBOUND && nr.v[q] < (q == 0 ? excl_r : umax(excl_r, mr[q - 1]));
+          df[q] = act && nf.v[q] != UNBOUND && nf.v[q] < (q == 0 ? excl_f : umax(excl_f, mf[q - 1]));
+          any_d = any_d || dr[q] || df[q];
+        }
+        if (wave::any(any_d)) {
+#pragma unroll
+          for (u32 q = 0; q < 4; ++q) {
+            const u64 mr_ = wave::ballot(dr[q]), mf_ = wave::ballot(df[q]);
+            if (dr[q]) {
+              const u32 e = n_disp_r + static_cast<u32>(wave::popc64(mr_ & lanemask_lt(lane)));
+              if (e < disp_cap) disp_keys_r[e] = (static_cast<u64>(nr.v[q]) << 32) | (w + q);
+              ws.r_move[w + q] = DISP_MARK;
+            }
+            if (df[q]) {
+              const u32 e = n_disp_f + static_cast<u32>(wave::popc64(mf_ & lanemask_lt(lane)));
+              if (e < disp_cap) disp_keys_f[e] = (static_cast<u64>(nf.v[q]) << 32) | (w + q);
+              ws.f_move[w + q] = DISP_MARK;
+            }
+            n_disp_r += static_cast<u32>(wave::popc64(mr_));
+            n_disp_f += static_cast<u32>(wave::popc64(mf_));
+          }
+        }
       }
   };
   {
@@ -3849,6 +3871,9 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
       }
     }
   }
+  c.n_disp[0] = n_disp_r;
+  c.n_disp[1] = n_disp_f;
+  c.disp_valid = n_disp_r <= disp_cap && n_disp_f <= disp_cap;
   wave::sync_mem();
   u32* list = reinterpret_cast<u32*>(c.lds.sort_lds);
   u32 n_rel = 0;
@@ -4450,6 +4475,9 @@ MODLE_DEV void init_cell(Cell& c, const Params& p, const Interval& iv, const Wor
   c.rel_valid = false;  // the epoch loop turns the list on; the phase-level hooks sweep
   c.keys_valid = false;
   c.n_keys = 0;
+  c.n_disp[0] = 0;
+  c.n_disp[1] = 0;
+  c.disp_valid = true;  // (nothing has been ranked yet: nothing can be out of order)
   c.n_bound = 0;
   c.inv_valid[0] = true;  // (reset_cell_buffers / run_test_phases write complete permutations)
   c.inv_valid[1] = true;

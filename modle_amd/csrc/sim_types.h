@@ -133,6 +133,9 @@ struct Workspace {
 constexpr u32 NUM_STATE_ARRAYS = 12 + NUM_TMP;
 // marker left in r_move / f_move by bind: "this unit was (re)bound this epoch"
 constexpr u32 NEW_MARK = 0xFFFFFFFFu;
+// ... and by the extrusion sweep: "this unit ended up below a unit of lower rank" (moves are
+// bounded by the interval's length, far below both marks)
+constexpr u32 DISP_MARK = 0xFFFFFFFEu;
 
 // LDS-resident (or host-emulated) per-wave context.
 struct WaveLds {
