@@ -46,7 +46,11 @@ def measured_traffic(workload_key):
     except (OSError, ValueError):
         return None
     entry = table.get(workload_key)
-    return entry["bytes_per_launch"] if entry else None
+    if not entry:
+        return None, None
+    # where and on which kernel it was measured: the figure is a committed measurement of another
+    # run (PMC counters cannot be collected from inside the benchmark), and the JSON line says so
+    return entry["bytes_per_launch"], f"{entry.get('source', 'profiles/')}; {entry.get('kernel', '')}"
 
 
 def parse_args():
@@ -375,6 +379,7 @@ def main():
             json.dump(sums, f)
 
     if rank == 0:
+        traffic_bytes, traffic_source = measured_traffic(f"{args.workload}:{cells_per_gpu}")
         out = {
             "metric": "simulated cells/sec (whole node), GRCh38 default barriers"
                       + (" [PHILOX generator policy: statistically equivalent output, not the "
@@ -405,7 +410,7 @@ def main():
                                       + " sum-reduce issued on a side stream as intervals complete"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(f"{args.workload}:{cells_per_gpu}"),
+                         "traffic": traffic_bytes, "traffic_source": traffic_source,
                          "kernel": "modle_simulate_cells",
                          "kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": step_bytes},
