@@ -65,6 +65,12 @@ CASES = {
     "mass_release": dict(size=120_000_000, barriers=True,
                          cfg=dict(num_cells=4, skip_burnin=1, avg_lef_processivity=8000,
                                   target_contact_density=0.0004)),
+    # more LEFs than the LDS id filters have bits (32768): ids that share a bit pass the filters
+    # together -- the release candidates' and the partner lookups' sweeps then store a few ranks
+    # nobody asked for, and nothing else may change
+    "many_lefs_hashed_filters": dict(size=50_000_000, barriers=True,
+                                     cfg=dict(num_cells=4, skip_burnin=1, number_of_lefs_per_mbp=700.0,
+                                              target_contact_density=0.02)),
     # a 4 Mb window that ends 10 Mb below the 32-bit position limit of the device layout, on a
     # chromosome longer than any real one: positions above 2^31 (the 64-bit scans of the move
     # adjustment, saturating key arithmetic in LEF-BAR detection)
