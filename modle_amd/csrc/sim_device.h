@@ -2846,242 +2846,17 @@ MODLE_DEV_NOINLINE void correct_moves_primary_standalone(Cell& c) {
 
 // process_secondary_lef_lef_collisions (reference: simulation_detect_collisions.cpp:400-515).
 // The pass is a chain: a stalled unit can stall its follower, which can stall the next one, and
-// every candidate consumes one Bernoulli draw in rank order.  Each batch of 64 consecutive ranks
-// is loaded into registers, a vector test discards the ranks that cannot be candidates and the
-// rest are walked in order with lane broadcasts.  Ranks whose collision was avoided are
-// appended to `list` (rank positions, visiting order) for fix_secondary.
+// every candidate consumes one Bernoulli draw in rank order.  Ranks whose collision was avoided
+// are appended to `list` (rank positions, visiting order) for fix_secondary.
 //
 // correct_moves_for_lef_bar_collisions (reference: simulation_correct_moves.cpp:19-50) is fused
-// into the load: a unit stalled by a barrier gets move = distance - 1.  (It has to come after
+// into the first pass: a unit stalled by a barrier gets move = distance - 1.  (It has to come after
 // primary detection, which tests the uncorrected moves.)
-template <bool FWD>
-MODLE_DEV_NOINLINE u32 process_secondary_dense(Cell& c, BoundaryCounts bc, u32* list, u32 list_cap,
-                                bool& overflow, bool correct_lef_bar, bool do_secondary) {
-  Workspace& ws = c.ws;
-  const Params& p = *c.p;
-  const u32 n = wave::uniform(c.n_active);
-  const u32 lane = wave::lane();
-  const u32* pos = FWD ? ws.f_pos : ws.r_pos;
-  const u32* ids = FWD ? ws.f_id : ws.r_id;
-  const u32* barpos = stalling_barrier_positions<FWD>(ws);
-  u32* moves = FWD ? ws.f_move : ws.r_move;
-  u32* coll = FWD ? ws.f_coll : ws.r_coll;
-  // run_lef_lef_collision_trial (simulation_impl.hpp:93-96): no draw when the bypass probability
-  // is 0 (always collide) -- and none when it is 1: bernoulli_distribution(0) returns false
-  // without touching the engine
-  const f64 p_collide = 1.0 - p.p_bypass;
-  const bool never_collide = p.p_bypass != 0.0 && p_collide == 0.0;
-  const bool trials = p.p_bypass != 0.0 && !never_collide;
-  u32 n_list = 0;
-  // rev: followers i = max(1, n5) .. n-1 ascending, blocker = rank i-1
-  // fwd: followers i-1 for i = (n - min(n3, n3-1) - 1) .. 1 descending, blocker = rank i
-  const i32 f_first = FWD ? static_cast<i32>(bc.n3 == 0 ? n - 1 : n - bc.n3) - 1
-                          : static_cast<i32>(umax(1u, bc.n5));
-  // every rank is visited in direction order (so that every LEF-BAR move gets corrected); only
-  // ranks from f_first on (in visiting order) can be followers
-  u32 carry_pos = 0, carry_move = 0, carry_coll = 0, carry_id = 0;
-  const u32 nbatch = (n + 63) / 64;
-  constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
-  struct UnitRegs {
-    u32 P[UX], I[UX], M[UX], C[UX], B[UX];
-  };
-  const auto load_units = [&](auto op, u32 bg, UnitRegs& r) {
-#pragma unroll
-    for (u32 u = 0; u < UX; ++u) {
-      const u32 bi = bg + u;
-      // (ranks stay far below 2^31: 32-bit index arithmetic)
-      const i32 kk = FWD ? static_cast<i32>(n) - 1 - static_cast<i32>(bi * 64 + lane)
-                         : static_cast<i32>(bi * 64 + lane);
-      const bool act = kk >= 0 && static_cast<u32>(kk) < n;
-      const u32 k = act ? static_cast<u32>(kk) : 0;
-      r.P[u] = op(pos, k, act, 0, r.P[u]);
-      r.I[u] = op(ids, k, act, 0, r.I[u]);
-      r.M[u] = op(moves, k, act, 0, r.M[u]);
-      r.C[u] = op(coll, k, act, 0, r.C[u]);
-      r.B[u] = op(barpos, k, act, 0, r.B[u]);
-    }
-  };
-  UnitRegs cur;
-  load_units(wave::LdRaw{}, 0, cur);
-  for (u32 bg = 0; bg < nbatch; bg += UX) {
-    UnitRegs g = cur;
-    load_units(wave::LdMask{}, bg, g);  // (defaults of the lanes outside the range)
-    if (bg + UX < nbatch) load_units(wave::LdRaw{}, bg + UX, cur);
-    const u32* Pq = g.P;
-    const u32* Iq = g.I;
-    const u32* Mq = g.M;
-    const u32* Cq = g.C;
-    const u32* Bq = g.B;
-#pragma unroll
-    for (u32 u = 0; u < UX; ++u) {
-      const u32 bi = bg + u;
-      if (bi >= nbatch) break;
-      // (ranks stay far below 2^31: 32-bit index arithmetic)
-      const i32 kk = FWD ? static_cast<i32>(n) - 1 - static_cast<i32>(bi * 64 + lane)
-                         : static_cast<i32>(bi * 64 + lane);
-      const bool act = kk >= 0 && static_cast<u32>(kk) < n;
-      const u32 k = act ? static_cast<u32>(kk) : 0;
-      const u32 P = Pq[u], id = Iq[u], M0 = Mq[u], C0 = Cq[u];
-      u32 M = M0, C = C0;
-      if (correct_lef_bar && act && cw_occurred_as(C, EV_LEF_BAR)) {
-        const u32 bp = Bq[u];
-        M = (FWD ? bp - P : P - bp) - 1;
-      }
-      const bool follower = do_secondary && act && (FWD ? (kk <= f_first) : (kk >= f_first));
-      // vector pre-filter: follower free and able to reach the blocker's current position
-      const u32 bp_in = wave::shfl_up1(P);
-      const u32 blocker_pos = lane > 0 ? bp_in : carry_pos;
-      const bool pot = follower && !cw_occurred(C) &&
-                       (FWD ? static_cast<u64>(P) + M >= blocker_pos
-                            : static_cast<u64>(P) - M <= blocker_pos);
-      // A follower only needs a closer look when its blocker is stalled already, or may become
-      // stalled in this pass because it is a candidate itself (cascade): propagate "blocker may
-      // be stalled" along runs of consecutive candidates with scalar bit operations.
-      const u64 potm = wave::ballot(pot);
-      const bool blk_occ_in = wave::shfl_up1(cw_occurred(C));
-      const u64 occm = wave::ballot(lane > 0 ? blk_occ_in : cw_occurred(carry_coll));
-      u64 pend = potm & occm;
-      for (;;) {
-        const u64 grown = pend | (potm & (pend << 1));
-        if (grown == pend) break;
-        pend = grown;
-      }
-      // Runs of consecutive pending lanes are chains: the first lane's blocker is stalled already,
-      // every other lane's blocker is the lane before it.  A chain collides lane by lane until a
-      // lane cannot reach its blocker's landing position or draws "avoid"; whatever follows in the
-      // run stays as it is (its blocker is not stalled).  While the chain holds, the blocker of the
-      // lane at offset d of its run lands d bp behind (rev) / ahead of (fwd) the landing position
-      // of the run's own blocker, so which lanes can draw at all follows from the positions and
-      // moves alone and is worked out once; the draws are then taken in lane order, all at once,
-      // and every "avoid" only drops the rest of its run and moves the later lanes to earlier raws.
-      // The lane-by-lane rounds below handle what this does not: a pending unit AT its blocker's
-      // position (a collision then moves it by 0, not by distance - 1) and moves that wrap.
-      if (pend != 0) {
-        const bool mine = ((pend >> lane) & 1u) != 0;
-        const bool odd = (mine && P == blocker_pos) || (act && (FWD ? P + M < P : M > P));
-        const bool carry_odd = FWD ? carry_pos + carry_move < carry_pos : carry_move > carry_pos;
-        if (!wave::any(odd) && !carry_odd) {
-          const u32 bI_in = wave::shfl_up1(id);
-          const u32 bId = lane > 0 ? bI_in : carry_id;
-          const u32 carry_land = FWD ? carry_pos + carry_move : carry_pos - carry_move;
-          const u64 lt = lanemask_lt(lane), le = lt | (u64(1) << lane);
-          const u64 starts = pend & ~(pend << 1), ends = pend & ~(pend >> 1);
-          const u32 s = mine ? static_cast<u32>(63 - wave::clz64(starts & le)) : lane;  // start of the lane's run
-          const u32 land = FWD ? P + M : P - M;  // (final for the lanes that are not pending)
-          const u32 lb_in = wave::shfl(land, s > 0 ? s - 1 : 0u);
-          const u32 lb = s > 0 ? lb_in : carry_land;
-          const u32 off = lane - s;
-          const u32 land_prev = FWD ? lb - off : lb + off;  // the blocker's landing while the chain holds
-          const bool geo = FWD ? (P + M >= land_prev) : (P - M <= land_prev);
-          const u64 ngeo = wave::ballot(mine && !geo);
-          const bool alive = mine && ((ngeo & le) >> s) == 0;  // no lane of the run up to here falls short
-          u64 live = wave::ballot(alive);  // lanes that draw unless an "avoid" before them ends their run
-          u64 hits = 0;                    // lanes that collide
-          u32 drawn = 0;                   // raws consumed
-          while (live != 0) {
-            bool outcome = !never_collide;
-            if (trials) {
-              rng_ensure(c.g, drawn + static_cast<u32>(wave::popc64(live)));
-              const u32 tq = drawn + static_cast<u32>(wave::popc64(live & lt));
-              outcome = bernoulli_raw(rng_peek(c.g, c.g.pos + tq), p_collide);
-            }
-            const u64 av = wave::ballot(((live >> lane) & 1u) != 0 && !outcome);
-            if (av == 0) {
-              hits |= live;
-              drawn += static_cast<u32>(wave::popc64(live));
-              break;
-            }
-            const u32 a = static_cast<u32>(wave::ctz64(av));                       // the first "avoid"
-            const u32 e = static_cast<u32>(wave::ctz64(ends & ~lanemask_lt(a)));  // end of its run
-            hits |= live & lanemask_lt(a);
-            drawn += static_cast<u32>(wave::popc64(live & lanemask_lt(a))) + 1;
-            if (lane == a) {
-              C = cw_make(bId, EV_LEF_LEF_SECONDARY);
-              if (n_list < list_cap) list[n_list] = k;
-              if (c.filter_on) {
-                rank_filter_add_id(c, id);
-                rank_filter_add_id(c, bId);
-              }
-            }
-            ++n_list;
-            if (n_list > list_cap) overflow = true;
-            live = e >= 63 ? u64(0) : live & ~lanemask_lt(e + 1);
-          }
-          if (trials && drawn != 0) rng_advance(c.g, drawn);
-          if ((hits >> lane) & 1u) {
-            const u32 move = FWD ? land_prev - P : P - land_prev;
-            M = umin(move, move - 1);
-            C = cw_make(bId, EV_COLLISION | EV_LEF_LEF_SECONDARY);
-          }
-          pend = 0;
-        }
-      }
-      // Rounds: a pending lane is ready when its blocker (the lane before it) is not pending any
-      // more; all ready lanes below the first lane that still waits are resolved together, their
-      // Bernoulli draws numbered in lane order (the reference's visiting order).  A batch
-      // without cascades takes one round.
-      while (pend != 0) {
-        const u32 bP_in = wave::shfl_up1(P), bM_in = wave::shfl_up1(M);
-        const u32 bC_in = wave::shfl_up1(C), bI_in = wave::shfl_up1(id);
-        const u32 bP = lane > 0 ? bP_in : carry_pos;
-        const u32 bM = lane > 0 ? bM_in : carry_move;
-        const u32 bC = lane > 0 ? bC_in : carry_coll;
-        const u32 bId = lane > 0 ? bI_in : carry_id;
-        const u64 ready = pend & ~(pend << 1);
-        const u64 waiting = pend & ~ready;
-        const u64 now =
-            waiting != 0 ? (ready & lanemask_lt(static_cast<u32>(wave::ctz64(waiting)))) : ready;
-        const bool mine = ((now >> lane) & 1u) != 0;
-        const bool geo = FWD ? (static_cast<u64>(P) + M >= static_cast<u64>(bP) + bM)
-                             : (static_cast<u64>(P) - M <= static_cast<u64>(bP) - bM);
-        const bool draws = mine && cw_occurred(bC) && geo;
-        const u64 dm = wave::ballot(draws);
-        bool collide = draws && !never_collide;
-        if (trials && dm != 0) {
-          const u32 cnt = static_cast<u32>(wave::popc64(dm));
-          rng_ensure(c.g, cnt);
-          const u32 t = static_cast<u32>(wave::popc64(dm & lanemask_lt(lane)));
-          collide = draws && bernoulli_raw(rng_peek(c.g, c.g.pos + t), p_collide);
-          rng_advance(c.g, cnt);
-        }
-        const bool avoided = draws && !collide;
-        if (collide) {
-          const u32 move = FWD ? (bP + bM) - P : P - (bP - bM);
-          M = umin(move, move - 1);
-          C = cw_make(bId, EV_COLLISION | EV_LEF_LEF_SECONDARY);
-        }
-        const u64 am = wave::ballot(avoided);
-        if (avoided) {
-          C = cw_make(bId, EV_LEF_LEF_SECONDARY);
-          const u32 j = n_list + static_cast<u32>(wave::popc64(am & lanemask_lt(lane)));
-          if (j < list_cap) list[j] = k;
-          if (c.filter_on) {
-            rank_filter_add_id(c, id);
-            rank_filter_add_id(c, bId);
-          }
-        }
-        n_list += static_cast<u32>(wave::popc64(am));
-        if (n_list > list_cap) overflow = true;
-        pend &= ~now;
-      }
-      if (act && (M != M0 || C != C0)) {
-        moves[k] = M;
-        coll[k] = C;
-      }
-      carry_pos = wave::bcast(P, 63);
-      carry_move = wave::bcast(M, 63);
-      carry_coll = wave::bcast(C, 63);
-      carry_id = wave::bcast(id, 63);
-    }
-  }
-  wave::sync_mem();
-  return n_list;
-}
-
-// The same in two passes.  Nearly every batch of 64 consecutive ranks holds a few candidates (units
-// queued behind a stalled unit try again in every epoch), so the dense form above runs its chain
-// resolution -- a long dependent sequence of ballots, scalar bit operations, LDS reads and draws --
-// once per batch for a handful of useful lanes.  Here the first pass only corrects the LEF-BAR
+//
+// Two passes.  Nearly every batch of 64 consecutive ranks holds a few candidates (units
+// queued behind a stalled unit try again in every epoch), so a one-pass form (rounds 1-2) ran its
+// chain resolution -- a long dependent sequence of ballots, scalar bit operations, LDS reads and
+// draws -- once per batch for a handful of useful lanes.  The first pass only corrects the LEF-BAR
 // moves and FILTERS: the candidates (a superset: units that can reach their blocker's position and
 // whose blocker is, or may become, stalled) are appended in visiting order to a compact list of
 // ranks in device scratch.  The second pass resolves 64 CANDIDATES at a time: it gathers their
@@ -3215,8 +2990,7 @@ struct SecondaryFilter {
 // Pass 2 of one direction over the `n_cand` candidates pass 1 listed in ws.tmp[0] (rev) /
 // ws.tmp[1] (fwd).
 template <bool FWD>
-MODLE_DEV_NOINLINE u32 secondary_resolve(Cell& c, BoundaryCounts bc, u32 n_cand, u32* list, u32 list_cap,
-                                         bool& overflow, bool correct_lef_bar, bool do_secondary) {
+MODLE_DEV_NOINLINE u32 secondary_resolve(Cell& c, u32 n_cand, u32* list, u32 list_cap, bool& overflow) {
   Workspace& ws = c.ws;
   const Params& p = *c.p;
   const u32 lane = wave::lane();
@@ -3232,10 +3006,9 @@ MODLE_DEV_NOINLINE u32 secondary_resolve(Cell& c, BoundaryCounts bc, u32 n_cand,
   const bool never_collide = p.p_bypass != 0.0 && p_collide == 0.0;
   const bool trials = p.p_bypass != 0.0 && !never_collide;
   if (n_cand == 0) return 0;
-  if (n_cand > list_cap) {
-    // (more candidates than the scratch holds: the dense form redoes the pass -- the LEF-BAR
-    // correction is idempotent, nothing else has been written)
-    return process_secondary_dense<FWD>(c, bc, list, list_cap, overflow, correct_lef_bar, do_secondary);
+  if (n_cand > list_cap) {  // (cannot happen: a candidate is an active unit, the list holds capacity_lefs)
+    c.error = ERR_INTERNAL;
+    return 0;
   }
 
   u32 n_list = 0;
@@ -3436,7 +3209,7 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
   f.init(c, bc, list_cap, correct_lef_bar, do_secondary);
   for (u32 bg = 0; bg < f.nbatch; bg += SecondaryFilter<FWD>::UX) f.step(bg);
   wave::sync_mem();
-  return secondary_resolve<FWD>(c, bc, f.n_cand, list, list_cap, overflow, correct_lef_bar, do_secondary);
+  return secondary_resolve<FWD>(c, f.n_cand, list, list_cap, overflow);
 }
 
 // both directions: the two filters in one loop, then the rev and the fwd resolve pass (draw order)
@@ -3457,8 +3230,8 @@ MODLE_DEV_NOINLINE void process_secondary_both(Cell& c, BoundaryCounts bc, u32* 
 #ifdef MODLE_PHASE_TIMERS
   c.ph[14] += wave::clock() - t_pass1;  // (sub_a: the filter pass; the rest of the phase is pass 2)
 #endif
-  n_rev = secondary_resolve<false>(c, bc, fr.n_cand, list_rev, list_cap, overflow, true, true);
-  n_fwd = secondary_resolve<true>(c, bc, ff.n_cand, list_fwd, list_cap, overflow, true, true);
+  n_rev = secondary_resolve<false>(c, fr.n_cand, list_rev, list_cap, overflow);
+  n_fwd = secondary_resolve<true>(c, ff.n_cand, list_fwd, list_cap, overflow);
 }
 
 // fix_secondary_lef_lef_collisions (reference: simulation_detect_collisions.cpp:517-644).
