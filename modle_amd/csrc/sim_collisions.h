@@ -1,0 +1,1765 @@
+// sim_collisions.h -- part of sim_device.h (included by it, in this order): process_collisions: boundaries, LEF-BAR, primary and secondary LEF-LEF collisions, fix_secondary.
+#pragma once
+
+namespace modle_dev {
+
+// =============================================================================================
+// process_collisions (reference: simulation.cpp:763-793 and simulation_detect_collisions.cpp)
+// =============================================================================================
+struct BoundaryCounts {
+  u32 n5, n3;
+};
+
+// detect_units_at_interval_boundaries (reference: simulation_detect_collisions.cpp:25-120)
+MODLE_DEV_NOINLINE BoundaryCounts detect_boundaries(Cell& c) {
+  Workspace& ws = c.ws;
+  const u32 n = wave::uniform(c.n_active);
+  const u32 lane = wave::lane();
+  const u32 start = c.iv->start, last = c.iv->end - 1;
+  const u32 first_fwd_pos = ws.f_pos[0];
+  // position of the last bound unit in rev rank order
+  u32 last_rev_pos = 0;
+  for (u32 top = n; top > 0;) {
+    const u32 cnt = umin(64u, top);
+    const bool act = lane < cnt;
+    const u32 P = wave::ld_sel(ws.r_pos, top - 1 - lane, act, UNBOUND);  // descending ranks
+    const u64 m = wave::ballot(act && P != UNBOUND);
+    if (m != 0) {
+      last_rev_pos = wave::bcast(P, static_cast<u32>(wave::ctz64(m)));
+      break;
+    }
+    top -= cnt;
+  }
+  BoundaryCounts out{0, 0};
+  const u32 mark5 = cw_make(5, EV_COLLISION | EV_CHROM_BOUNDARY);
+  const u32 mark3 = cw_make(3, EV_COLLISION | EV_CHROM_BOUNDARY);
+  for (u32 base = 0; base < n; base += 64) {
+    const u32 k = base + lane;
+    const bool act = k < n;
+    const u32 P = wave::ld_sel(ws.r_pos, k, act, 0);
+    const u32 M = wave::ld_sel(ws.r_move, k, act, 0);
+    const bool at = act && P == start;
+    const bool brk_b = act && !at && P > first_fwd_pos;
+    const bool brk_c = act && !at && !brk_b && P - M == start;
+    const u64 stop = wave::ballot(brk_b || brk_c);
+    const u32 s = stop != 0 ? static_cast<u32>(wave::ctz64(stop)) : 64u;
+    const bool mark = act && ((lane < s && at) || (lane == s && brk_c));
+    if (mark) ws.r_coll[k] = mark5;
+    out.n5 += static_cast<u32>(wave::popc64(wave::ballot(mark)));
+    if (stop != 0) break;
+  }
+  // fwd units: ranks n-1 down to 1 (rank 0 is never visited, simulation_detect_collisions.cpp:91)
+  for (u32 top = n; top > 1;) {
+    const u32 cnt = umin(64u, top - 1);
+    const u32 k = top - 1 - lane;
+    const bool act = lane < cnt;
+    const u32 P = wave::ld_sel(ws.f_pos, k, act, 0);
+    const u32 M = wave::ld_sel(ws.f_move, k, act, 0);
+    const bool bnd = act && P != UNBOUND;
+    const bool unb = act && !bnd;
+    const bool at = bnd && P == last;
+    const bool brk_b = bnd && !at && P < last_rev_pos;
+    const bool brk_c = bnd && !at && !brk_b && P + M == last;
+    const u64 stop = wave::ballot(brk_b || brk_c);
+    const u32 s = stop != 0 ? static_cast<u32>(wave::ctz64(stop)) : 64u;
+    const bool mark = (lane < s && at) || (lane == s && brk_c);
+    if (mark) ws.f_coll[k] = mark3;
+    out.n3 += static_cast<u32>(wave::popc64(wave::ballot(mark || (lane < s && unb))));
+    if (stop != 0) break;
+    top -= cnt;
+  }
+  wave::sync_mem();
+  return out;
+}
+
+// detect_lef_bar_collisions (reference: simulation_detect_collisions.cpp:123-247), evaluated
+// per extrusion unit: barrier b is tested against the first rev unit downstream of it (first fwd
+// unit upstream), so the barriers that can stall the unit of rank j are those between the unit
+// of rank j-1 and itself that lie within its move.  Bernoulli trials (pblock not in {0,1}) are
+// numbered in the reference's order: barriers ascending for rev units, descending for fwd units.
+//
+// The barriers a batch of 64 consecutive ranks can touch form one index range that continues
+// where the previous batch stopped.  A window of BAR_WIN barriers (position and a flag word:
+// state, blocking direction) is staged in LDS with one coalesced load and all per-unit searches
+// run there; a batch whose units need more than the window falls back to device memory.
+// The window lives in the LDS sort buffer (idle during the collision passes): BAR_WIN positions
+// followed by BAR_WIN flag words.  It is re-staged only when a batch starts closer than BAR_NEED
+// barriers to its far edge.
+constexpr u32 BAR_WIN = SORT_LDS_CAP;  // SORT_LDS_CAP u64 keys = 2 * BAR_WIN words
+constexpr u32 BAR_NEED = 128;
+
+// Position of the barrier that stalls the unit of rank k (valid where the collision word says
+// LEF-BAR), written by detect_lef_bar for the passes that correct moves.  Lives in ranking
+// scratch, which is idle during the collision passes.
+template <bool FWD>
+MODLE_DEV u32* stalling_barrier_positions(const Workspace& ws) {
+  return FWD ? ws.tmp[4] : ws.tmp[3];
+}
+
+// Barriers [s0, s1) are staged.  STAGED_ONLY accessors assume the index is inside the staged
+// range (the caller has checked that the whole batch stays inside); the general ones read
+// everything else from device memory.
+struct BarView {
+  const Interval* iv;
+  const u8* active;
+  const u32* st_pos;
+  const u32* st_flag;
+  u32 s0, s1;
+  template <bool STAGED_ONLY>
+  MODLE_DEV_MEMBER u32 pos(u32 b) const {
+    if (STAGED_ONLY) return st_pos[b - s0];
+    return (b >= s0 && b < s1) ? st_pos[b - s0] : iv->bar_pos[b];
+  }
+  // bit 0: active, bits 1..2: blocking direction
+  template <bool STAGED_ONLY>
+  MODLE_DEV_MEMBER u32 flag(u32 b) const {
+    if (STAGED_ONLY) return st_flag[b - s0];
+    return (b >= s0 && b < s1) ? st_flag[b - s0]
+                               : (static_cast<u32>(active[b] != 0) | (static_cast<u32>(iv->bar_dir[b]) << 1));
+  }
+};
+
+// first barrier index in [lo, hi) whose position is >= key (hi when there is none)
+template <bool STAGED_ONLY>
+MODLE_DEV u32 bar_view_lower_bound(const BarView& v, u32 lo, u32 hi, u64 key) {
+  while (lo < hi) {
+    const u32 mid = (lo + hi) >> 1;
+    if (v.pos<STAGED_ONLY>(mid) < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// Barrier index window [b_lo, b_hi) of one unit: lo_key <= position < hi_key.  With STAGED_ONLY
+// the search stays inside the staged range and reports `edge` when the answer touches an edge
+// beyond which more barriers exist (the batch is then redone with the general accessors).
+template <bool FWD, bool STAGED_ONLY>
+MODLE_DEV void lef_bar_window(const BarView& v, u32 nb, u32 anchor, u64 lo_key, u64 hi_key,
+                              u32& b_lo, u32& b_hi, bool& edge) {
+  edge = false;
+  if (!FWD) {
+    if (STAGED_ONLY) {
+      // the answer is almost always within a few dozen barriers of the batch's anchor
+      const u32 near = umin(anchor + BAR_NEED, v.s1);
+      b_lo = bar_view_lower_bound<true>(v, anchor, near, lo_key);
+      if (b_lo == near && near < v.s1) b_lo = bar_view_lower_bound<true>(v, near, v.s1, lo_key);
+    } else {
+      b_lo = bar_view_lower_bound<false>(v, v.s0, v.s1, lo_key);
+    }
+    if (b_lo == v.s1 && v.s1 < nb) {
+      if (STAGED_ONLY) {
+        edge = true;
+        b_hi = b_lo;
+        return;
+      }
+      b_lo = bar_view_lower_bound<false>(v, v.s1, nb, lo_key);
+    }
+    b_hi = b_lo;
+    const u32 lim = STAGED_ONLY ? v.s1 : nb;
+    while (b_hi < lim && v.pos<STAGED_ONLY>(b_hi) < hi_key) ++b_hi;
+    if (STAGED_ONLY && b_hi == v.s1 && v.s1 < nb) edge = true;
+  } else {
+    if (STAGED_ONLY) {
+      const u32 near = anchor > v.s0 + BAR_NEED ? anchor - BAR_NEED : v.s0;
+      b_hi = bar_view_lower_bound<true>(v, near, anchor, hi_key);
+      if (b_hi == near && near > v.s0) b_hi = bar_view_lower_bound<true>(v, v.s0, near, hi_key);
+    } else {
+      b_hi = bar_view_lower_bound<false>(v, v.s0, v.s1, hi_key);
+    }
+    if (b_hi == v.s0 && v.s0 > 0) {
+      if (STAGED_ONLY) {
+        edge = true;
+        b_lo = b_hi;
+        return;
+      }
+      b_hi = bar_view_lower_bound<false>(v, 0, v.s0, hi_key);
+    }
+    b_lo = b_hi;
+    const u32 lim = STAGED_ONLY ? v.s0 : 0;
+    while (b_lo > lim && v.pos<STAGED_ONLY>(b_lo - 1) >= lo_key) --b_lo;
+    if (STAGED_ONLY && b_lo == v.s0 && v.s0 > 0) edge = true;
+  }
+}
+
+// Bernoulli trials of one unit: how many it consumes (count_only) or which barrier stalls it
+template <bool FWD, bool STAGED_ONLY>
+MODLE_DEV u32 lef_bar_count_trials(const BarView& v, const Params& p, u32 b_lo, u32 b_hi) {
+  const u32 major_dir = FWD ? DIR_FWD : DIR_REV;
+  u32 ntr = 0;
+  for (u32 b = b_lo; b < b_hi; ++b) {
+    const u32 fl = v.flag<STAGED_ONLY>(b);
+    const f64 pb = (fl >> 1) == major_dir ? p.pblock_major : p.pblock_minor;
+    ntr += ((fl & 1u) && pb != 1.0 && pb != 0.0) ? 1u : 0u;
+  }
+  return ntr;
+}
+
+template <bool FWD, bool STAGED_ONLY>
+MODLE_DEV u32 lef_bar_pick(const BarView& v, const Params& p, const Rng& g, u32 b_lo, u32 b_hi,
+                           u32 trial_off, bool& hard, u32& bpos) {
+  const u32 major_dir = FWD ? DIR_FWD : DIR_REV;
+  u32 winner = 0xFFFFFFFFu;
+  u32 t = 0;
+  for (u32 q = b_lo; q < b_hi; ++q) {
+    const u32 b = FWD ? (b_hi - 1 - (q - b_lo)) : q;  // reference visiting order
+    const u32 fl = v.flag<STAGED_ONLY>(b);
+    if (!(fl & 1u)) continue;
+    const f64 pb = (fl >> 1) == major_dir ? p.pblock_major : p.pblock_minor;
+    bool hit;
+    if (pb == 1.0) {
+      hit = true;
+    } else if (pb == 0.0) {
+      hit = false;
+    } else {
+      hit = bernoulli_raw(rng_peek(g, g.pos + trial_off + t), pb);
+      ++t;
+    }
+    if (hit) {  // later visits overwrite earlier ones
+      winner = b;
+      hard = (fl >> 1) == major_dir;
+    }
+  }
+  if (winner != 0xFFFFFFFFu) bpos = v.pos<STAGED_ONLY>(winner);
+  return winner;
+}
+
+// ---------------------------------------------------------------------------------------------
+// detect_lef_bar_collisions when both blocking probabilities are 0 or 1 (the reference default:
+// major 1, minor 0): no Bernoulli trial is drawn and a barrier stalls a unit iff it is active
+// and the probability that applies to its direction is 1.  Of the barriers in a unit's window the
+// reference keeps the one it visits last: the highest such barrier for a rev unit, the lowest
+// for a fwd unit.  The stalling barriers are therefore compacted (position, index | hard << 31)
+// into the LDS window, in ascending order, and a unit needs one search there and one test.
+//
+// The compacted window holds every stalling barrier with index in [s0, s1); it serves any unit
+// window [lo, hi) with lo >= lo_cover and hi <= hi_cover.  Unit windows are disjoint and ordered
+// like the ranks, so every batch continues the search where the previous one stopped; a batch
+// whose windows do not fit is looked up in device memory.
+// ---------------------------------------------------------------------------------------------
+constexpr u32 HITBAR_NEAR = 127;
+
+// Copies `cnt` (<= BAR_WIN) list entries into the LDS window: all loads in flight, then the LDS
+// writes.  A real call: it runs a few times per pass and its registers stay out of the pass's
+// allocation.
+MODLE_DEV_CALL void stage_stalling_window_call(MODLE_LDS u32* cp, MODLE_LDS u32* ci,
+                                               const u32* hpos, const u32* hidx, u32 cnt) {
+  const u32 lane = wave::lane();
+  const u32* gp = wave::as_global(hpos);
+  const u32* gi = wave::as_global(hidx);
+  u32 Hp[BAR_WIN / 64], Hi[BAR_WIN / 64];
+#pragma unroll
+  for (u32 t = 0; t < BAR_WIN / 64; ++t) {
+    const u32 e = lane + 64 * t;
+    Hp[t] = e < cnt ? gp[e] : 0;
+    Hi[t] = e < cnt ? gi[e] : 0;
+  }
+#pragma unroll
+  for (u32 t = 0; t < BAR_WIN / 64; ++t) {
+    const u32 e = lane + 64 * t;
+    if (e < cnt) {
+      cp[e] = Hp[t];
+      ci[e] = Hi[t];
+    }
+  }
+}  // entries next to the anchor that the fixed-step search covers
+
+template <bool FWD>
+MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
+  Workspace& ws = c.ws;
+  const Interval& iv = *c.iv;
+  const Params& p = *c.p;
+  const u32 n = wave::uniform(c.n_active);
+  const u32 nb = wave::uniform(iv.n_barriers);
+  const bool major_hits = p.pblock_major == 1.0, minor_hits = p.pblock_minor == 1.0;
+  if (!major_hits && !minor_hits) return;  // no barrier ever stalls a unit
+  const u32 major_dir = FWD ? DIR_FWD : DIR_REV;
+  const u32 lane = wave::lane();
+  const u32* pos = FWD ? ws.f_pos : ws.r_pos;
+  const u32* moves = FWD ? ws.f_move : ws.r_move;
+  u32* coll = FWD ? ws.f_coll : ws.r_coll;
+  u32* barpos = stalling_barrier_positions<FWD>(ws);
+  u32* cp = reinterpret_cast<u32*>(c.lds.sort_lds);  // positions of the compacted barriers
+  u32* ci = cp + BAR_WIN;                              // their indices (| HITBAR_HARD)
+  const u32 j_rev0 = bc.n5 == 0 ? 0 : bc.n5 - 1;
+  const u32 j_fwd0 = bc.n3 == 0 ? n - 1 : n - bc.n3;
+  u32 carry_pos = 0;
+  const u32 nh = wave::uniform(c.n_hit[FWD ? 1 : 0]);
+  if (nh == 0 || n == 0) return;  // no barrier stalls a unit of this direction in this epoch
+  const u32* hpos = ws.hit_pos[FWD ? 1 : 0];
+  const u32* hidx = ws.hit_idx[FWD ? 1 : 0];
+  constexpr u32 c0 = 0;
+  u32 g0 = 0, g1 = 0, cnt = 0;      // the window holds list entries [g0, g1): cp[0 .. cnt)
+  bool staged = false;
+  u32 lo_cover = 1, hi_cover = 0;   // nothing staged yet (0xFFFFFFFF: no bound)
+  u32 anchor = 0;                   // rev: entries below it lie before the batch; fwd: entries at
+                                    // or above it lie beyond the batch (relative to c0)
+  // Four consecutive ranks per lane, blocks of 256 ranks on 256-rank boundaries (128-bit loads);
+  // rev: ranks ascending from j_rev0, fwd: ranks descending from j_fwd0 (lane 0 holds the highest
+  // ranks of a block and walks its four units downwards).  Ranks outside the sweep are masked.
+  const u32 b_first = (FWD ? j_fwd0 : j_rev0) / 256;
+  const u32 nblk = FWD ? b_first + 1 : (n + 255) / 256 - b_first;
+  const auto word0 = [&](u32 t) { return (FWD ? b_first - t : b_first + t) * 256 + 4 * (FWD ? 63 - lane : lane); };
+  struct Blk {
+    wave::U32x4 P, M;
+  };
+  const auto load_blk = [&](u32 t, Blk& r) {
+    const u32 w = word0(t);
+    const u32 wq = w < n ? w : 0u;
+    r.P = wave::ld4(pos, wq);
+    r.M = wave::ld4(moves, wq);
+  };
+  Blk cur;
+  load_blk(0, cur);
+  for (u32 t = 0; t < nblk; ++t) {
+    const Blk g = cur;
+    if (t + 1 < nblk) load_blk(t + 1, cur);
+    const u32 w = word0(t);
+    u32 k[4], P[4], lo_key[4], hi_key[4];
+    bool bnd[4];
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j) {  // j: position in sweep order inside the lane
+      const u32 q = FWD ? 3 - j : j;
+      k[j] = w + q;
+      const bool act = FWD ? k[j] <= j_fwd0 : (k[j] >= j_rev0 && k[j] < n);
+      P[j] = act ? g.P.v[q] : 0u;
+      bnd[j] = act && P[j] != UNBOUND;
+    }
+    const u32 nbr_in = wave::shfl_up1(P[3]);
+    const u32 nbr0 = lane > 0 ? nbr_in : carry_pos;
+    carry_pos = wave::bcast(P[3], 63);
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j) {
+      const u32 q = FWD ? 3 - j : j;
+      const u32 M = g.M.v[q];
+      const bool first = k[j] == (FWD ? j_fwd0 : j_rev0);
+      const u32 nbr = j == 0 ? nbr0 : P[j - 1];
+      // see detect_lef_bar; 32-bit keys: positions lie below 2^32 - 2 (the host rejects longer
+      // intervals), and a reach beyond that is as good as 2^32 - 2
+      lo_key[j] = 0;
+      hi_key[j] = 0;
+      if (bnd[j]) {
+        if (!FWD) {
+          const u32 reach = P[j] - M;
+          lo_key[j] = first ? reach : umax(reach, nbr);
+          hi_key[j] = P[j];
+        } else {
+          const u32 sum = P[j] + M;
+          const u32 reach = (sum < P[j] || sum > 0xFFFFFFFEu) ? 0xFFFFFFFEu : sum;
+          lo_key[j] = P[j] + 1;
+          hi_key[j] = (first ? reach : umin(reach, nbr)) + 1;
+        }
+      }
+    }
+    const u64 bm = wave::ballot(bnd[0] || bnd[1] || bnd[2] || bnd[3]);
+    if (bm == 0) continue;
+    const u32 l_first = static_cast<u32>(wave::ctz64(bm));
+    const u32 l_last = static_cast<u32>(63 - wave::clz64(bm));
+    // keys of the lane's first / last bound unit in sweep order
+    const u32 jf = bnd[0] ? 0u : bnd[1] ? 1u : bnd[2] ? 2u : 3u;
+    const u32 jl = bnd[3] ? 3u : bnd[2] ? 2u : bnd[1] ? 1u : 0u;
+    const u32 lo_f = jf == 0 ? lo_key[0] : jf == 1 ? lo_key[1] : jf == 2 ? lo_key[2] : lo_key[3];
+    const u32 hi_f = jf == 0 ? hi_key[0] : jf == 1 ? hi_key[1] : jf == 2 ? hi_key[2] : hi_key[3];
+    const u32 lo_l = jl == 3 ? lo_key[3] : jl == 2 ? lo_key[2] : jl == 1 ? lo_key[1] : lo_key[0];
+    const u32 hi_l = jl == 3 ? hi_key[3] : jl == 2 ? hi_key[2] : jl == 1 ? hi_key[1] : hi_key[0];
+    // keys the block spans (sweep order holds ascending positions for rev, descending for fwd)
+    const u32 need_lo = FWD ? wave::bcast(lo_l, l_last) : wave::bcast(lo_f, l_first);
+    const u32 need_hi = FWD ? wave::bcast(hi_f, l_first) : wave::bcast(hi_l, l_last);
+    if (need_lo < lo_cover || need_hi > hi_cover) {
+      // Move the window along the list to where this block starts (one coalesced load of
+      // positions and indices).  Entries the window has already passed are dropped by counting;
+      // when the block lies beyond the whole window, the window keeps moving.
+      u32 moved = 0;
+      for (;;) {
+        if (staged) {
+          // window entries before the block (rev: below need_lo; fwd: below need_hi)
+          const u32 key = FWD ? need_hi : need_lo;
+          u32 below = 0;
+#pragma unroll
+          for (u32 e0 = 0; e0 < BAR_WIN / 64; ++e0) {
+            const u32 e = lane + 64 * e0;
+            const u32 ce = cp[e];  // (e < BAR_WIN: inside the window whatever cnt is)
+            below += static_cast<u32>(wave::popc64(wave::ballot((e < cnt) & (ce < key))));
+          }
+          if (!FWD) {
+            g0 += below;
+          } else {
+            g1 = g0 + below;
+          }
+        } else {
+          if (FWD) g1 = nh; else g0 = 0;
+        }
+        if (!FWD) {
+          g1 = umin(g0 + BAR_WIN, nh);
+        } else {
+          g0 = g1 > BAR_WIN ? g1 - BAR_WIN : 0;
+        }
+        cnt = g1 - g0;
+        wave::lockstep();
+        {
+          // what the window does not hold: everything before it lies below lo_cover,
+          // everything after it at or above hi_cover
+          const u32 edge_lo = g0 > 0 ? hpos[g0 - 1] : 0;
+          const u32 edge_hi = g1 < nh ? hpos[g1] : 0;
+          stage_stalling_window_call((MODLE_LDS u32*)cp, (MODLE_LDS u32*)ci, hpos + g0, hidx + g0, cnt);
+          lo_cover = g0 > 0 ? wave::uniform(edge_lo) + 1 : 0;
+          hi_cover = g1 < nh ? wave::uniform(edge_hi) : 0xFFFFFFFFu;
+        }
+        wave::sync_lds();
+        staged = true;
+        anchor = FWD ? cnt : 0;
+        // done unless the block starts beyond this window and the list goes on
+        const bool beyond = FWD ? (need_hi <= lo_cover && g0 > 0) : (need_lo >= hi_cover && g1 < nh);
+        if (!beyond || ++moved > 64) break;  // (a block that is still not covered is looked up in device memory)
+      }
+    }
+    u32 winner[4], bpos[4];
+    bool hard[4];
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j) {
+      winner[j] = 0xFFFFFFFFu;
+      bpos[j] = 0;
+      hard[j] = false;
+    }
+    if (need_lo >= lo_cover && need_hi <= hi_cover) {
+      // four searches side by side, all from the anchor the previous block left
+      u32 q[4];
+#pragma unroll
+      for (u32 j = 0; j < 4; ++j) q[j] = anchor;
+      if (!FWD) {
+        // q = number of entries before the unit: the last of them is the candidate
+#pragma unroll
+        for (u32 sft = 64; sft >= 1; sft >>= 1) {
+          // (the four reads of a round are issued together: left alone the compiler waits for each)
+          u32 jx[4], kv[4];
+          bool in[4];
+#pragma unroll
+          for (u32 j = 0; j < 4; ++j) {
+            jx[j] = q[j] + sft;
+            in[j] = bnd[j] & (jx[j] <= cnt);
+            kv[j] = cp[c0 + (in[j] ? jx[j] - 1 : 0)];  // (no branch around the read)
+          }
+          wave::sched_fence();
+#pragma unroll
+          for (u32 j = 0; j < 4; ++j) {
+            if (in[j] & (kv[j] < hi_key[j])) q[j] = jx[j];
+          }
+          wave::sched_fence();
+        }
+        bool far = false;  // the fixed steps ran out: finish with a binary search (rare)
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) far = far || (bnd[j] && q[j] == anchor + HITBAR_NEAR && q[j] < cnt);
+        if (wave::any(far)) {
+#pragma unroll
+          for (u32 j = 0; j < 4; ++j) {
+            if (bnd[j] && q[j] == anchor + HITBAR_NEAR && q[j] < cnt) {
+              u32 hi = cnt;
+              u32 l = q[j];
+              while (l < hi) {
+                const u32 mid = (l + hi) >> 1;
+                if (cp[c0 + mid] < hi_key[j]) l = mid + 1; else hi = mid;
+              }
+              q[j] = l;
+            }
+          }
+        }
+        // the candidates of the four units: position and index read together, then tested
+        u32 bp[4], wd[4];
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          const u32 e = c0 + (q[j] > 0 ? q[j] - 1 : 0);
+          bp[j] = cp[e];
+          wd[j] = ci[e];
+        }
+        wave::sched_fence();
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          if (bnd[j] & (q[j] > 0) & (bp[j] >= lo_key[j])) {
+            winner[j] = wd[j] & ~HITBAR_HARD;
+            hard[j] = (wd[j] & HITBAR_HARD) != 0;
+            bpos[j] = bp[j];
+          }
+        }
+      } else {
+        // q = number of entries at or before the unit: entry q is the candidate
+#pragma unroll
+        for (u32 sft = 64; sft >= 1; sft >>= 1) {
+          u32 kv[4];
+          bool in[4];
+#pragma unroll
+          for (u32 j = 0; j < 4; ++j) {
+            in[j] = bnd[j] & (q[j] >= sft);
+            kv[j] = cp[c0 + (in[j] ? q[j] - sft : 0)];  // (no branch around the read)
+          }
+          wave::sched_fence();
+#pragma unroll
+          for (u32 j = 0; j < 4; ++j) {
+            if (in[j] & (kv[j] >= lo_key[j])) q[j] -= sft;
+          }
+          wave::sched_fence();
+        }
+        bool far = false;  // the fixed steps ran out: finish with a binary search (rare)
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) far = far || (bnd[j] && q[j] + HITBAR_NEAR == anchor && q[j] > 0);
+        if (wave::any(far)) {
+#pragma unroll
+          for (u32 j = 0; j < 4; ++j) {
+            if (bnd[j] && q[j] + HITBAR_NEAR == anchor && q[j] > 0) {
+              u32 lo = 0;
+              u32 h = q[j];
+              while (lo < h) {
+                const u32 mid = (lo + h) >> 1;
+                if (cp[c0 + mid] < lo_key[j]) lo = mid + 1; else h = mid;
+              }
+              q[j] = h;
+            }
+          }
+        }
+        // the candidates of the four units: position and index read together, then tested
+        u32 bp[4], wd[4];
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          const u32 e = c0 + (q[j] < cnt ? q[j] : 0);
+          bp[j] = cp[e];
+          wd[j] = ci[e];
+        }
+        wave::sched_fence();
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          if (bnd[j] & (q[j] < cnt) & (bp[j] < hi_key[j])) {
+            winner[j] = wd[j] & ~HITBAR_HARD;
+            hard[j] = (wd[j] & HITBAR_HARD) != 0;
+            bpos[j] = bp[j];
+          }
+        }
+      }
+      const u32 q_last = jl == 3 ? q[3] : jl == 2 ? q[2] : jl == 1 ? q[1] : q[0];
+      anchor = wave::bcast(q_last, l_last);
+    } else {
+      // the block spans more stalling barriers than the window holds (few, far apart units):
+      // per-unit searches in device memory
+      BarView v;
+      v.iv = &iv;
+      v.active = ws.bar_active;
+      v.st_pos = cp;
+      v.st_flag = ci;
+      v.s0 = FWD ? nb : 0;  // empty staged range at the end the search starts from
+      v.s1 = v.s0;
+#pragma unroll
+      for (u32 j = 0; j < 4; ++j) {
+        u32 b_lo = 0, b_hi = 0;
+        bool edge = false;
+        if (bnd[j]) lef_bar_window<FWD, false>(v, nb, 0, lo_key[j], hi_key[j], b_lo, b_hi, edge);
+        winner[j] = lef_bar_pick<FWD, false>(v, p, c.g, b_lo, b_hi, 0, hard[j], bpos[j]);
+        // (the loads of this rare path end here: see detect_primary)
+        wave::pin(winner[j]);
+        wave::pin(bpos[j]);
+        u32 hd = hard[j] ? 1u : 0u;
+        wave::pin(hd);
+        hard[j] = hd != 0;
+      }
+      // the staged entries stay valid, but the next block must not trust the anchor
+      lo_cover = 1;
+      hi_cover = 0;
+    }
+    if (wave::any((winner[0] & winner[1] & winner[2] & winner[3]) != 0xFFFFFFFFu)) {
+#pragma unroll
+      for (u32 j = 0; j < 4; ++j) {
+        if (winner[j] != 0xFFFFFFFFu) {
+          coll[k[j]] = cw_make(winner[j], EV_COLLISION | EV_LEF_BAR) | (hard[j] ? CW_HARD : 0u);
+          barpos[k[j]] = bpos[j];
+        }
+      }
+    }
+  }
+  wave::sync_mem();
+}
+
+template <bool FWD>
+MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
+  Workspace& ws = c.ws;
+  const Interval& iv = *c.iv;
+  const Params& p = *c.p;
+  const u32 n = wave::uniform(c.n_active);
+  const u32 nb = wave::uniform(iv.n_barriers);
+  if (nb == 0) return;
+  const u32 lane = wave::lane();
+  const u32* pos = FWD ? ws.f_pos : ws.r_pos;
+  const u32* moves = FWD ? ws.f_move : ws.r_move;
+  u32* coll = FWD ? ws.f_coll : ws.r_coll;
+  const bool trials = !((p.pblock_major == 1.0 || p.pblock_major == 0.0) &&
+                        (p.pblock_minor == 1.0 || p.pblock_minor == 0.0));
+  if (!trials) {
+    detect_lef_bar_det<FWD>(c, bc);
+    return;
+  }
+  u32* barpos = stalling_barrier_positions<FWD>(ws);
+  u32* st_pos = reinterpret_cast<u32*>(c.lds.sort_lds);
+  u32* st_flag = st_pos + BAR_WIN;
+  // first / last rank that takes part
+  const u32 j_rev0 = bc.n5 == 0 ? 0 : bc.n5 - 1;
+  const u32 j_fwd0 = bc.n3 == 0 ? n - 1 : n - bc.n3;
+  u32 carry_pos = 0;  // position of the neighbouring unit processed by the previous batch
+  u32 anchor = 0;     // rev: first barrier index the next batch can need; fwd: one past the last
+  BarView v;
+  v.iv = &iv;
+  v.active = ws.bar_active;
+  v.st_pos = st_pos;
+  v.st_flag = st_flag;
+  v.s0 = 0;
+  v.s1 = 0;  // nothing staged yet
+  bool located = false;
+  const u32 nbatch = (n + 63) / 64;
+  constexpr u32 UX = 4;  // batches whose loads are in flight together
+  for (u32 bg = 0; bg < nbatch; bg += UX) {
+    u32 Pq[UX], Mq[UX];
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      // rev: ranks ascending; fwd: ranks descending, lane 0 = highest rank of the batch
+      const i64 kk = FWD ? static_cast<i64>(j_fwd0) - static_cast<i64>(bg + u) * 64 - lane
+                         : static_cast<i64>(j_rev0) + static_cast<i64>(bg + u) * 64 + lane;
+      const bool act = kk >= 0 && kk < static_cast<i64>(n);
+      Pq[u] = wave::ld_sel(pos, static_cast<u32>(kk), act, 0);
+      Mq[u] = wave::ld_sel(moves, static_cast<u32>(kk), act, 0);
+    }
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 bi = bg + u;
+      const i64 kk = FWD ? static_cast<i64>(j_fwd0) - static_cast<i64>(bi) * 64 - lane
+                         : static_cast<i64>(j_rev0) + static_cast<i64>(bi) * 64 + lane;
+      const bool act = kk >= 0 && kk < static_cast<i64>(n);
+      if (!wave::any(act)) break;
+      const u32 k = act ? static_cast<u32>(kk) : 0;
+      const u32 P = Pq[u];
+      const u32 M = Mq[u];
+      const bool bnd = act && P != UNBOUND;
+      // neighbour towards which the barriers are shadowed (rank k-1 for rev, k+1 for fwd)
+      const u32 nbr_in = wave::shfl_up1(P);
+      const bool first = (bi == 0 && lane == 0);
+      const u32 nbr = lane > 0 ? nbr_in : carry_pos;
+      // the unit can be stalled by barriers with lo_key <= position < hi_key
+      u64 lo_key = 0, hi_key = 0;
+      if (bnd) {
+        if (!FWD) {
+          // prev <= bpos < P and P - bpos <= M
+          const u32 reach = P - M;  // M <= P - start after clamping
+          lo_key = first ? reach : umax(reach, nbr);
+          hi_key = P;
+        } else {
+          // P < bpos <= next and bpos - P <= M
+          const u64 reach = static_cast<u64>(P) + M;
+          lo_key = static_cast<u64>(P) + 1;
+          hi_key = (first ? reach : umin64(reach, nbr)) + 1;
+        }
+      }
+      const u64 bm = wave::ballot(bnd);
+      carry_pos = wave::bcast(P, 63);
+      if (bm == 0) continue;
+      // the first batch with a bound unit locates the window through the bucket table; later
+      // batches continue where the previous one stopped
+      if (!located) {
+        const u32 l0 = static_cast<u32>(wave::ctz64(bm));
+        const u64 key = FWD ? wave::bcast(hi_key, l0) : wave::bcast(lo_key, l0);
+        anchor = wave::uniform(bar_lower_bound(iv, key));
+        located = true;
+      }
+      const bool restage = FWD ? (v.s1 == 0 || (anchor < v.s0 + BAR_NEED && v.s0 > 0) || anchor > v.s1)
+                               : (v.s1 == 0 || (anchor + BAR_NEED > v.s1 && v.s1 < nb) || anchor < v.s0);
+      if (restage) {
+        if (!FWD) {
+          v.s0 = anchor;
+          v.s1 = umin(anchor + BAR_WIN, nb);
+        } else {
+          v.s1 = anchor;
+          v.s0 = anchor > BAR_WIN ? anchor - BAR_WIN : 0;
+        }
+        wave::lockstep();
+        for (u32 t = lane; t < BAR_WIN; t += 64) {
+          const u32 b = v.s0 + t;
+          if (b < v.s1) {
+            st_pos[t] = iv.bar_pos[b];
+            st_flag[t] =
+                static_cast<u32>(ws.bar_active[b] != 0) | (static_cast<u32>(iv.bar_dir[b]) << 1);
+          }
+        }
+        wave::sync_lds();
+      }
+      // windows of barrier indices [b_lo, b_hi): in LDS when every unit of the batch stays inside
+      // the staged range, otherwise through the general accessors
+      u32 b_lo = 0, b_hi = 0;
+      bool edge = false;
+      if (bnd) lef_bar_window<FWD, true>(v, nb, anchor, lo_key, hi_key, b_lo, b_hi, edge);
+      const bool staged_only = !wave::any(edge);
+      if (!staged_only) {
+        b_lo = 0;
+        b_hi = 0;
+        if (bnd) lef_bar_window<FWD, false>(v, nb, anchor, lo_key, hi_key, b_lo, b_hi, edge);
+      }
+      // number of Bernoulli trials this unit consumes
+      u32 ntr = 0;
+      if (trials) {
+        ntr = staged_only ? lef_bar_count_trials<FWD, true>(v, p, b_lo, b_hi)
+                          : lef_bar_count_trials<FWD, false>(v, p, b_lo, b_hi);
+      }
+      u32 off = 0, total = 0;
+      if (trials) {
+        // exclusive prefix sum of ntr over lanes
+        off = wave_prefix_sum_u32(ntr);
+        total = wave::bcast(off, 63);
+        off -= ntr;
+      }
+      bool hard = false;
+      u32 bpos = 0;
+      u32 winner = 0xFFFFFFFFu;
+      if (total <= RNG_BLOCK) {
+        if (total != 0) rng_ensure(c.g, total);
+        winner = staged_only ? lef_bar_pick<FWD, true>(v, p, c.g, b_lo, b_hi, off, hard, bpos)
+                             : lef_bar_pick<FWD, false>(v, p, c.g, b_lo, b_hi, off, hard, bpos);
+        rng_advance(c.g, total);
+      } else {
+        // More Bernoulli trials in this batch than one block of the PRNG ring serves (dense
+        // barrier annotations with a fractional blocking probability): the lanes are resolved in
+        // rounds, each taking the longest run of lanes (in lane = stream order) whose trials fit
+        // one block; a single unit with more trials than that is replayed sequentially.
+        u64 pend = wave::ballot(bnd);
+        u32 base_tr = 0;  // trials consumed by the lanes resolved so far
+        while (pend != 0) {
+          const bool mine_pending = ((pend >> lane) & 1u) != 0;
+          const bool fits = mine_pending && (off + ntr - base_tr <= RNG_BLOCK);
+          const u64 fm = wave::ballot(fits);
+          if (fm == 0) {
+            const u32 l = static_cast<u32>(wave::ctz64(pend));
+            const u32 lo = wave::bcast(b_lo, l), hi = wave::bcast(b_hi, l);
+            const u32 major_dir = FWD ? DIR_FWD : DIR_REV;
+            u32 w = 0xFFFFFFFFu;
+            bool h = false;
+            for (u32 q = lo; q < hi; ++q) {
+              const u32 b = FWD ? (hi - 1 - (q - lo)) : q;  // reference visiting order
+              const u32 fl = wave::uniform(v.flag<false>(b));
+              if (!(fl & 1u)) continue;
+              const f64 pb = (fl >> 1) == major_dir ? p.pblock_major : p.pblock_minor;
+              bool hit;
+              if (pb == 1.0) {
+                hit = true;
+              } else if (pb == 0.0) {
+                hit = false;
+              } else {
+                hit = bernoulli_raw(rng_next(c.g), pb);
+              }
+              if (hit) {
+                w = b;
+                h = (fl >> 1) == major_dir;
+              }
+            }
+            if (lane == l) {
+              winner = w;
+              hard = h;
+              if (w != 0xFFFFFFFFu) bpos = v.pos<false>(w);
+            }
+            base_tr += wave::bcast(ntr, l);
+            pend &= ~(u64(1) << l);
+          } else {
+            // fitting lanes are a run of pending lanes starting at the first one
+            const u32 l_last_fit = static_cast<u32>(63 - wave::clz64(fm));
+            const u32 cnt = wave::bcast(off + ntr, l_last_fit) - base_tr;
+            if (cnt != 0) rng_ensure(c.g, cnt);
+            if (fits) {
+              winner = staged_only
+                           ? lef_bar_pick<FWD, true>(v, p, c.g, b_lo, b_hi, off - base_tr, hard, bpos)
+                           : lef_bar_pick<FWD, false>(v, p, c.g, b_lo, b_hi, off - base_tr, hard, bpos);
+            }
+            rng_advance(c.g, cnt);
+            base_tr += cnt;
+            pend &= ~fm;
+          }
+        }
+      }
+      if (winner != 0xFFFFFFFFu) {
+        coll[k] = cw_make(winner, EV_COLLISION | EV_LEF_BAR) | (hard ? CW_HARD : 0u);
+        barpos[k] = bpos;
+      }
+      // where the next batch continues: past the last bound unit's window (rev) / below it (fwd)
+      const u32 l_last = static_cast<u32>(63 - wave::clz64(bm));
+      anchor = FWD ? wave::bcast(b_lo, l_last) : wave::bcast(b_hi, l_last);
+    }
+  }
+  wave::sync_mem();
+}
+
+// compute_lef_lef_collision_pos (reference: simulation.cpp:523-551)
+MODLE_DEV void lef_lef_collision_pos(u32 rev_p, u32 fwd_p, u32 rev_move, u32 fwd_move,
+                                     u32& out_rev, u32& out_fwd) {
+  // (all operands are below 2^32: the sum of the two converted moves is exact and equals the
+  // converted 64-bit sum, and the rounded product is at most fwd_move: 32-bit conversions)
+  const f64 relative_speed = static_cast<f64>(rev_move) + static_cast<f64>(fwd_move);
+  const f64 ttc = static_cast<f64>(rev_p - fwd_p) / relative_speed;
+  const u32 cpos = fwd_p + static_cast<u32>(wave::f_round(static_cast<f64>(fwd_move) * ttc));
+  if (cpos == fwd_p) {
+    out_rev = cpos + 1;
+    out_fwd = cpos;
+  } else {
+    out_rev = cpos;
+    out_fwd = cpos - 1;
+  }
+}
+
+// Position of the barrier a stalled unit's collision word points at.  The reference indexes the
+// barrier array with the word's index without checking that the word is a LEF-BAR collision
+// (simulation_detect_collisions.cpp:371, 389; only asserted in debug builds): a unit flagged at
+// the interval boundary (index 5 / 3) that still takes part in the primary pass makes it read
+// barrier #5 / #3, or past the end of the array when there are fewer barriers.  In-range
+// indices behave like the reference; out-of-range ones (undefined behaviour there) read as 0.
+MODLE_DEV u32 stalling_barrier_pos(const Interval& iv, u32 word) {
+  const u32 idx = cw_index(word);
+  return idx < iv.n_barriers ? iv.bar_pos[idx] : 0u;
+}
+
+// detect_primary_lef_lef_collisions (reference: simulation_detect_collisions.cpp:250-397),
+// evaluated per rev unit: the merge loop pairs the rev unit of rank j with the last fwd unit
+// strictly upstream of it, provided j is the first rev unit downstream of that fwd unit and the
+// fwd unit is not the last one the loop is allowed to look at.
+//
+// With `fuse_correct`, correct_moves_for_primary_lef_lef_collisions (reference:
+// simulation_correct_moves.cpp:53-121) is applied on the spot: every unit takes part in at most
+// one pair and the pair's corrected moves depend only on the two units (original moves, or
+// "distance to the stalling barrier - 1" for a unit that stays stalled by a barrier, which is
+// what correct_moves_for_lef_bar_collisions stores for it).
+// what one batch of detect_primary reads from device memory: the rev units of 64 ranks and a
+// slice of STAGE_CAP fwd units
+// (positions for the whole slice: every lane searches them; moves, collision words and ids for
+// its first PRIMARY_NEAR units only: a rev unit's partner is almost always among them)
+constexpr u32 PRIMARY_NEAR = 256;
+// one block of detect_primary: TWO consecutive rev ranks per lane (128 ranks, 64-bit loads) and
+// the slices of the fwd-side arrays
+struct PrimaryBatch {
+  wave::U32x2 R, rev_move, rev_id, rc, rbp;
+  u32 sp[STAGE_CAP / 64];
+  u32 sm[PRIMARY_NEAR / 64], sc[PRIMARY_NEAR / 64], si[PRIMARY_NEAR / 64], sb[PRIMARY_NEAR / 64];
+};
+// `base` is even; ranks outside [first, n) are masked where the values are used
+template <class Op>
+MODLE_DEV void primary_load_batch(Op op, const Workspace& ws, u32 n, u32 base, u32 w0, u32 lane,
+                                  PrimaryBatch& b, bool rev_side) {
+  if (rev_side) {
+    const u32 k0 = base + 2 * lane;
+    const u32 kq = k0 < n ? k0 : 0u;
+    b.R = wave::ld2(ws.r_pos, kq);
+    b.rev_move = wave::ld2(ws.r_move, kq);
+    b.rev_id = wave::ld2(ws.r_id, kq);
+    b.rc = wave::ld2(ws.r_coll, kq);
+    // position of the barrier that stalls the unit (meaningful where the word says LEF-BAR):
+    // having it here keeps a dependent load, and with it a wait for everything in flight, out of
+    // the block's work
+    b.rbp = wave::ld2(stalling_barrier_positions<false>(ws), kq);
+  }
+#pragma unroll
+  for (u32 q = 0; q < STAGE_CAP / 64; ++q) {
+    const u32 t = lane + 64 * q;
+    b.sp[q] = op(ws.f_pos, w0 + t, w0 + t < n, UNBOUND, b.sp[q]);
+  }
+#pragma unroll
+  for (u32 q = 0; q < PRIMARY_NEAR / 64; ++q) {
+    const u32 t = lane + 64 * q;
+    const bool in = w0 + t < n;
+    b.sm[q] = op(ws.f_move, w0 + t, in, 0, b.sm[q]);
+    b.sc[q] = op(ws.f_coll, w0 + t, in, 0, b.sc[q]);
+    b.si[q] = op(ws.f_id, w0 + t, in, 0, b.si[q]);
+    b.sb[q] = op(stalling_barrier_positions<true>(ws), w0 + t, in, 0, b.sb[q]);
+  }
+}
+
+MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_correct) {
+  Workspace& ws = c.ws;
+  const Params& p = *c.p;
+  const Interval& iv = *c.iv;
+  const u32 n = wave::uniform(c.n_active);
+  if (bc.n5 == n || bc.n3 == n) return;
+  const u32 lane = wave::lane();
+  const u32 i2 = bc.n3 == 0 ? n : n - (bc.n3 - 1);
+  // run_lef_lef_collision_trial (simulation_impl.hpp:93-96): no draw when the bypass probability
+  // is 0 (always collide) -- and none when it is 1: bernoulli_distribution(0) returns false
+  // without touching the engine
+  const f64 p_collide = 1.0 - p.p_bypass;
+  const bool never_collide = p.p_bypass != 0.0 && p_collide == 0.0;
+  const bool trials = p.p_bypass != 0.0 && !never_collide;
+  const u32 prim = EV_COLLISION | EV_LEF_LEF_PRIMARY;
+  // LDS slices of the fwd-side arrays, ranks [w0, w0 + STAGE_CAP): positions in the staging
+  // buffer, moves / collision words / ids / barrier positions in the (idle) sort buffer
+  u32* stage = c.lds.stage;
+  u32* st_move = reinterpret_cast<u32*>(c.lds.sort_lds);
+  u32* st_coll = st_move + PRIMARY_NEAR;
+  u32* st_id = st_coll + PRIMARY_NEAR;
+  u32* st_bp = st_id + PRIMARY_NEAR;
+  static_assert(4 * PRIMARY_NEAR <= 2 * SORT_LDS_CAP, "fwd slices do not fit the sort buffer");
+  u32 carry_pos = 0;
+  u32 carry_pf = 0;  // fwd units strictly upstream of the last rev unit handled so far
+  // pf = number of fwd units strictly upstream of R.  pf is monotone in the rank, so slices of
+  // the fwd arrays starting at the previous block's value are staged in LDS (one round trip
+  // together with the block's rev-side loads) and everything is looked up there; units whose
+  // partner lies beyond the slice use device memory.  The loads of the next block are issued as
+  // soon as this block knows where its last unit falls among the fwd units, before the rest of
+  // its work.  What they can miss are this block's updates of the fwd unit at the start of the
+  // next slice (its move and collision word), and no unit of the next block can pair with that
+  // unit: it lies upstream of this block's last rev unit, which is then the "first rev unit
+  // downstream of it".
+  const u32 first = bc.n5;
+  PrimaryBatch cur;
+  primary_load_batch(wave::LdRaw{}, ws, n, first & ~1u, 0, lane, cur, true);
+  for (u32 base = first & ~1u; base < n; base += 128) {
+    const u32 w0 = carry_pf > 0 ? carry_pf - 1 : 0;
+    primary_load_batch(wave::LdMask{}, ws, n, base, w0, lane, cur, false);  // (defaults outside the range)
+    u32 k[2], R[2], rev_move_k[2], rev_id_k[2], rc_k[2], rbp_k[2];
+    bool act[2];
+#pragma unroll
+    for (u32 j = 0; j < 2; ++j) {
+      k[j] = base + 2 * lane + j;
+      act[j] = k[j] >= first && k[j] < n;
+      R[j] = act[j] ? cur.R.v[j] : UNBOUND;
+      rev_move_k[j] = act[j] ? cur.rev_move.v[j] : 0u;
+      rev_id_k[j] = act[j] ? cur.rev_id.v[j] : 0u;
+      rc_k[j] = act[j] ? cur.rc.v[j] : 0u;
+      rbp_k[j] = act[j] ? cur.rbp.v[j] : 0u;
+    }
+    wave::lockstep();
+#pragma unroll
+    for (u32 q = 0; q < STAGE_CAP / 64; ++q) stage[lane + 64 * q] = cur.sp[q];
+#pragma unroll
+    for (u32 q = 0; q < PRIMARY_NEAR / 64; ++q) {
+      const u32 t = lane + 64 * q;
+      st_move[t] = cur.sm[q];
+      st_coll[t] = cur.sc[q];
+      st_id[t] = cur.si[q];
+      st_bp[t] = cur.sb[q];
+    }
+    wave::sync_lds();
+    const u32 prev_in = wave::shfl_up1(R[1]);
+    const u32 Rprev0 = lane > 0 ? prev_in : carry_pos;
+    // number of staged positions below R: a fixed-step search (no loop control, the eight steps
+    // are the same for every unit; the two reads of a round are issued together)
+    u32 lo[2] = {0, 0};
+    static_assert(STAGE_CAP == 256, "the search below covers 256 entries");
+#pragma unroll
+    for (u32 sft = 128; sft >= 1; sft >>= 1) {
+      u32 sv[2];
+#pragma unroll
+      for (u32 j = 0; j < 2; ++j) sv[j] = stage[lo[j] + sft - 1];
+      wave::sched_fence();
+#pragma unroll
+      for (u32 j = 0; j < 2; ++j) {
+        if (sv[j] < R[j]) lo[j] += sft;
+      }
+      wave::sched_fence();
+    }
+    const u32 st_last = stage[STAGE_CAP - 1];
+    u32 pf[2] = {0, 0};
+#pragma unroll
+    for (u32 j = 0; j < 2; ++j) {
+      if (act[j]) {
+        u32 l = lo[j];
+        if (l == STAGE_CAP - 1 && st_last < R[j]) l = STAGE_CAP;
+        if (l == STAGE_CAP && w0 + STAGE_CAP < n) {
+          pf[j] = lower_bound_u32(ws.f_pos, n, R[j]);
+        } else {
+          pf[j] = umin(w0 + l, n);
+        }
+      }
+    }
+    // pf of the last active unit
+    const u64 am = wave::ballot(act[0] || act[1]);
+    const u32 next_pf = wave::bcast(act[1] ? pf[1] : pf[0], static_cast<u32>(63 - wave::clz64(am)));
+    if (base + 128 < n) {
+      primary_load_batch(wave::LdRaw{}, ws, n, base + 128, next_pf > 0 ? next_pf - 1 : 0, lane, cur, true);
+    }
+    // the partner of each unit (the fwd unit right upstream of it): its five words are read from
+    // the slices together, without branches; partners beyond the slices come from device memory
+    static_assert(PRIMARY_NEAR == STAGE_CAP, "one staged range for all five fwd-side arrays");
+    bool cand[2] = {false, false};
+    u32 F[2], rev_move[2], fwd_move[2], fwd_id_s[2], fc_s[2], fbp_s[2];
+    bool has[2], staged[2];
+#pragma unroll
+    for (u32 j = 0; j < 2; ++j) {
+      has[j] = act[j] && pf[j] >= 1 && pf[j] < i2;
+      const u32 kf = pf[j] - 1;
+      staged[j] = has[j] && kf >= w0 && kf - w0 < STAGE_CAP;
+      const u32 e = staged[j] ? kf - w0 : 0u;
+      F[j] = stage[e];
+      fwd_move[j] = st_move[e];
+      fwd_id_s[j] = st_id[e];
+      fc_s[j] = st_coll[e];
+      fbp_s[j] = st_bp[e];
+      rev_move[j] = rev_move_k[j];
+    }
+    wave::sched_fence();
+    if (wave::any((has[0] && !staged[0]) || (has[1] && !staged[1]))) {
+#pragma unroll
+      for (u32 j = 0; j < 2; ++j) {
+        if (has[j] && !staged[j]) {
+          const u32 kf = pf[j] - 1;
+          F[j] = ws.f_pos[kf];
+          fwd_move[j] = ws.f_move[kf];
+          fwd_id_s[j] = ws.f_id[kf];
+          fc_s[j] = ws.f_coll[kf];
+          fbp_s[j] = stalling_barrier_positions<true>(ws)[kf];
+        }
+        // (the loads end HERE: where values loaded on a rare path merge with the common path the
+        // compiler waits for everything in flight -- the next block's loads -- on both)
+        wave::pin(F[j]);
+        wave::pin(fwd_move[j]);
+        wave::pin(fwd_id_s[j]);
+        wave::pin(fc_s[j]);
+        wave::pin(fbp_s[j]);
+      }
+    }
+#pragma unroll
+    for (u32 j = 0; j < 2; ++j) {
+      const u32 Rprev = j == 0 ? Rprev0 : R[0];
+      const bool first_after = (k[j] == first) || Rprev <= F[j];
+      const u32 delta = R[j] - F[j];  // > 0 by construction (where it is used)
+      cand[j] = has[j] && first_after && static_cast<u64>(delta) < static_cast<u64>(rev_move[j]) + fwd_move[j];
+    }
+    const u64 cm0 = wave::ballot(cand[0]), cm1 = wave::ballot(cand[1]);
+    bool hit[2] = {cand[0] && !never_collide, cand[1] && !never_collide};
+    if (trials && (cm0 | cm1) != 0) {
+      const u32 cnt = static_cast<u32>(wave::popc64(cm0) + wave::popc64(cm1));
+      rng_ensure(c.g, cnt);
+      // draws in rank order: unit (lane, j) after the units of the lanes before it and after unit 0
+      // of its own lane
+      const u64 lt = lanemask_lt(lane);
+      const u32 t0 = static_cast<u32>(wave::popc64(cm0 & lt) + wave::popc64(cm1 & lt));
+      const u32 t1 = t0 + (cand[0] ? 1u : 0u);
+      hit[0] = cand[0] && bernoulli_raw(rng_peek(c.g, c.g.pos + t0), p_collide);
+      hit[1] = cand[1] && bernoulli_raw(rng_peek(c.g, c.g.pos + t1), p_collide);
+      rng_advance(c.g, cnt);
+    }
+    // The collisions are rare (a few units per block) and their handling is long divergent code:
+    // it runs once for the lane's unit that collided, and a second time only when both units of a
+    // lane did.
+    const auto handle_hit = [&](u32 pf_h, u32 k_h, u32 R_h, u32 F_h, u32 rev_move_h, u32 fwd_move_h, u32 rev_id_k_h,
+                                u32 fwd_id_s_h, u32 rc_k_h, u32 fc_s_h, u32 rbp_k_h, u32 fbp_s_h) {
+      const u32 kf = pf_h - 1;
+      const u32 rev_id = rev_id_k_h, fwd_id = fwd_id_s_h;
+      u32 cpos_rev, cpos_fwd;
+      lef_lef_collision_pos(R_h, F_h, rev_move_h, fwd_move_h, cpos_rev, cpos_fwd);
+      const u32 rc = rc_k_h, fc = fc_s_h;
+      const bool rev_occ = cw_occurred(rc), fwd_occ = cw_occurred(fc);
+      u32 rev_other = 0, fwd_other = 0;
+      const bool rev_odd = rev_occ && !cw_occurred_as(rc, EV_LEF_BAR);
+      const bool fwd_odd = fwd_occ && !cw_occurred_as(fc, EV_LEF_BAR);
+      // a stalled unit whose word is not a LEF-BAR collision (flagged at the interval boundary):
+      // the barrier its index points at is read on a path of its own, and the load ends there
+      // (see above)
+      if (rev_odd || fwd_odd) {
+        if (rev_odd) rev_other = stalling_barrier_pos(iv, rc);
+        if (fwd_odd) fwd_other = stalling_barrier_pos(iv, fc);
+        wave::pin(rev_other);
+        wave::pin(fwd_other);
+      }
+      bool both = false;
+      if (!rev_occ && !fwd_occ) {
+        ws.r_coll[k_h] = cw_make(fwd_id, prim);
+        ws.f_coll[kf] = cw_make(rev_id, prim);
+        both = true;
+      } else if (rev_occ && !fwd_occ) {
+        const u32 barrier_pos = rev_odd ? rev_other : rbp_k_h;
+        ws.f_coll[kf] = cw_make(rev_id, prim);
+        if (cpos_fwd > barrier_pos) {
+          // the LEF-LEF collision happens before the predicted LEF-BAR one
+          ws.r_coll[k_h] = cw_make(fwd_id, prim);
+          both = true;
+        } else if (fuse_correct && cw_occurred_as(rc, EV_LEF_BAR)) {
+          // fwd unit runs into a rev unit that stays stalled 1 bp downstream of its barrier
+          const u32 rev_move_stalled = (R_h - barrier_pos) - 1;
+          ws.f_move[kf] = (R_h - rev_move_stalled) - F_h - 1;
+        }
+      } else if (!rev_occ && fwd_occ) {
+        const u32 barrier_pos = fwd_odd ? fwd_other : fbp_s_h;
+        ws.r_coll[k_h] = cw_make(fwd_id, prim);
+        if (cpos_rev < barrier_pos) {
+          ws.f_coll[kf] = cw_make(rev_id, prim);
+          both = true;
+        } else if (fuse_correct && cw_occurred_as(fc, EV_LEF_BAR)) {
+          const u32 fwd_move_stalled = (barrier_pos - F_h) - 1;
+          ws.r_move[k_h] = R_h - (F_h + fwd_move_stalled) - 1;
+        }
+      }
+      if (both && fuse_correct) {
+        ws.r_move[k_h] = R_h - cpos_rev;
+        ws.f_move[kf] = cpos_fwd - F_h;
+      }
+    };
+    if (wave::any(hit[0] || hit[1])) {
+      const u32 h = hit[0] ? 0u : 1u;
+      if (hit[0] || hit[1]) {
+        handle_hit(h ? pf[1] : pf[0], h ? k[1] : k[0], h ? R[1] : R[0], h ? F[1] : F[0], h ? rev_move[1] : rev_move[0],
+                   h ? fwd_move[1] : fwd_move[0], h ? rev_id_k[1] : rev_id_k[0], h ? fwd_id_s[1] : fwd_id_s[0],
+                   h ? rc_k[1] : rc_k[0], h ? fc_s[1] : fc_s[0], h ? rbp_k[1] : rbp_k[0], h ? fbp_s[1] : fbp_s[0]);
+      }
+      if (wave::any(hit[0] && hit[1])) {
+        if (hit[0] && hit[1]) {
+          handle_hit(pf[1], k[1], R[1], F[1], rev_move[1], fwd_move[1], rev_id_k[1], fwd_id_s[1], rc_k[1], fc_s[1],
+                     rbp_k[1], fbp_s[1]);
+        }
+      }
+    }
+    carry_pos = wave::bcast(R[1], 63);
+    carry_pf = next_pf;
+  }
+  wave::sync_mem();
+}
+
+// correct_moves_for_primary_lef_lef_collisions (reference: simulation_correct_moves.cpp:53-121)
+// as a stand-alone pass; only used by the phase-level test entry point when the reference's
+// hook sequence runs it separately from detection.
+MODLE_DEV_NOINLINE void correct_moves_primary_standalone(Cell& c) {
+  ensure_inverse_both(c);
+  Workspace& ws = c.ws;
+  const u32 n = wave::uniform(c.n_active);
+  const u32 lane = wave::lane();
+  for (u32 base = 0; base < n; base += 64) {
+    const u32 k = base + lane;
+    if (k < n) {
+      const u32 rc = ws.r_coll[k];
+      if (cw_occurred_as(rc, EV_LEF_LEF_PRIMARY)) {
+        const u32 kf = ws.f_rank[cw_index(rc)];
+        const u32 fc = ws.f_coll[kf];
+        if (cw_occurred_as(fc, EV_LEF_LEF_PRIMARY)) {
+          u32 p1, p2;
+          lef_lef_collision_pos(ws.r_pos[k], ws.f_pos[kf], ws.r_move[k], ws.f_move[kf], p1, p2);
+          ws.r_move[k] = ws.r_pos[k] - p1;
+          ws.f_move[kf] = p2 - ws.f_pos[kf];
+        } else if (cw_occurred_as(fc, EV_LEF_BAR)) {
+          ws.r_move[k] = ws.r_pos[k] - (ws.f_pos[kf] + ws.f_move[kf]) - 1;
+        }
+      }
+    }
+  }
+  wave::sync_mem();
+  for (u32 base = 0; base < n; base += 64) {
+    const u32 k = base + lane;
+    if (k < n) {
+      const u32 fc = ws.f_coll[k];
+      if (cw_occurred_as(fc, EV_LEF_LEF_PRIMARY)) {
+        const u32 kr = ws.r_rank[cw_index(fc)];
+        if (cw_occurred_as(ws.r_coll[kr], EV_LEF_BAR))
+          ws.f_move[k] = (ws.r_pos[kr] - ws.r_move[kr]) - ws.f_pos[k] - 1;
+      }
+    }
+  }
+  wave::sync_mem();
+}
+
+// process_secondary_lef_lef_collisions (reference: simulation_detect_collisions.cpp:400-515).
+// The pass is a chain: a stalled unit can stall its follower, which can stall the next one, and
+// every candidate consumes one Bernoulli draw in rank order.  Ranks whose collision was avoided
+// are appended to `list` (rank positions, visiting order) for fix_secondary.
+//
+// correct_moves_for_lef_bar_collisions (reference: simulation_correct_moves.cpp:19-50) is fused
+// into the first pass: a unit stalled by a barrier gets move = distance - 1.  (It has to come after
+// primary detection, which tests the uncorrected moves.)
+//
+// Two passes.  Nearly every batch of 64 consecutive ranks holds a few candidates (units
+// queued behind a stalled unit try again in every epoch), so a one-pass form (rounds 1-2) ran its
+// chain resolution -- a long dependent sequence of ballots, scalar bit operations, LDS reads and
+// draws -- once per batch for a handful of useful lanes.  The first pass only corrects the LEF-BAR
+// moves and FILTERS: the candidates (a superset: units that can reach their blocker's position and
+// whose blocker is, or may become, stalled) are appended in visiting order to a compact list of
+// ranks in device scratch.  The second pass resolves 64 CANDIDATES at a time: it gathers their
+// units and their blockers (the unit of the adjacent rank) and runs the chain logic once for 64
+// useful lanes.  A candidate whose blocker is a candidate too (`cont`) finds it in the lane before
+// it (or in the carry of the previous group): runs of such lanes are the chains.  Draw order =
+// list order = visiting order.  The Bernoulli outcomes of a group are evaluated up front for the
+// first 64 outputs of the stream; which unit takes which output follows from masks, with one
+// round per avoided collision that cuts a chain short (not per avoided collision).
+constexpr u32 SEC_CONT = 0x40000000u;  // on the rank word of a list entry: the blocker is the entry before
+constexpr u32 SEC_BOCC = 0x80000000u;  // ... the blocker (not a candidate) is stalled
+
+// Pass 1 as a stepper, so that the rev and the fwd instance can share one loop (they are
+// independent: no draws, each reads and writes its own direction's arrays): two dependency chains
+// per iteration instead of one.
+template <bool FWD>
+struct SecondaryFilter {
+  static constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
+  struct UnitRegs {
+    u32 P[UX], M[UX], C[UX], B[UX];
+  };
+  const u32 *pos, *coll, *barpos;
+  u32 *moves, *q_k, *dump;
+  u32 n, lane, nbatch, cap, n_cand, carry_pos, carry_coll;
+  i32 f_first;
+  bool correct_lef_bar, do_secondary, carry_pending;
+  UnitRegs cur;
+
+  MODLE_DEV_MEMBER void load_units(bool raw, u32 bg, UnitRegs& r) const {
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 bi = bg + u;
+      // (ranks stay far below 2^31: 32-bit index arithmetic)
+      const i32 kk = FWD ? static_cast<i32>(n) - 1 - static_cast<i32>(bi * 64 + lane)
+                         : static_cast<i32>(bi * 64 + lane);
+      const bool act = kk >= 0 && static_cast<u32>(kk) < n;
+      const u32 k = act ? static_cast<u32>(kk) : 0;
+      if (raw) {
+        r.P[u] = wave::LdRaw{}(pos, k, act, 0, r.P[u]);
+        r.M[u] = wave::LdRaw{}(moves, k, act, 0, r.M[u]);
+        r.C[u] = wave::LdRaw{}(coll, k, act, 0, r.C[u]);
+        r.B[u] = wave::LdRaw{}(barpos, k, act, 0, r.B[u]);
+      } else {
+        r.P[u] = wave::LdMask{}(pos, k, act, 0, r.P[u]);
+        r.M[u] = wave::LdMask{}(moves, k, act, 0, r.M[u]);
+        r.C[u] = wave::LdMask{}(coll, k, act, 0, r.C[u]);
+        r.B[u] = wave::LdMask{}(barpos, k, act, 0, r.B[u]);
+      }
+    }
+  }
+  MODLE_DEV_MEMBER void init(Cell& c, BoundaryCounts bc, u32 list_cap, bool lef_bar, bool secondary) {
+    Workspace& ws = c.ws;
+    n = wave::uniform(c.n_active);
+    lane = wave::lane();
+    pos = FWD ? ws.f_pos : ws.r_pos;
+    coll = FWD ? ws.f_coll : ws.r_coll;
+    barpos = stalling_barrier_positions<FWD>(ws);
+    moves = FWD ? ws.f_move : ws.r_move;
+    // the candidate list (rank | flags) lives in a scratch array that is idle during the collision
+    // passes; lanes with nothing to store hit a scratch word of their own (stores under a branch
+    // cannot be counted by the compiler, and the wait for the next group's loads then becomes a
+    // wait for every store in flight)
+    q_k = FWD ? ws.tmp[1] : ws.tmp[0];
+    dump = reinterpret_cast<u32*>(ws.sort_keys) + 2 * lane + (FWD ? 1 : 0);
+    cap = list_cap;
+    correct_lef_bar = lef_bar;
+    do_secondary = secondary;
+    // rev: followers i = max(1, n5) .. n-1 ascending, blocker = rank i-1
+    // fwd: followers i-1 for i = (n - min(n3, n3-1) - 1) .. 1 descending, blocker = rank i
+    f_first = FWD ? static_cast<i32>(bc.n3 == 0 ? n - 1 : n - bc.n3) - 1
+                  : static_cast<i32>(umax(1u, bc.n5));
+    nbatch = (n + 63) / 64;
+    n_cand = 0;
+    carry_pos = 0;
+    carry_coll = 0;
+    carry_pending = false;
+    load_units(true, 0, cur);
+  }
+  // one group of UX batches (bg = first batch of the group)
+  MODLE_DEV_MEMBER void step(u32 bg) {
+    UnitRegs g = cur;
+    load_units(false, bg, g);  // (defaults of the lanes outside the range)
+    if (bg + UX < nbatch) load_units(true, bg + UX, cur);
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 bi = bg + u;
+      if (bi >= nbatch) break;
+      const i32 kk = FWD ? static_cast<i32>(n) - 1 - static_cast<i32>(bi * 64 + lane)
+                         : static_cast<i32>(bi * 64 + lane);
+      const bool act = kk >= 0 && static_cast<u32>(kk) < n;
+      const u32 k = act ? static_cast<u32>(kk) : 0;
+      const u32 P = g.P[u], M0 = g.M[u], C = g.C[u];
+      u32 M = M0;
+      if (correct_lef_bar && act && cw_occurred_as(C, EV_LEF_BAR)) {
+        const u32 bp = g.B[u];
+        M = (FWD ? bp - P : P - bp) - 1;
+      }
+      *((act && M != M0) ? &moves[k] : dump) = M;
+      const bool follower = do_secondary && act && (FWD ? (kk <= f_first) : (kk >= f_first));
+      // the blocker: the unit visited before this one
+      const u32 bP_in = wave::shfl_up1(P), bC_in = wave::shfl_up1(C);
+      const u32 bP = lane > 0 ? bP_in : carry_pos, bC = lane > 0 ? bC_in : carry_coll;
+      const bool pot = follower && !cw_occurred(C) &&
+                       (FWD ? static_cast<u64>(P) + M >= bP : static_cast<u64>(P) - M <= bP);
+      const u64 potm = wave::ballot(pot);
+      // blocker stalled already, or itself a candidate (then it may become stalled in pass 2):
+      // propagate along runs of consecutive candidates.  The unit before lane 0 counts as "may be
+      // stalled" when it is a candidate (its outcome is not known in this pass).
+      const u64 occm = wave::ballot(cw_occurred(bC)) | (carry_pending ? u64(1) : u64(0));
+      u64 pend = potm & occm;
+      for (;;) {
+        const u64 grown = pend | (potm & (pend << 1));
+        if (grown == pend) break;
+        pend = grown;
+      }
+      {
+        const bool mine = ((pend >> lane) & 1u) != 0;
+        const u32 e = n_cand + static_cast<u32>(wave::popc64(pend & lanemask_lt(lane)));
+        const bool cont = lane > 0 ? ((pend >> (lane - 1)) & 1u) != 0 : carry_pending;
+        *((mine && e < cap) ? &q_k[e] : dump) =
+            k | (cont ? SEC_CONT : 0u) | (cw_occurred(bC) ? SEC_BOCC : 0u);
+      }
+      n_cand += static_cast<u32>(wave::popc64(pend));
+      carry_pending = (pend >> 63) != 0;
+      carry_pos = wave::bcast(P, 63);
+      carry_coll = wave::bcast(C, 63);
+    }
+  }
+};
+
+// Pass 2 of one direction over the `n_cand` candidates pass 1 listed in ws.tmp[0] (rev) /
+// ws.tmp[1] (fwd).
+template <bool FWD>
+MODLE_DEV_NOINLINE u32 secondary_resolve(Cell& c, u32 n_cand, u32* list, u32 list_cap, bool& overflow) {
+  Workspace& ws = c.ws;
+  const Params& p = *c.p;
+  const u32 lane = wave::lane();
+  const u32* pos = FWD ? ws.f_pos : ws.r_pos;
+  const u32* ids = FWD ? ws.f_id : ws.r_id;
+  u32* moves = FWD ? ws.f_move : ws.r_move;
+  u32* coll = FWD ? ws.f_coll : ws.r_coll;
+  const u32* const q_k = FWD ? ws.tmp[1] : ws.tmp[0];
+  // run_lef_lef_collision_trial (simulation_impl.hpp:93-96): no draw when the bypass probability
+  // is 0 (always collide) -- and none when it is 1: bernoulli_distribution(0) returns false
+  // without touching the engine
+  const f64 p_collide = 1.0 - p.p_bypass;
+  const bool never_collide = p.p_bypass != 0.0 && p_collide == 0.0;
+  const bool trials = p.p_bypass != 0.0 && !never_collide;
+  if (n_cand == 0) return 0;
+  if (n_cand > list_cap) {  // (cannot happen: a candidate is an active unit, the list holds capacity_lefs)
+    c.error = ERR_INTERNAL;
+    return 0;
+  }
+
+  u32 n_list = 0;
+  u32 fin_pos = 0, fin_move = 0, fin_coll = 0, fin_id = 0;  // the candidate before this group, resolved
+  // the units of a group and their blockers (the unit visited before: the adjacent rank) are
+  // gathered through the list; the next group's list entries and units are requested one group
+  // ahead.  (A blocker's move is final here: blockers that are candidates are taken from the lane
+  // before, and everything else was settled by pass 1.)
+  struct CandRegs {
+    u32 K, P, M, C, I, bP, bM, bI;
+  };
+  const auto load_units_of = [&](u32 base, u32 kword, CandRegs& r) {
+    const bool in = base + lane < n_cand;
+    const u32 k = in ? (kword & CW_INDEX_MASK) : 0u;
+    // (the first unit in visiting order is never a candidate: the adjacent rank exists)
+    const u32 kb = in ? (FWD ? k + 1 : k - 1) : 0u;
+    r.K = kword;
+    r.P = wave::LdRaw{}(pos, k, true, 0, 0u);
+    r.M = wave::LdRaw{}(moves, k, true, 0, 0u);
+    r.C = wave::LdRaw{}(coll, k, true, 0, 0u);
+    r.I = wave::LdRaw{}(ids, k, true, 0, 0u);
+    r.bP = wave::LdRaw{}(pos, kb, true, 0, 0u);
+    r.bM = wave::LdRaw{}(moves, kb, true, 0, 0u);
+    r.bI = wave::LdRaw{}(ids, kb, true, 0, 0u);
+  };
+  const auto load_kword = [&](u32 base) { return wave::ld_sel(q_k, base + lane, base + lane < n_cand, 0u); };
+  CandRegs ccur;
+  load_units_of(0, load_kword(0), ccur);
+  u32 kword_next = 64 < n_cand ? load_kword(64) : 0u;
+  for (u32 base = 0; base < n_cand; base += 64) {
+    const CandRegs q = ccur;
+    if (base + 64 < n_cand) {
+      load_units_of(base + 64, kword_next, ccur);
+      if (base + 128 < n_cand) kword_next = load_kword(base + 128);
+    }
+    const u32 m = umin(64u, n_cand - base);
+    const bool valid = lane < m;
+    const u64 vmask = m == 64 ? ~u64(0) : lanemask_lt(m);
+    const u32 k = q.K & CW_INDEX_MASK;
+    const u32 P = q.P, id = q.I, M0 = q.M, C0 = q.C;
+    u32 M = M0, C = C0;
+    // blocker of the first lane when it is the last candidate of the previous group: resolved now
+    bool cont = valid && (q.K & SEC_CONT) != 0;
+    bool bocc = (q.K & SEC_BOCC) != 0;
+    u32 xP = q.bP, xM = q.bM, xI = q.bI;  // explicit blocker (lanes that do not continue a chain)
+    if (lane == 0 && cont) {
+      xP = fin_pos;
+      xM = fin_move;
+      xI = fin_id;
+      bocc = cw_occurred(fin_coll);
+      cont = false;
+    }
+    const u64 contm = wave::ballot(cont);
+    const u64 lt = lanemask_lt(lane), le = lt | (u64(1) << lane);
+    const u64 starts = vmask & ~contm, ends = vmask & ~(contm >> 1);
+    const u32 pP_in = wave::shfl_up1(P);
+    const u32 blocker_pos = cont ? pP_in : xP;
+    const auto wraps = [](u32 pp, u32 mm) { return FWD ? pp + mm < pp : mm > pp; };
+    const bool odd = valid && (P == blocker_pos || wraps(P, M) || (!cont && wraps(xP, xM)));
+    u64 pend = vmask;
+    if (!wave::any(odd)) {
+      const u32 bI_in = wave::shfl_up1(id);
+      const u32 bId = cont ? bI_in : xI;
+      const u32 s = valid ? static_cast<u32>(63 - wave::clz64(starts & le)) : lane;  // start of the lane's run
+      // landing position and state of the run's own blocker (explicit at the run's first lane)
+      const u32 xland = FWD ? xP + xM : xP - xM;
+      const u32 lb = wave::shfl(xland, s);
+      const bool head_ok = wave::shfl(static_cast<u32>(bocc), s) != 0;
+      const u32 off = lane - s;
+      const u32 land_prev = FWD ? lb - off : lb + off;  // the blocker's landing while the chain holds
+      const bool geo = FWD ? (P + M >= land_prev) : (P - M <= land_prev);
+      // a run whose first blocker is not stalled does nothing at all
+      const u64 ngeo = wave::ballot(valid && (!geo || (lane == s && !head_ok)));
+      const bool alive = valid && ((ngeo & le) >> s) == 0;
+      // the lanes that draw unless an "avoid" before them ends their chain: in every run a
+      // prefix of its lanes
+      const u64 live = wave::ballot(alive);
+      // outcome of stream output t, for the first 64 outputs (at most popc(live) are consumed)
+      u64 outcomes = never_collide ? u64(0) : ~u64(0);
+      if (trials && live != 0) {
+        rng_ensure(c.g, static_cast<u32>(wave::popc64(live)));
+        outcomes = wave::ballot(bernoulli_raw(rng_peek(c.g, c.g.pos + lane), p_collide));
+      }
+      u64 hits = 0, avoids = 0;  // lanes that collide / whose collision is avoided
+      u32 drawn = 0;             // outputs consumed
+#ifdef MODLE_PHASE_TIMERS
+      const u64 t_walk = wave::clock();
+#endif
+      // Every lane takes the output its position among the drawing lanes gives it.  That is final
+      // up to the first "avoid" that ends a chain with lanes still to draw behind it (those lanes
+      // drop out, and every later lane moves to an earlier output): one round per such avoid, and
+      // most avoids are the last lane of their chain.
+      const u64 has_successor = (live >> 1) & (contm >> 1);  // the next lane draws after this one, same chain
+      for (u64 rem = live; rem != 0;) {
+        const u32 t = drawn + static_cast<u32>(wave::popc64(rem & lt));
+        const bool collide = ((outcomes >> (t & 63u)) & 1u) != 0;
+        const u64 av = wave::ballot(((rem >> lane) & 1u) != 0 && !collide);
+        const u64 cut = av & has_successor;
+        if (cut == 0) {
+          hits |= rem & ~av;
+          avoids |= av;
+          drawn += static_cast<u32>(wave::popc64(rem));
+          break;
+        }
+        const u32 a = static_cast<u32>(wave::ctz64(cut));
+        const u32 e = static_cast<u32>(wave::ctz64(ends & ~lanemask_lt(a)));  // end of its run
+        const u64 upto = lanemask_lt(a) | (u64(1) << a);
+        hits |= rem & upto & ~av;
+        avoids |= av & upto;
+        drawn += static_cast<u32>(wave::popc64(rem & upto));
+        rem = e >= 63 ? u64(0) : rem & ~lanemask_lt(e + 1);
+      }
+#ifdef MODLE_PHASE_TIMERS
+      c.ph[15] += wave::clock() - t_walk;
+#endif
+      if (trials && drawn != 0) rng_advance(c.g, drawn);
+      if ((avoids >> lane) & 1u) {
+        C = cw_make(bId, EV_LEF_LEF_SECONDARY);
+        const u32 j = n_list + static_cast<u32>(wave::popc64(avoids & lt));
+        if (j < list_cap) list[j] = k;
+        if (c.filter_on) {
+          rank_filter_add_id(c, id);
+          rank_filter_add_id(c, bId);
+        }
+      }
+      n_list += static_cast<u32>(wave::popc64(avoids));
+      if (n_list > list_cap) overflow = true;
+      if ((hits >> lane) & 1u) {
+        const u32 move = FWD ? land_prev - P : P - land_prev;
+        M = umin(move, move - 1);
+        C = cw_make(bId, EV_COLLISION | EV_LEF_LEF_SECONDARY);
+      }
+      pend = 0;
+    }
+    // Rounds (a candidate AT its blocker's position, moves that wrap): a lane is ready when its
+    // blocker -- the lane before it for a chain lane -- is resolved; all ready lanes below the first
+    // lane that still waits are resolved together, their draws numbered in lane order.
+    while (pend != 0) {
+      const u32 pP = wave::shfl_up1(P), pM = wave::shfl_up1(M);
+      const u32 pC = wave::shfl_up1(C), pI = wave::shfl_up1(id);
+      const u32 bP = cont ? pP : xP, bM = cont ? pM : xM, bId = cont ? pI : xI;
+      const bool b_stalled = cont ? cw_occurred(pC) : bocc;
+      const u64 ready = pend & ~((pend << 1) & contm);
+      const u64 waiting = pend & ~ready;
+      const u64 now =
+          waiting != 0 ? (ready & lanemask_lt(static_cast<u32>(wave::ctz64(waiting)))) : ready;
+      const bool mine = ((now >> lane) & 1u) != 0;
+      const bool geo = FWD ? (static_cast<u64>(P) + M >= static_cast<u64>(bP) + bM)
+                           : (static_cast<u64>(P) - M <= static_cast<u64>(bP) - bM);
+      const bool draws = mine && b_stalled && geo;
+      const u64 dm = wave::ballot(draws);
+      bool collide = draws && !never_collide;
+      if (trials && dm != 0) {
+        const u32 cnt = static_cast<u32>(wave::popc64(dm));
+        rng_ensure(c.g, cnt);
+        const u32 t = static_cast<u32>(wave::popc64(dm & lanemask_lt(lane)));
+        collide = draws && bernoulli_raw(rng_peek(c.g, c.g.pos + t), p_collide);
+        rng_advance(c.g, cnt);
+      }
+      const bool avoided = draws && !collide;
+      if (collide) {
+        const u32 move = FWD ? (bP + bM) - P : P - (bP - bM);
+        M = umin(move, move - 1);
+        C = cw_make(bId, EV_COLLISION | EV_LEF_LEF_SECONDARY);
+      }
+      const u64 am = wave::ballot(avoided);
+      if (avoided) {
+        C = cw_make(bId, EV_LEF_LEF_SECONDARY);
+        const u32 j = n_list + static_cast<u32>(wave::popc64(am & lanemask_lt(lane)));
+        if (j < list_cap) list[j] = k;
+        if (c.filter_on) {
+          rank_filter_add_id(c, id);
+          rank_filter_add_id(c, bId);
+        }
+      }
+      n_list += static_cast<u32>(wave::popc64(am));
+      if (n_list > list_cap) overflow = true;
+      pend &= ~now;
+    }
+    if (valid && (M != M0 || C != C0)) {
+      moves[k] = M;
+      coll[k] = C;
+    }
+    fin_pos = wave::bcast(P, m - 1);
+    fin_move = wave::bcast(M, m - 1);
+    fin_coll = wave::bcast(C, m - 1);
+    fin_id = wave::bcast(id, m - 1);
+  }
+  wave::sync_mem();
+  return n_list;
+}
+
+// one direction: filter, then resolve (phase-level hooks; the epoch loop runs the two filters in one loop)
+template <bool FWD>
+MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, u32 list_cap,
+                                         bool& overflow, bool correct_lef_bar, bool do_secondary) {
+  SecondaryFilter<FWD> f;
+  f.init(c, bc, list_cap, correct_lef_bar, do_secondary);
+  for (u32 bg = 0; bg < f.nbatch; bg += SecondaryFilter<FWD>::UX) f.step(bg);
+  wave::sync_mem();
+  return secondary_resolve<FWD>(c, f.n_cand, list, list_cap, overflow);
+}
+
+// both directions: the two filters in one loop, then the rev and the fwd resolve pass (draw order)
+MODLE_DEV_NOINLINE void process_secondary_both(Cell& c, BoundaryCounts bc, u32* list_rev, u32* list_fwd,
+                                               u32 list_cap, bool& overflow, u32& n_rev, u32& n_fwd) {
+  SecondaryFilter<false> fr;
+  SecondaryFilter<true> ff;
+  fr.init(c, bc, list_cap, true, true);
+  ff.init(c, bc, list_cap, true, true);
+#ifdef MODLE_PHASE_TIMERS
+  const u64 t_pass1 = wave::clock();
+#endif
+  for (u32 bg = 0; bg < fr.nbatch; bg += SecondaryFilter<false>::UX) {
+    fr.step(bg);
+    ff.step(bg);
+  }
+  wave::sync_mem();
+#ifdef MODLE_PHASE_TIMERS
+  c.ph[14] += wave::clock() - t_pass1;  // (sub_a: the filter pass; the rest of the phase is pass 2)
+#endif
+  n_rev = secondary_resolve<false>(c, fr.n_cand, list_rev, list_cap, overflow);
+  n_fwd = secondary_resolve<true>(c, ff.n_cand, list_fwd, list_cap, overflow);
+}
+
+// fix_secondary_lef_lef_collisions (reference: simulation_detect_collisions.cpp:517-644).
+// Rare (one entry per avoided secondary collision); replayed sequentially, uniformly.  The two
+// units trade places: slots i-1 and i of the rank-ordered arrays are rewritten.
+MODLE_DEV_NOINLINE void fix_secondary_rev_seq(Cell& c, const u32* list, u32 n_list) {
+  Workspace& ws = c.ws;
+  const u32 start = c.iv->start;
+  const u32 sec = EV_LEF_LEF_SECONDARY;
+  for (u32 q = 0; q < n_list; ++q) {  // list is in ascending rank order
+    const u32 i = list[q];
+    if (!cw_avoided_as(ws.r_coll[i], sec)) continue;
+    const u32 id1 = ws.r_id[i - 1], id2 = ws.r_id[i];
+    const u32 p1 = ws.r_pos[i - 1], p2 = ws.r_pos[i];
+    const u32 m1 = ws.r_move[i - 1];
+    const u32 c1 = ws.r_coll[i - 1];
+    const u32 pos1 = p1 - m1;
+    const u32 m2 = p2 > pos1 + 1 ? p2 - (pos1 + 1) : 0;
+    const u32 c2 = cw_make(id1, EV_COLLISION | sec);
+    const u32 np1 = umin(ws.f_pos[ws.f_rank[id1]], p2);
+    const u32 np2 = umin(ws.f_pos[ws.f_rank[id2]], p1);
+    wave::lockstep();
+    // unit 2 moves to slot i-1 with unit 1's old collision / move, unit 1 to slot i
+    ws.r_id[i - 1] = id2;
+    ws.r_pos[i - 1] = np2;
+    ws.r_coll[i - 1] = c1;
+    ws.r_move[i - 1] = umin(np2 - start, m1);
+    ws.r_id[i] = id1;
+    ws.r_pos[i] = np1;
+    ws.r_coll[i] = c2;
+    ws.r_move[i] = umin(np1 - start, m2);
+    ws.r_rank[id2] = i - 1;
+    ws.r_rank[id1] = i;
+    wave::sync_mem();
+  }
+}
+
+MODLE_DEV_NOINLINE void fix_secondary_fwd_seq(Cell& c, const u32* list, u32 n_list) {
+  Workspace& ws = c.ws;
+  const u32 last = c.iv->end - 1;
+  const u32 sec = EV_LEF_LEF_SECONDARY;
+  for (u32 q = n_list; q-- > 0;) {  // list is in descending rank order; the fix loop ascends
+    const u32 i = list[q];
+    if (!cw_avoided_as(ws.f_coll[i], sec)) continue;
+    const u32 id1 = ws.f_id[i], id2 = ws.f_id[i + 1];
+    const u32 p1 = ws.f_pos[i], p2 = ws.f_pos[i + 1];
+    const u32 m2 = ws.f_move[i + 1];
+    const u32 c2 = ws.f_coll[i + 1];
+    const u32 pos2 = p2 + m2;
+    const u32 m1 = pos2 > p1 + 1 ? pos2 - (p1 + 1) : 0;
+    const u32 c1 = cw_make(id2, EV_COLLISION | sec);
+    const u32 np1 = umax(ws.r_pos[ws.r_rank[id1]], p2);
+    const u32 np2 = umax(ws.r_pos[ws.r_rank[id2]], p1);
+    wave::lockstep();
+    ws.f_id[i] = id2;
+    ws.f_pos[i] = np2;
+    ws.f_coll[i] = c1;
+    ws.f_move[i] = umin(last - np2, m1);
+    ws.f_id[i + 1] = id1;
+    ws.f_pos[i + 1] = np1;
+    ws.f_coll[i + 1] = c2;
+    ws.f_move[i + 1] = umin(last - np1, m2);
+    ws.f_rank[id2] = i;
+    ws.f_rank[id1] = i + 1;
+    wave::sync_mem();
+  }
+}
+
+// Entries of the list touch the rank slots {i-1, i} (rev) / {i, i+1} (fwd).  Unless two entries are
+// adjacent ranks the swaps are independent of each other and every lane performs one; a list
+// with adjacent entries (a cascade of avoided collisions) is replayed sequentially.
+MODLE_DEV bool fix_list_has_adjacent_entries(const u32* list, u32 n_list, bool ascending) {
+  const u32 lane = wave::lane();
+  bool adj = false;
+  for (u32 base = 0; base < n_list; base += 64) {
+    const u32 q = base + lane;
+    bool a = false;
+    if (q + 1 < n_list) {
+      const u32 x = list[q], y = list[q + 1];
+      a = ascending ? (y <= x + 1) : (x <= y + 1);
+    }
+    adj = wave::any(a) || adj;
+  }
+  return adj;
+}
+
+MODLE_DEV_NOINLINE void fix_secondary_rev(Cell& c, const u32* list, u32 n_list) {
+  if (fix_list_has_adjacent_entries(list, n_list, true)) {
+    fix_secondary_rev_seq(c, list, n_list);
+    return;
+  }
+  Workspace& ws = c.ws;
+  const u32 lane = wave::lane();
+  const u32 start = c.iv->start;
+  const u32 sec = EV_LEF_LEF_SECONDARY;
+  for (u32 base = 0; base < n_list; base += 64) {
+    const u32 q = base + lane;
+    if (q < n_list) {
+      const u32 i = list[q];
+      if (cw_avoided_as(ws.r_coll[i], sec)) {
+        const u32 id1 = ws.r_id[i - 1], id2 = ws.r_id[i];
+        const u32 p1 = ws.r_pos[i - 1], p2 = ws.r_pos[i];
+        const u32 m1 = ws.r_move[i - 1];
+        const u32 c1 = ws.r_coll[i - 1];
+        const u32 pos1 = p1 - m1;
+        const u32 m2 = p2 > pos1 + 1 ? p2 - (pos1 + 1) : 0;
+        const u32 c2 = cw_make(id1, EV_COLLISION | sec);
+        const u32 np1 = umin(ws.f_pos[ws.f_rank[id1]], p2);
+        const u32 np2 = umin(ws.f_pos[ws.f_rank[id2]], p1);
+        ws.r_id[i - 1] = id2;
+        ws.r_pos[i - 1] = np2;
+        ws.r_coll[i - 1] = c1;
+        ws.r_move[i - 1] = umin(np2 - start, m1);
+        ws.r_id[i] = id1;
+        ws.r_pos[i] = np1;
+        ws.r_coll[i] = c2;
+        ws.r_move[i] = umin(np1 - start, m2);
+        ws.r_rank[id2] = i - 1;
+        ws.r_rank[id1] = i;
+      }
+    }
+  }
+  wave::sync_mem();
+}
+
+MODLE_DEV_NOINLINE void fix_secondary_fwd(Cell& c, const u32* list, u32 n_list) {
+  if (fix_list_has_adjacent_entries(list, n_list, false)) {
+    fix_secondary_fwd_seq(c, list, n_list);
+    return;
+  }
+  Workspace& ws = c.ws;
+  const u32 lane = wave::lane();
+  const u32 last = c.iv->end - 1;
+  const u32 sec = EV_LEF_LEF_SECONDARY;
+  for (u32 base = 0; base < n_list; base += 64) {
+    const u32 q = base + lane;
+    if (q < n_list) {
+      const u32 i = list[q];
+      if (cw_avoided_as(ws.f_coll[i], sec)) {
+        const u32 id1 = ws.f_id[i], id2 = ws.f_id[i + 1];
+        const u32 p1 = ws.f_pos[i], p2 = ws.f_pos[i + 1];
+        const u32 m2 = ws.f_move[i + 1];
+        const u32 c2 = ws.f_coll[i + 1];
+        const u32 pos2 = p2 + m2;
+        const u32 m1 = pos2 > p1 + 1 ? pos2 - (p1 + 1) : 0;
+        const u32 c1 = cw_make(id2, EV_COLLISION | sec);
+        const u32 np1 = umax(ws.r_pos[ws.r_rank[id1]], p2);
+        const u32 np2 = umax(ws.r_pos[ws.r_rank[id2]], p1);
+        ws.f_id[i] = id2;
+        ws.f_pos[i] = np2;
+        ws.f_coll[i] = c1;
+        ws.f_move[i] = umin(last - np2, m1);
+        ws.f_id[i + 1] = id1;
+        ws.f_pos[i + 1] = np1;
+        ws.f_coll[i + 1] = c2;
+        ws.f_move[i + 1] = umin(last - np1, m2);
+        ws.f_rank[id2] = i;
+        ws.f_rank[id1] = i + 1;
+      }
+    }
+  }
+  wave::sync_mem();
+}
+
+// fix_secondary needs the OTHER unit of the two LEFs of every list entry: entries of the rev list
+// the fwd units, entries of the fwd list the rev units.  Without a complete inverse permutation
+// their ranks come from ONE sweep over both id arrays (four ranks per lane, four blocks of loads in
+// flight per direction) against the bitmap of LEF ids the secondary pass has collected in LDS:
+// ws.r_rank / ws.f_rank then hold valid entries for those LEFs.  (The rev fix re-orders rev units
+// before the fwd fix looks at them, but it updates ws.r_rank for every unit it moves; the ids on
+// the slots a cascade of fixes touches are the ids of its entries, whatever their order.)
+MODLE_DEV_NOINLINE void lookup_partner_ranks(Cell& c, bool want_r, bool want_f) {
+  want_r = want_r && !c.inv_valid[0];
+  want_f = want_f && !c.inv_valid[1];
+  if (!want_f && !want_r) return;
+  Workspace& ws = c.ws;
+  const u32 n = wave::uniform(c.n_active);
+  const u32 lane = wave::lane();
+  wave::sync_lds();
+  constexpr u32 GB = 4;  // blocks of 256 ranks per group of loads
+  const u32 nblk = (n + 255) / 256;
+  for (u32 t0 = 0; t0 < nblk; t0 += GB) {
+    wave::U32x4 R[GB], F[GB];
+#pragma unroll
+    for (u32 g = 0; g < GB; ++g) {
+      const u32 w = 256 * (t0 + g) + 4 * lane;
+      R[g] = wave::ld4(ws.r_id, (want_r && w < n) ? w : 0u);
+      F[g] = wave::ld4(ws.f_id, (want_f && w < n) ? w : 0u);
+    }
+#pragma unroll
+    for (u32 g = 0; g < GB; ++g) {
+      const u32 w = 256 * (t0 + g) + 4 * lane;
+#pragma unroll
+      for (u32 q = 0; q < 4; ++q) {
+        const bool in = w + q < n;
+        if (want_r && in && rank_filter_test(c, R[g].v[q])) ws.r_rank[R[g].v[q]] = w + q;
+        if (want_f && in && rank_filter_test(c, F[g].v[q])) ws.f_rank[F[g].v[q]] = w + q;
+      }
+    }
+  }
+  wave::sync_mem();
+}
+
+// returns false when an internal capacity was exceeded (the cell is then flagged as failed)
+MODLE_DEV bool phase_process_collisions(Cell& c) {
+  BoundaryCounts bc;
+  PHASE(c, 8, bc = detect_boundaries(c));
+  PHASE(c, 9, detect_lef_bar<false>(c, bc); detect_lef_bar<true>(c, bc));
+  PHASE(c, 10, detect_primary(c, bc, true));
+  bool overflow = false;
+  // avoided secondary collisions are listed in device scratch: one entry per unit at most
+  u32* list_rev = c.ws.tmp[5];
+  u32* list_fwd = c.ws.tmp[6];
+  const u32 cap = c.ws.capacity_lefs;
+  u32 nr = 0, nf = 0;
+  // (the LDS sort buffer is idle from here to the release: it holds the id filter)
+  c.filter_on = !(c.inv_valid[0] && c.inv_valid[1]);
+  if (c.filter_on) rank_filter_clear(c, c.n_active);
+  PHASE(c, 11, process_secondary_both(c, bc, list_rev, list_fwd, cap, overflow, nr, nf));
+  c.filter_on = false;
+  if (overflow) c.error = ERR_LIST_OVERFLOW;
+  if (c.error != 0) return false;
+  PHASE(c, 12, if ((nr | nf) != 0) lookup_partner_ranks(c, nf != 0, nr != 0);
+        if (nr != 0) fix_secondary_rev(c, list_rev, nr);
+        if (nf != 0) fix_secondary_fwd(c, list_fwd, nf));
+  return true;
+}
+
+}  // namespace modle_dev
