@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs
     finished_interval = 0xFFFFFFFFu;
     t = wave::bcast(t, 0);  // scalar from here on: the queue loop is a scalar loop
     if (t >= a.n_tasks) break;  // every wave leaves once the queue is empty
-    if (wave::uniform(wave::load_agent_u32(wave::as_global(a.abort_flag))) != 0) {
+    if (wave::uniform(wave::load_system_u32(wave::as_global(a.abort_flag))) != 0) {
       // cancelled: tasks that never started are reported as such (all lanes store the same word)
       CellResult none;
       __builtin_memset(&none, 0, sizeof(none));
@@ -344,11 +344,16 @@ struct modle_hip_handle {
   DevBuf<CellResult> d_results;
   DevBuf<u32> d_status;
   DevBuf<u32> d_counter;
-  DevBuf<u32> d_abort;
+  // The abort word lives in host-mapped memory: modle_hip_cancel raises it with a plain store
+  // while the persistent kernel holds every CU (anything that goes through a stream -- a fill
+  // kernel, a stream memory operation, a small copy -- is executed by a kernel of its own and
+  // waits for a free CU, i.e. for the launch to end), and the waves read it over the fabric once
+  // every few epochs.
+  u32* h_abort = nullptr;
+  u32* d_abort = nullptr;  // device address of the same word
   u32* h_remaining = nullptr;  // host-mapped per-interval completion counters of the launch
   u32* d_remaining = nullptr;
   size_t remaining_cap = 0;
-  hipStream_t cancel_stream = nullptr;  // non-blocking: raises the abort word beside the kernel
   // read / written by modle_hip_cancel and modle_hip_interval_done, which may run on another host
   // thread than the one that launches and waits
   std::atomic<bool> cancelled{false};
@@ -416,8 +421,8 @@ modle_hip_handle* modle_hip_create(const modle_hip_config* c, int device, char* 
   zig.insert(zig.end(), ZIG_EXP_Y, ZIG_EXP_Y + 257);
   if (h->d_jump.ensure(jump.size()) != hipSuccess || h->d_zig.ensure(zig.size()) != hipSuccess ||
       h->d_counter.ensure(1) != hipSuccess || h->d_phase_out.ensure(2) != hipSuccess ||
-      h->d_abort.ensure(1) != hipSuccess || hipMemset(h->d_abort.p, 0, 4) != hipSuccess ||
-      hipStreamCreateWithFlags(&h->cancel_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&h->h_abort), 64, hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_abort), h->h_abort, 0) != hipSuccess ||
       hipMemcpy(h->d_jump.p, jump.data(), jump.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(h->d_zig.p, zig.data(), zig.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
       hipEventCreate(&h->ev_start) != hipSuccess || hipEventCreate(&h->ev_stop) != hipSuccess) {
@@ -433,7 +438,7 @@ void modle_hip_destroy(modle_hip_handle* h) {
   if (h->in_flight) (void)hipStreamSynchronize(h->stream);
   if (h->ev_start != nullptr) (void)hipEventDestroy(h->ev_start);
   if (h->ev_stop != nullptr) (void)hipEventDestroy(h->ev_stop);
-  if (h->cancel_stream != nullptr) (void)hipStreamDestroy(h->cancel_stream);
+  if (h->h_abort != nullptr) (void)hipHostFree(h->h_abort);
   if (h->h_remaining != nullptr) (void)hipHostFree(h->h_remaining);
   if (h->trace_host != nullptr) {
     (void)hipHostUnregister(h->trace_host);
@@ -675,7 +680,7 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
   a.results = h->d_results.p;
   a.status = h->d_status.p;
   a.task_counter = h->d_counter.p;
-  a.abort_flag = h->d_abort.p;
+  a.abort_flag = h->d_abort;
   a.interval_remaining = h->d_remaining;
   a.trace = nullptr;
   a.trace_cap = 0;
@@ -741,7 +746,7 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
     // (it came before this launch) or raises the word after the reset -- never in between, where
     // the reset would swallow it.
     std::lock_guard<std::mutex> lock(h->abort_mu);
-    HIP_TRY(hipMemsetAsync(h->d_abort.p, 0, 4, h->stream));
+    __atomic_store_n(h->h_abort, 0u, __ATOMIC_RELEASE);
     h->cancelled = false;
     const bool ev0 = hipEventRecord(h->ev_start, h->stream) == hipSuccess;
     hipLaunchKernelGGL(modle_simulate_cells, dim3(grid), dim3(kThreadsPerBlock), 0, h->stream, a);
@@ -770,8 +775,10 @@ int modle_hip_cancel(modle_hip_handle* h, char* err, size_t errlen) {
   if (!h->in_flight) return MODLE_HIP_OK;
   HIP_TRY(hipSetDevice(h->device));
   // every wave reads the word at the top of its next epoch and stops pulling tasks
-  HIP_TRY(hipMemsetAsync(h->d_abort.p, 0x01, 4, h->cancel_stream));
-  HIP_TRY(hipStreamSynchronize(h->cancel_stream));
+  // (a plain store into host-mapped memory: see the handle's h_abort; found by
+  // tests/test_gpu_cancel.py, which saw a cancel issued through a stream take effect only when
+  // the first workgroups of the launch retired)
+  __atomic_store_n(h->h_abort, 1u, __ATOMIC_RELEASE);
   h->cancelled = true;
   return MODLE_HIP_OK;
 }

@@ -244,8 +244,11 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
     } else if (epoch - num_burnin_epochs >= task.num_target_epochs) {
       break;
     }
-    // cancellation, checked once per epoch like the reference's `_ctx` (simulation.cpp:933)
-    if (lds.abort_flag != nullptr && wave::uniform(wave::load_agent_u32(lds.abort_flag)) != 0) {
+    // cancellation (the reference polls `_ctx` once per epoch, simulation.cpp:933): the abort word
+    // is in host memory (see modle_hip_cancel), one round trip over the fabric: it is read every
+    // sixteenth epoch, a few milliseconds apart
+    if (lds.abort_flag != nullptr && (epoch & 15u) == 0 &&
+        wave::uniform(wave::load_system_u32(lds.abort_flag)) != 0) {
       status = ERR_CANCELLED;
       break;
     }

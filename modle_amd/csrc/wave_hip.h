@@ -253,9 +253,9 @@ MODLE_DEV T ld_sel(const T* p, uint32_t k, bool ok, D dflt) {
   const T v = ld_stream(at(p, ok ? k : 0u));
   return ok ? v : static_cast<T>(dflt);
 }
-// word written by another agent (the host) while the kernel runs: bypasses this CU's L1
-MODLE_DEV uint32_t load_agent_u32(const uint32_t* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// word in host memory written by the host while the kernel runs (the abort word)
+MODLE_DEV uint32_t load_system_u32(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 MODLE_DEV void atomic_inc_u32(uint32_t* p) { atomicAdd(p, 1u); }
 MODLE_DEV void atomic_add_u64(uint64_t* p, uint64_t v) {

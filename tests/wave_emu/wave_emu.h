@@ -242,7 +242,7 @@ template <class T, class D>
 MODLE_DEV T ld_sel(const T* p, uint32_t k, bool ok, D dflt) {
   return ok ? p[k] : static_cast<T>(dflt);
 }
-MODLE_DEV uint32_t load_agent_u32(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+MODLE_DEV uint32_t load_system_u32(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
 MODLE_DEV void atomic_inc_u32(uint32_t* p) { __atomic_fetch_add(p, 1u, __ATOMIC_RELAXED); }
 MODLE_DEV void atomic_add_u64(uint64_t* p, uint64_t v) {
   __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
