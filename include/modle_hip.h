@@ -181,7 +181,8 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
  * scheduler_simulate.cpp:162). */
 int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen);
 /* Asks a launch in flight to stop (the counterpart of the `_ctx` flag the reference polls once
- * per epoch, simulation.cpp:933): every cell leaves at the top of its next epoch, cells that
+ * per epoch, simulation.cpp:933; here every sixteenth epoch, the word being in host-mapped memory
+ * so that it can be raised while the kernel holds every CU): every cell leaves at the top of one of its next epochs, cells that
  * have not started are skipped, and modle_hip_wait returns MODLE_HIP_ERR_CANCELLED.  Contacts
  * registered before the stop stay in the matrices.  May be called from another host thread than
  * the one that waits.  No-op when nothing is in flight. */
