@@ -43,6 +43,8 @@ struct Cell {
   // rank update re-inserts them like the units bound in between.
   u32 n_disp[2];
   bool disp_valid;
+  // upper bound of the fwd moves of this epoch (0xFFFFFFFF: unknown), set by the move adjustment
+  u32 max_fwd_move;
   // ws.r_rank / ws.f_rank ([0] rev, [1] fwd) hold the complete inverse permutation.  The rank
   // update of the epoch loop does not write it (one scattered store per unit and epoch): the
   // sparse consumers -- bind, release, fix_secondary -- get the ranks of the few LEFs they need

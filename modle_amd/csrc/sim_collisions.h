@@ -822,17 +822,18 @@ MODLE_DEV u32 stalling_barrier_pos(const Interval& iv, u32 word) {
 // one pair and the pair's corrected moves depend only on the two units (original moves, or
 // "distance to the stalling barrier - 1" for a unit that stays stalled by a barrier, which is
 // what correct_moves_for_lef_bar_collisions stores for it).
-// what one batch of detect_primary reads from device memory: the rev units of 64 ranks and a
-// slice of STAGE_CAP fwd units
-// (positions for the whole slice: every lane searches them; moves, collision words and ids for
-// its first PRIMARY_NEAR units only: a rev unit's partner is almost always among them)
-constexpr u32 PRIMARY_NEAR = 256;
-// one block of detect_primary: TWO consecutive rev ranks per lane (128 ranks, 64-bit loads) and
-// the slices of the fwd-side arrays
+// Two passes (round 3).  A rev unit pairs with the fwd unit right upstream of it only when the two
+// can meet within this epoch's moves, which a few per cent of the units can; the one-pass form
+// nevertheless loaded five words per rev unit and staged five 256-entry slices of the fwd side in
+// LDS per block of 128 rev units.  Pass 1 reads positions and rev moves only: it finds every rev
+// unit's partner (a search in a staged slice of fwd POSITIONS) and lists the pairs that pass the
+// geometric test with the largest fwd move of the epoch in place of the partner's own move (the
+// move adjustment reports it: a superset).  Pass 2 takes 64 listed pairs at a time, gathers both
+// units' words and decides, draws and corrects exactly as the reference's merge loop does; list
+// order = rank order = draw order, and no unit belongs to two pairs.
 struct PrimaryBatch {
-  wave::U32x2 R, rev_move, rev_id, rc, rbp;
+  wave::U32x2 R, rev_move;
   u32 sp[STAGE_CAP / 64];
-  u32 sm[PRIMARY_NEAR / 64], sc[PRIMARY_NEAR / 64], si[PRIMARY_NEAR / 64], sb[PRIMARY_NEAR / 64];
 };
 // `base` is even; ranks outside [first, n) are masked where the values are used
 template <class Op>
@@ -843,26 +844,11 @@ MODLE_DEV void primary_load_batch(Op op, const Workspace& ws, u32 n, u32 base, u
     const u32 kq = k0 < n ? k0 : 0u;
     b.R = wave::ld2(ws.r_pos, kq);
     b.rev_move = wave::ld2(ws.r_move, kq);
-    b.rev_id = wave::ld2(ws.r_id, kq);
-    b.rc = wave::ld2(ws.r_coll, kq);
-    // position of the barrier that stalls the unit (meaningful where the word says LEF-BAR):
-    // having it here keeps a dependent load, and with it a wait for everything in flight, out of
-    // the block's work
-    b.rbp = wave::ld2(stalling_barrier_positions<false>(ws), kq);
   }
 #pragma unroll
   for (u32 q = 0; q < STAGE_CAP / 64; ++q) {
     const u32 t = lane + 64 * q;
     b.sp[q] = op(ws.f_pos, w0 + t, w0 + t < n, UNBOUND, b.sp[q]);
-  }
-#pragma unroll
-  for (u32 q = 0; q < PRIMARY_NEAR / 64; ++q) {
-    const u32 t = lane + 64 * q;
-    const bool in = w0 + t < n;
-    b.sm[q] = op(ws.f_move, w0 + t, in, 0, b.sm[q]);
-    b.sc[q] = op(ws.f_coll, w0 + t, in, 0, b.sc[q]);
-    b.si[q] = op(ws.f_id, w0 + t, in, 0, b.si[q]);
-    b.sb[q] = op(stalling_barrier_positions<true>(ws), w0 + t, in, 0, b.sb[q]);
   }
 }
 
@@ -881,157 +867,181 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
   const bool never_collide = p.p_bypass != 0.0 && p_collide == 0.0;
   const bool trials = p.p_bypass != 0.0 && !never_collide;
   const u32 prim = EV_COLLISION | EV_LEF_LEF_PRIMARY;
-  // LDS slices of the fwd-side arrays, ranks [w0, w0 + STAGE_CAP): positions in the staging
-  // buffer, moves / collision words / ids / barrier positions in the (idle) sort buffer
-  u32* stage = c.lds.stage;
-  u32* st_move = reinterpret_cast<u32*>(c.lds.sort_lds);
-  u32* st_coll = st_move + PRIMARY_NEAR;
-  u32* st_id = st_coll + PRIMARY_NEAR;
-  u32* st_bp = st_id + PRIMARY_NEAR;
-  static_assert(4 * PRIMARY_NEAR <= 2 * SORT_LDS_CAP, "fwd slices do not fit the sort buffer");
+  u32* stage = c.lds.stage;  // slice of the fwd positions, ranks [w0, w0 + STAGE_CAP)
+  // the list of pairs (rank of the rev unit, fwd units strictly upstream of it) in scratch that is
+  // idle until the secondary pass; lanes with nothing to store hit scratch words of their own
+  u32* const q_k = ws.tmp[0];
+  u32* const q_pf = ws.tmp[1];
+  u32* const dump = reinterpret_cast<u32*>(ws.sort_keys) + 2 * lane;
+  const u64 fwd_reach = wave::uniform(c.max_fwd_move);
+  u32 n_cand = 0;
   u32 carry_pos = 0;
   u32 carry_pf = 0;  // fwd units strictly upstream of the last rev unit handled so far
-  // pf = number of fwd units strictly upstream of R.  pf is monotone in the rank, so slices of
-  // the fwd arrays starting at the previous block's value are staged in LDS (one round trip
-  // together with the block's rev-side loads) and everything is looked up there; units whose
-  // partner lies beyond the slice use device memory.  The loads of the next block are issued as
-  // soon as this block knows where its last unit falls among the fwd units, before the rest of
-  // its work.  What they can miss are this block's updates of the fwd unit at the start of the
-  // next slice (its move and collision word), and no unit of the next block can pair with that
-  // unit: it lies upstream of this block's last rev unit, which is then the "first rev unit
-  // downstream of it".
+  // ---- pass 1 ----------------------------------------------------------------------------------
+  // pf = number of fwd units strictly upstream of R.  pf is monotone in the rank, so a slice of the
+  // fwd positions starting at the previous block's value is staged in LDS (one round trip together
+  // with the block's rev-side loads) and searched there; units whose partner lies beyond the slice
+  // use device memory.  The loads of the next block are issued as soon as this block knows where
+  // its last unit falls among the fwd units.
   const u32 first = bc.n5;
-  PrimaryBatch cur;
-  primary_load_batch(wave::LdRaw{}, ws, n, first & ~1u, 0, lane, cur, true);
-  for (u32 base = first & ~1u; base < n; base += 128) {
-    const u32 w0 = carry_pf > 0 ? carry_pf - 1 : 0;
-    primary_load_batch(wave::LdMask{}, ws, n, base, w0, lane, cur, false);  // (defaults outside the range)
-    u32 k[2], R[2], rev_move_k[2], rev_id_k[2], rc_k[2], rbp_k[2];
-    bool act[2];
-#pragma unroll
-    for (u32 j = 0; j < 2; ++j) {
-      k[j] = base + 2 * lane + j;
-      act[j] = k[j] >= first && k[j] < n;
-      R[j] = act[j] ? cur.R.v[j] : UNBOUND;
-      rev_move_k[j] = act[j] ? cur.rev_move.v[j] : 0u;
-      rev_id_k[j] = act[j] ? cur.rev_id.v[j] : 0u;
-      rc_k[j] = act[j] ? cur.rc.v[j] : 0u;
-      rbp_k[j] = act[j] ? cur.rbp.v[j] : 0u;
-    }
-    wave::lockstep();
-#pragma unroll
-    for (u32 q = 0; q < STAGE_CAP / 64; ++q) stage[lane + 64 * q] = cur.sp[q];
-#pragma unroll
-    for (u32 q = 0; q < PRIMARY_NEAR / 64; ++q) {
-      const u32 t = lane + 64 * q;
-      st_move[t] = cur.sm[q];
-      st_coll[t] = cur.sc[q];
-      st_id[t] = cur.si[q];
-      st_bp[t] = cur.sb[q];
-    }
-    wave::sync_lds();
-    const u32 prev_in = wave::shfl_up1(R[1]);
-    const u32 Rprev0 = lane > 0 ? prev_in : carry_pos;
-    // number of staged positions below R: a fixed-step search (no loop control, the eight steps
-    // are the same for every unit; the two reads of a round are issued together)
-    u32 lo[2] = {0, 0};
-    static_assert(STAGE_CAP == 256, "the search below covers 256 entries");
-#pragma unroll
-    for (u32 sft = 128; sft >= 1; sft >>= 1) {
-      u32 sv[2];
-#pragma unroll
-      for (u32 j = 0; j < 2; ++j) sv[j] = stage[lo[j] + sft - 1];
-      wave::sched_fence();
+  {
+    PrimaryBatch cur;
+    primary_load_batch(wave::LdRaw{}, ws, n, first & ~1u, 0, lane, cur, true);
+    for (u32 base = first & ~1u; base < n; base += 128) {
+      const u32 w0 = carry_pf > 0 ? carry_pf - 1 : 0;
+      primary_load_batch(wave::LdMask{}, ws, n, base, w0, lane, cur, false);  // (defaults outside the range)
+      u32 k[2], R[2], rev_move[2];
+      bool act[2];
 #pragma unroll
       for (u32 j = 0; j < 2; ++j) {
-        if (sv[j] < R[j]) lo[j] += sft;
+        k[j] = base + 2 * lane + j;
+        act[j] = k[j] >= first && k[j] < n;
+        R[j] = act[j] ? cur.R.v[j] : UNBOUND;
+        rev_move[j] = act[j] ? cur.rev_move.v[j] : 0u;
       }
-      wave::sched_fence();
-    }
-    const u32 st_last = stage[STAGE_CAP - 1];
-    u32 pf[2] = {0, 0};
+      wave::lockstep();
 #pragma unroll
-    for (u32 j = 0; j < 2; ++j) {
-      if (act[j]) {
-        u32 l = lo[j];
-        if (l == STAGE_CAP - 1 && st_last < R[j]) l = STAGE_CAP;
-        if (l == STAGE_CAP && w0 + STAGE_CAP < n) {
-          pf[j] = lower_bound_u32(ws.f_pos, n, R[j]);
-        } else {
-          pf[j] = umin(w0 + l, n);
+      for (u32 q = 0; q < STAGE_CAP / 64; ++q) stage[lane + 64 * q] = cur.sp[q];
+      wave::sync_lds();
+      const u32 prev_in = wave::shfl_up1(R[1]);
+      const u32 Rprev0 = lane > 0 ? prev_in : carry_pos;
+      // number of staged positions below R: a fixed-step search (no loop control, the eight steps
+      // are the same for every unit; the two reads of a round are issued together)
+      u32 lo[2] = {0, 0};
+      static_assert(STAGE_CAP == 256, "the search below covers 256 entries");
+#pragma unroll
+      for (u32 sft = 128; sft >= 1; sft >>= 1) {
+        u32 sv[2];
+#pragma unroll
+        for (u32 j = 0; j < 2; ++j) sv[j] = stage[lo[j] + sft - 1];
+        wave::sched_fence();
+#pragma unroll
+        for (u32 j = 0; j < 2; ++j) {
+          if (sv[j] < R[j]) lo[j] += sft;
         }
+        wave::sched_fence();
       }
-    }
-    // pf of the last active unit
-    const u64 am = wave::ballot(act[0] || act[1]);
-    const u32 next_pf = wave::bcast(act[1] ? pf[1] : pf[0], static_cast<u32>(63 - wave::clz64(am)));
-    if (base + 128 < n) {
-      primary_load_batch(wave::LdRaw{}, ws, n, base + 128, next_pf > 0 ? next_pf - 1 : 0, lane, cur, true);
-    }
-    // the partner of each unit (the fwd unit right upstream of it): its five words are read from
-    // the slices together, without branches; partners beyond the slices come from device memory
-    static_assert(PRIMARY_NEAR == STAGE_CAP, "one staged range for all five fwd-side arrays");
-    bool cand[2] = {false, false};
-    u32 F[2], rev_move[2], fwd_move[2], fwd_id_s[2], fc_s[2], fbp_s[2];
-    bool has[2], staged[2];
-#pragma unroll
-    for (u32 j = 0; j < 2; ++j) {
-      has[j] = act[j] && pf[j] >= 1 && pf[j] < i2;
-      const u32 kf = pf[j] - 1;
-      staged[j] = has[j] && kf >= w0 && kf - w0 < STAGE_CAP;
-      const u32 e = staged[j] ? kf - w0 : 0u;
-      F[j] = stage[e];
-      fwd_move[j] = st_move[e];
-      fwd_id_s[j] = st_id[e];
-      fc_s[j] = st_coll[e];
-      fbp_s[j] = st_bp[e];
-      rev_move[j] = rev_move_k[j];
-    }
-    wave::sched_fence();
-    if (wave::any((has[0] && !staged[0]) || (has[1] && !staged[1]))) {
+      const u32 st_last = stage[STAGE_CAP - 1];
+      u32 pf[2] = {0, 0};
 #pragma unroll
       for (u32 j = 0; j < 2; ++j) {
-        if (has[j] && !staged[j]) {
-          const u32 kf = pf[j] - 1;
-          F[j] = ws.f_pos[kf];
-          fwd_move[j] = ws.f_move[kf];
-          fwd_id_s[j] = ws.f_id[kf];
-          fc_s[j] = ws.f_coll[kf];
-          fbp_s[j] = stalling_barrier_positions<true>(ws)[kf];
+        if (act[j]) {
+          u32 l = lo[j];
+          if (l == STAGE_CAP - 1 && st_last < R[j]) l = STAGE_CAP;
+          if (l == STAGE_CAP && w0 + STAGE_CAP < n) {
+            pf[j] = lower_bound_u32(ws.f_pos, n, R[j]);
+          } else {
+            pf[j] = umin(w0 + l, n);
+          }
         }
-        // (the loads end HERE: where values loaded on a rare path merge with the common path the
-        // compiler waits for everything in flight -- the next block's loads -- on both)
-        wave::pin(F[j]);
-        wave::pin(fwd_move[j]);
-        wave::pin(fwd_id_s[j]);
-        wave::pin(fc_s[j]);
-        wave::pin(fbp_s[j]);
+      }
+      // pf of the last active unit
+      const u64 am = wave::ballot(act[0] || act[1]);
+      const u32 next_pf = wave::bcast(act[1] ? pf[1] : pf[0], static_cast<u32>(63 - wave::clz64(am)));
+      if (base + 128 < n) {
+        primary_load_batch(wave::LdRaw{}, ws, n, base + 128, next_pf > 0 ? next_pf - 1 : 0, lane, cur, true);
+      }
+      // the partner of each unit (the fwd unit right upstream of it): its position from the slice,
+      // without branches; partners beyond the slice come from device memory
+      u32 F[2];
+      bool has[2], staged[2];
+#pragma unroll
+      for (u32 j = 0; j < 2; ++j) {
+        has[j] = act[j] && pf[j] >= 1 && pf[j] < i2;
+        const u32 kf = pf[j] - 1;
+        staged[j] = has[j] && kf >= w0 && kf - w0 < STAGE_CAP;
+        F[j] = stage[staged[j] ? kf - w0 : 0u];
+      }
+      wave::sched_fence();
+      if (wave::any((has[0] && !staged[0]) || (has[1] && !staged[1]))) {
+#pragma unroll
+        for (u32 j = 0; j < 2; ++j) {
+          if (has[j] && !staged[j]) F[j] = ws.f_pos[pf[j] - 1];
+          // (the load ends HERE: where a value loaded on a rare path merges with the common path
+          // the compiler waits for everything in flight -- the next block's loads -- on both)
+          wave::pin(F[j]);
+        }
+      }
+      bool cand[2];
+#pragma unroll
+      for (u32 j = 0; j < 2; ++j) {
+        const u32 Rprev = j == 0 ? Rprev0 : R[0];
+        const bool first_after = (k[j] == first) || Rprev <= F[j];
+        const u32 delta = R[j] - F[j];  // > 0 by construction (where it is used)
+        cand[j] = has[j] && first_after && static_cast<u64>(delta) < static_cast<u64>(rev_move[j]) + fwd_reach;
+      }
+      const u64 cm0 = wave::ballot(cand[0]), cm1 = wave::ballot(cand[1]);
+      {
+        // rank order: unit (lane, j) after the units of the lanes before it and after unit 0 of its
+        // own lane
+        const u64 lt = lanemask_lt(lane);
+        const u32 e0 = n_cand + static_cast<u32>(wave::popc64(cm0 & lt) + wave::popc64(cm1 & lt));
+        const u32 e1 = e0 + (cand[0] ? 1u : 0u);
+        *(cand[0] ? &q_k[e0] : dump) = k[0];
+        *(cand[0] ? &q_pf[e0] : dump + 1) = pf[0];
+        *(cand[1] ? &q_k[e1] : dump) = k[1];
+        *(cand[1] ? &q_pf[e1] : dump + 1) = pf[1];
+      }
+      n_cand += static_cast<u32>(wave::popc64(cm0) + wave::popc64(cm1));
+      carry_pos = wave::bcast(R[1], 63);
+      carry_pf = next_pf;
+    }
+  }
+  wave::sync_mem();
+  // ---- pass 2 ----------------------------------------------------------------------------------
+  struct PairRegs {
+    u32 k, pf, R, rev_move, rev_id, rc, rbp, F, fwd_move, fwd_id, fc, fbp;
+  };
+  const auto load_pairs = [&](u32 base, u32 kk, u32 pp, PairRegs& r) {
+    const bool in = base + lane < n_cand;
+    const u32 k = in ? kk : 0u, kf = in ? pp - 1 : 0u;  // (a listed pair has pf >= 1)
+    r.k = kk;
+    r.pf = pp;
+    r.R = wave::LdRaw{}(ws.r_pos, k, true, 0, 0u);
+    r.rev_move = wave::LdRaw{}(ws.r_move, k, true, 0, 0u);
+    r.rev_id = wave::LdRaw{}(ws.r_id, k, true, 0, 0u);
+    r.rc = wave::LdRaw{}(ws.r_coll, k, true, 0, 0u);
+    r.rbp = wave::LdRaw{}(stalling_barrier_positions<false>(ws), k, true, 0, 0u);
+    r.F = wave::LdRaw{}(ws.f_pos, kf, true, 0, 0u);
+    r.fwd_move = wave::LdRaw{}(ws.f_move, kf, true, 0, 0u);
+    r.fwd_id = wave::LdRaw{}(ws.f_id, kf, true, 0, 0u);
+    r.fc = wave::LdRaw{}(ws.f_coll, kf, true, 0, 0u);
+    r.fbp = wave::LdRaw{}(stalling_barrier_positions<true>(ws), kf, true, 0, 0u);
+  };
+  const auto list_k = [&](u32 base) { return wave::ld_sel(q_k, base + lane, base + lane < n_cand, 0u); };
+  const auto list_pf = [&](u32 base) { return wave::ld_sel(q_pf, base + lane, base + lane < n_cand, 1u); };
+  PairRegs pcur;
+  u32 nk = 0, np = 1;
+  if (n_cand != 0) {
+    load_pairs(0, list_k(0), list_pf(0), pcur);
+    if (64 < n_cand) {
+      nk = list_k(64);
+      np = list_pf(64);
+    }
+  }
+  for (u32 base = 0; base < n_cand; base += 64) {
+    const PairRegs q = pcur;
+    if (base + 64 < n_cand) {
+      load_pairs(base + 64, nk, np, pcur);
+      if (base + 128 < n_cand) {
+        nk = list_k(base + 128);
+        np = list_pf(base + 128);
       }
     }
-#pragma unroll
-    for (u32 j = 0; j < 2; ++j) {
-      const u32 Rprev = j == 0 ? Rprev0 : R[0];
-      const bool first_after = (k[j] == first) || Rprev <= F[j];
-      const u32 delta = R[j] - F[j];  // > 0 by construction (where it is used)
-      cand[j] = has[j] && first_after && static_cast<u64>(delta) < static_cast<u64>(rev_move[j]) + fwd_move[j];
-    }
-    const u64 cm0 = wave::ballot(cand[0]), cm1 = wave::ballot(cand[1]);
-    bool hit[2] = {cand[0] && !never_collide, cand[1] && !never_collide};
-    if (trials && (cm0 | cm1) != 0) {
-      const u32 cnt = static_cast<u32>(wave::popc64(cm0) + wave::popc64(cm1));
+    const bool valid = base + lane < n_cand;
+    const u32 delta = q.R - q.F;
+    // (pass 1 has checked that the pair exists and that the rev unit is the first one downstream of
+    // the fwd unit; what is left is the geometric test with the partner's own move)
+    const bool cand = valid && static_cast<u64>(delta) < static_cast<u64>(q.rev_move) + q.fwd_move;
+    const u64 cm = wave::ballot(cand);
+    bool hit = cand && !never_collide;
+    if (trials && cm != 0) {
+      const u32 cnt = static_cast<u32>(wave::popc64(cm));
       rng_ensure(c.g, cnt);
-      // draws in rank order: unit (lane, j) after the units of the lanes before it and after unit 0
-      // of its own lane
-      const u64 lt = lanemask_lt(lane);
-      const u32 t0 = static_cast<u32>(wave::popc64(cm0 & lt) + wave::popc64(cm1 & lt));
-      const u32 t1 = t0 + (cand[0] ? 1u : 0u);
-      hit[0] = cand[0] && bernoulli_raw(rng_peek(c.g, c.g.pos + t0), p_collide);
-      hit[1] = cand[1] && bernoulli_raw(rng_peek(c.g, c.g.pos + t1), p_collide);
+      const u32 t = static_cast<u32>(wave::popc64(cm & lanemask_lt(lane)));
+      hit = cand && bernoulli_raw(rng_peek(c.g, c.g.pos + t), p_collide);
       rng_advance(c.g, cnt);
     }
-    // The collisions are rare (a few units per block) and their handling is long divergent code:
-    // it runs once for the lane's unit that collided, and a second time only when both units of a
-    // lane did.
     const auto handle_hit = [&](u32 pf_h, u32 k_h, u32 R_h, u32 F_h, u32 rev_move_h, u32 fwd_move_h, u32 rev_id_k_h,
                                 u32 fwd_id_s_h, u32 rc_k_h, u32 fc_s_h, u32 rbp_k_h, u32 fbp_s_h) {
       const u32 kf = pf_h - 1;
@@ -1085,22 +1095,9 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
         ws.f_move[kf] = cpos_fwd - F_h;
       }
     };
-    if (wave::any(hit[0] || hit[1])) {
-      const u32 h = hit[0] ? 0u : 1u;
-      if (hit[0] || hit[1]) {
-        handle_hit(h ? pf[1] : pf[0], h ? k[1] : k[0], h ? R[1] : R[0], h ? F[1] : F[0], h ? rev_move[1] : rev_move[0],
-                   h ? fwd_move[1] : fwd_move[0], h ? rev_id_k[1] : rev_id_k[0], h ? fwd_id_s[1] : fwd_id_s[0],
-                   h ? rc_k[1] : rc_k[0], h ? fc_s[1] : fc_s[0], h ? rbp_k[1] : rbp_k[0], h ? fbp_s[1] : fbp_s[0]);
-      }
-      if (wave::any(hit[0] && hit[1])) {
-        if (hit[0] && hit[1]) {
-          handle_hit(pf[1], k[1], R[1], F[1], rev_move[1], fwd_move[1], rev_id_k[1], fwd_id_s[1], rc_k[1], fc_s[1],
-                     rbp_k[1], fbp_s[1]);
-        }
-      }
+    if (wave::any(hit)) {
+      if (hit) handle_hit(q.pf, q.k, q.R, q.F, q.rev_move, q.fwd_move, q.rev_id, q.fwd_id, q.rc, q.fc, q.rbp, q.fbp);
     }
-    carry_pos = wave::bcast(R[1], 63);
-    carry_pf = next_pf;
   }
   wave::sync_mem();
 }

@@ -84,6 +84,7 @@ MODLE_DEV void init_cell(Cell& c, const Params& p, const Interval& iv, const Wor
   c.n_disp[0] = 0;
   c.n_disp[1] = 0;
   c.disp_valid = true;  // (nothing has been ranked yet: nothing can be out of order)
+  c.max_fwd_move = 0xFFFFFFFFu;
   c.n_bound = 0;
   c.inv_valid[0] = true;  // (reset_cell_buffers / run_test_phases write complete permutations)
   c.inv_valid[1] = true;

@@ -223,6 +223,7 @@ struct AdjustSweepX4 {
   i32 carry_d;
   bool carry_ok, carry_cross;
   i64 viol_rank;
+  u32 lane_max;  // largest move this lane has stored
   wave::U32x4 ids;
   Blk cur;
 
@@ -263,6 +264,7 @@ struct AdjustSweepX4 {
     carry_ok = false;
     carry_cross = false;
     viol_rank = -1;
+    lane_max = 0;
     load_ids(0);
     load_blk(0);
     if (1 < nblk) load_ids(1);
@@ -321,6 +323,7 @@ struct AdjustSweepX4 {
       cross[j] = ok[j] && (FWD ? static_cast<u64>(P[j]) + Mnew > last
                                : static_cast<u64>(P[j]) <= static_cast<u64>(start) + Mnew);
       O.v[FWD ? j : 3 - j] = (bnd[j] && do_clamp) ? umin(Mnew, FWD ? last - P[j] : P[j] - start) : Mnew;
+      lane_max = umax(lane_max, k[j] < n ? O.v[FWD ? j : 3 - j] : 0u);
     }
     if (w + 3 < n) {
       wave::st4(mv_out, w, O);
@@ -614,11 +617,15 @@ MODLE_DEV_NOINLINE void adjust_moves_both_x4(Cell& c, const u32* mv_rev, const u
   }
   viol_rev = r.viol_rank;
   viol_fwd = f.viol_rank;
+  // the largest fwd move of the epoch bounds what a fwd unit can contribute to a primary collision
+  // (detect_primary's filter pass); unknown when the sequential replay is going to change moves
+  c.max_fwd_move = viol_fwd < 0 ? wave::bcast(wave_prefix_max_u32(f.lane_max), 63) : 0xFFFFFFFFu;
 }
 
 // `all_bound`: every active LEF is bound (the epoch loop's invariant at this point)
 MODLE_DEV void phase_generate_moves(Cell& c, bool burnin_completed, bool all_bound = true) {
   const Params& p = *c.p;
+  c.max_fwd_move = 0xFFFFFFFFu;  // (set by adjust_moves_both_x4 when it runs)
   if (!all_bound) {
     PHASE(c, 5, generate_moves_dir<false>(c, burnin_completed ? p.rev_speed : p.rev_speed_burnin, p.rev_std);
           generate_moves_dir<true>(c, burnin_completed ? p.fwd_speed : p.fwd_speed_burnin, p.fwd_std);
