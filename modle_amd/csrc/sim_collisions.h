@@ -831,6 +831,11 @@ MODLE_DEV u32 stalling_barrier_pos(const Interval& iv, u32 word) {
 // move adjustment reports it: a superset).  Pass 2 takes 64 listed pairs at a time, gathers both
 // units' words and decides, draws and corrects exactly as the reference's merge loop does; list
 // order = rank order = draw order, and no unit belongs to two pairs.
+#ifndef MODLE_PRIMARY_BACK
+#define MODLE_PRIMARY_BACK 128  // (a smaller value in a test build of the emulator exercises the fall-back)
+#endif
+constexpr u32 PRIMARY_BACK = MODLE_PRIMARY_BACK;  // fwd ranks before a block's first rev rank in its slice
+static_assert(PRIMARY_BACK + 128 <= STAGE_CAP, "the slice must reach the block's last rank");
 struct PrimaryBatch {
   wave::U32x2 R, rev_move;
   u32 sp[STAGE_CAP / 64];
@@ -876,19 +881,24 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
   const u64 fwd_reach = wave::uniform(c.max_fwd_move);
   u32 n_cand = 0;
   u32 carry_pos = 0;
-  u32 carry_pf = 0;  // fwd units strictly upstream of the last rev unit handled so far
   // ---- pass 1 ----------------------------------------------------------------------------------
-  // pf = number of fwd units strictly upstream of R.  pf is monotone in the rank, so a slice of the
-  // fwd positions starting at the previous block's value is staged in LDS (one round trip together
-  // with the block's rev-side loads) and searched there; units whose partner lies beyond the slice
-  // use device memory.  The loads of the next block are issued as soon as this block knows where
-  // its last unit falls among the fwd units.
+  // pf = number of fwd units strictly upstream of R.  Every LEF has its rev unit at or upstream of
+  // its fwd unit, so pf(k) = k - (LEFs whose loop spans the position of rev unit k): at most k, and
+  // below it by the local depth of coverage, a few units to a few dozen.  The slice of fwd positions
+  // a block of 128 rev ranks searches is therefore the FIXED window of ranks [base - PRIMARY_BACK,
+  // base + 128): nothing about the loads of a block depends on the search of the block before it
+  // (it used to: the slice started where the previous block's last unit fell, so every block paid
+  // a full memory round trip after its search), and they are requested two blocks ahead.  A unit
+  // with more than PRIMARY_BACK loops over it is looked up in device memory.
   const u32 first = bc.n5;
+  const auto slice_start = [](u32 base) { return base > PRIMARY_BACK ? base - PRIMARY_BACK : 0u; };
   {
-    PrimaryBatch cur;
-    primary_load_batch(wave::LdRaw{}, ws, n, first & ~1u, 0, lane, cur, true);
-    for (u32 base = first & ~1u; base < n; base += 128) {
-      const u32 w0 = carry_pf > 0 ? carry_pf - 1 : 0;
+    const u32 b0 = first & ~1u;
+    PrimaryBatch pa, pb;
+    primary_load_batch(wave::LdRaw{}, ws, n, b0, slice_start(b0), lane, pa, true);
+    if (b0 + 128 < n) primary_load_batch(wave::LdRaw{}, ws, n, b0 + 128, slice_start(b0 + 128), lane, pb, true);
+    const auto block = [&](PrimaryBatch& cur, u32 base) {
+      const u32 w0 = slice_start(base);
       primary_load_batch(wave::LdMask{}, ws, n, base, w0, lane, cur, false);  // (defaults outside the range)
       u32 k[2], R[2], rev_move[2];
       bool act[2];
@@ -903,6 +913,8 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
 #pragma unroll
       for (u32 q = 0; q < STAGE_CAP / 64; ++q) stage[lane + 64 * q] = cur.sp[q];
       wave::sync_lds();
+      // (the block's registers are free: request the block after the next one)
+      if (base + 256 < n) primary_load_batch(wave::LdRaw{}, ws, n, base + 256, slice_start(base + 256), lane, cur, true);
       const u32 prev_in = wave::shfl_up1(R[1]);
       const u32 Rprev0 = lane > 0 ? prev_in : carry_pos;
       // number of staged positions below R: a fixed-step search (no loop control, the eight steps
@@ -923,23 +935,24 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
       }
       const u32 st_last = stage[STAGE_CAP - 1];
       u32 pf[2] = {0, 0};
+      bool beyond = false;  // the answer lies outside the slice (rare): device memory
 #pragma unroll
       for (u32 j = 0; j < 2; ++j) {
-        if (act[j]) {
-          u32 l = lo[j];
-          if (l == STAGE_CAP - 1 && st_last < R[j]) l = STAGE_CAP;
-          if (l == STAGE_CAP && w0 + STAGE_CAP < n) {
-            pf[j] = lower_bound_u32(ws.f_pos, n, R[j]);
-          } else {
-            pf[j] = umin(w0 + l, n);
-          }
-        }
+        u32 l = lo[j];
+        if (l == STAGE_CAP - 1 && st_last < R[j]) l = STAGE_CAP;
+        pf[j] = umin(w0 + l, n);
+        // every staged position is at or above R and the slice does not start at rank 0: fwd units
+        // before the slice may be at or above R too.  (The other end cannot be exceeded: pf <= k.)
+        beyond = beyond || (act[j] && ((l == 0 && w0 > 0) || (l == STAGE_CAP && w0 + STAGE_CAP < n)));
       }
-      // pf of the last active unit
-      const u64 am = wave::ballot(act[0] || act[1]);
-      const u32 next_pf = wave::bcast(act[1] ? pf[1] : pf[0], static_cast<u32>(63 - wave::clz64(am)));
-      if (base + 128 < n) {
-        primary_load_batch(wave::LdRaw{}, ws, n, base + 128, next_pf > 0 ? next_pf - 1 : 0, lane, cur, true);
+      if (wave::any(beyond)) {
+#pragma unroll
+        for (u32 j = 0; j < 2; ++j) {
+          const u32 l = pf[j] - w0;
+          if (act[j] && ((l == 0 && w0 > 0) || (l == STAGE_CAP && w0 + STAGE_CAP < n)))
+            pf[j] = lower_bound_u32(ws.f_pos, n, R[j]);
+          wave::pin(pf[j]);  // (the loads of this rare path end here)
+        }
       }
       // the partner of each unit (the fwd unit right upstream of it): its position from the slice,
       // without branches; partners beyond the slice come from device memory
@@ -984,7 +997,10 @@ MODLE_DEV_NOINLINE void detect_primary(Cell& c, BoundaryCounts bc, bool fuse_cor
       }
       n_cand += static_cast<u32>(wave::popc64(cm0) + wave::popc64(cm1));
       carry_pos = wave::bcast(R[1], 63);
-      carry_pf = next_pf;
+    };
+    for (u32 base = b0; base < n; base += 256) {
+      block(pa, base);
+      if (base + 128 < n) block(pb, base + 128);
     }
   }
   wave::sync_mem();
