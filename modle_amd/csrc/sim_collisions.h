@@ -1187,40 +1187,49 @@ constexpr u32 SEC_BOCC = 0x80000000u;  // ... the blocker (not a candidate) is s
 // Pass 1 as a stepper, so that the rev and the fwd instance can share one loop (they are
 // independent: no draws, each reads and writes its own direction's arrays): two dependency chains
 // per iteration instead of one.
+// composition of two steps of the candidate recurrence x' = p | (q & x), packed as p | q << 1:
+// `later` applied after `earlier`
+MODLE_DEV u32 sec_compose(u32 earlier, u32 later) {
+  const u32 p = (later & 1u) | ((later >> 1) & earlier & 1u);
+  const u32 q = (later >> 1) & (earlier >> 1) & 1u;
+  return p | (q << 1);
+}
+MODLE_DEV u32 wave_prefix_sec_compose(u32 v) {
+#define MODLE_STEP(S) v = sec_compose(wave::scan_move<S>(v, 2u), v);
+  MODLE_SCAN_STEPS(MODLE_STEP)
+#undef MODLE_STEP
+  return v;
+}
+
 template <bool FWD>
 struct SecondaryFilter {
-  static constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
-  struct UnitRegs {
-    u32 P[UX], M[UX], C[UX], B[UX];
+  // FOUR consecutive ranks per lane, blocks of 256 ranks (128-bit loads); fwd: lane 0 holds the
+  // highest ranks of a block and walks its four units downwards, so that (lane, unit) is the
+  // visiting order in both directions.  "Is a candidate" is a recurrence along the visiting order,
+  //     x[u] = pot[u] & (blocker_stalled[u] | x[u - 1])
+  // (pot: free follower that can reach its blocker's position): a step is the function
+  // x -> p | (q & x) with p = pot & blocker_stalled, q = pot, steps compose to functions of the
+  // same form, so the lane composes its four steps, ONE cross-lane scan composes the lanes, and
+  // every lane replays its four steps from the value that enters it.
+  struct Blk {
+    wave::U32x4 P, M, C, B;
   };
   const u32 *pos, *coll, *barpos;
   u32 *moves, *q_k, *dump;
-  u32 n, lane, nbatch, cap, n_cand, carry_pos, carry_coll;
+  u32 n, lane, nblk, cap, n_cand, carry_pos, carry_coll;
   i32 f_first;
   bool correct_lef_bar, do_secondary, carry_pending;
-  UnitRegs cur;
+  Blk cur;
 
-  MODLE_DEV_MEMBER void load_units(bool raw, u32 bg, UnitRegs& r) const {
-#pragma unroll
-    for (u32 u = 0; u < UX; ++u) {
-      const u32 bi = bg + u;
-      // (ranks stay far below 2^31: 32-bit index arithmetic)
-      const i32 kk = FWD ? static_cast<i32>(n) - 1 - static_cast<i32>(bi * 64 + lane)
-                         : static_cast<i32>(bi * 64 + lane);
-      const bool act = kk >= 0 && static_cast<u32>(kk) < n;
-      const u32 k = act ? static_cast<u32>(kk) : 0;
-      if (raw) {
-        r.P[u] = wave::LdRaw{}(pos, k, act, 0, r.P[u]);
-        r.M[u] = wave::LdRaw{}(moves, k, act, 0, r.M[u]);
-        r.C[u] = wave::LdRaw{}(coll, k, act, 0, r.C[u]);
-        r.B[u] = wave::LdRaw{}(barpos, k, act, 0, r.B[u]);
-      } else {
-        r.P[u] = wave::LdMask{}(pos, k, act, 0, r.P[u]);
-        r.M[u] = wave::LdMask{}(moves, k, act, 0, r.M[u]);
-        r.C[u] = wave::LdMask{}(coll, k, act, 0, r.C[u]);
-        r.B[u] = wave::LdMask{}(barpos, k, act, 0, r.B[u]);
-      }
-    }
+  // first rank of this lane in block t of the sweep (t = 0 is the block the sweep starts with)
+  MODLE_DEV_MEMBER u32 word0(u32 t) const { return (FWD ? nblk - 1 - t : t) * 256 + 4 * (FWD ? 63 - lane : lane); }
+  MODLE_DEV_MEMBER void load_blk(u32 t, Blk& r) const {
+    const u32 w = word0(t);
+    const u32 wq = w < n ? w : 0u;
+    r.P = wave::ld4(pos, wq);
+    r.M = wave::ld4(moves, wq);
+    r.C = wave::ld4(coll, wq);
+    r.B = wave::ld4(barpos, wq);
   }
   MODLE_DEV_MEMBER void init(Cell& c, BoundaryCounts bc, u32 list_cap, bool lef_bar, bool secondary) {
     Workspace& ws = c.ws;
@@ -1232,7 +1241,7 @@ struct SecondaryFilter {
     moves = FWD ? ws.f_move : ws.r_move;
     // the candidate list (rank | flags) lives in a scratch array that is idle during the collision
     // passes; lanes with nothing to store hit a scratch word of their own (stores under a branch
-    // cannot be counted by the compiler, and the wait for the next group's loads then becomes a
+    // cannot be counted by the compiler, and the wait for the next block's loads then becomes a
     // wait for every store in flight)
     q_k = FWD ? ws.tmp[1] : ws.tmp[0];
     dump = reinterpret_cast<u32*>(ws.sort_keys) + 2 * lane + (FWD ? 1 : 0);
@@ -1243,62 +1252,77 @@ struct SecondaryFilter {
     // fwd: followers i-1 for i = (n - min(n3, n3-1) - 1) .. 1 descending, blocker = rank i
     f_first = FWD ? static_cast<i32>(bc.n3 == 0 ? n - 1 : n - bc.n3) - 1
                   : static_cast<i32>(umax(1u, bc.n5));
-    nbatch = (n + 63) / 64;
+    nblk = (n + 255) / 256;
     n_cand = 0;
     carry_pos = 0;
     carry_coll = 0;
     carry_pending = false;
-    load_units(true, 0, cur);
+    load_blk(0, cur);
   }
-  // one group of UX batches (bg = first batch of the group)
-  MODLE_DEV_MEMBER void step(u32 bg) {
-    UnitRegs g = cur;
-    load_units(false, bg, g);  // (defaults of the lanes outside the range)
-    if (bg + UX < nbatch) load_units(true, bg + UX, cur);
+  // one block of 256 ranks
+  MODLE_DEV_MEMBER void step(u32 t) {
+    const Blk g = cur;
+    if (t + 1 < nblk) load_blk(t + 1, cur);
+    const u32 w = word0(t);
+    u32 k[4], P[4], M[4], C[4];
+    bool act[4];
 #pragma unroll
-    for (u32 u = 0; u < UX; ++u) {
-      const u32 bi = bg + u;
-      if (bi >= nbatch) break;
-      const i32 kk = FWD ? static_cast<i32>(n) - 1 - static_cast<i32>(bi * 64 + lane)
-                         : static_cast<i32>(bi * 64 + lane);
-      const bool act = kk >= 0 && static_cast<u32>(kk) < n;
-      const u32 k = act ? static_cast<u32>(kk) : 0;
-      const u32 P = g.P[u], M0 = g.M[u], C = g.C[u];
-      u32 M = M0;
-      if (correct_lef_bar && act && cw_occurred_as(C, EV_LEF_BAR)) {
-        const u32 bp = g.B[u];
-        M = (FWD ? bp - P : P - bp) - 1;
+    for (u32 j = 0; j < 4; ++j) {  // j: position in visiting order inside the lane
+      const u32 q = FWD ? 3 - j : j;
+      k[j] = w + q;
+      act[j] = k[j] < n;
+      P[j] = g.P.v[q];
+      C[j] = act[j] ? g.C.v[q] : 0u;
+      const u32 M0 = g.M.v[q];
+      M[j] = M0;
+      if (correct_lef_bar && act[j] && cw_occurred_as(C[j], EV_LEF_BAR)) {
+        const u32 bp = g.B.v[q];
+        M[j] = (FWD ? bp - P[j] : P[j] - bp) - 1;
       }
-      *((act && M != M0) ? &moves[k] : dump) = M;
-      const bool follower = do_secondary && act && (FWD ? (kk <= f_first) : (kk >= f_first));
-      // the blocker: the unit visited before this one
-      const u32 bP_in = wave::shfl_up1(P), bC_in = wave::shfl_up1(C);
-      const u32 bP = lane > 0 ? bP_in : carry_pos, bC = lane > 0 ? bC_in : carry_coll;
-      const bool pot = follower && !cw_occurred(C) &&
-                       (FWD ? static_cast<u64>(P) + M >= bP : static_cast<u64>(P) - M <= bP);
-      const u64 potm = wave::ballot(pot);
-      // blocker stalled already, or itself a candidate (then it may become stalled in pass 2):
-      // propagate along runs of consecutive candidates.  The unit before lane 0 counts as "may be
-      // stalled" when it is a candidate (its outcome is not known in this pass).
-      const u64 occm = wave::ballot(cw_occurred(bC)) | (carry_pending ? u64(1) : u64(0));
-      u64 pend = potm & occm;
-      for (;;) {
-        const u64 grown = pend | (potm & (pend << 1));
-        if (grown == pend) break;
-        pend = grown;
-      }
-      {
-        const bool mine = ((pend >> lane) & 1u) != 0;
-        const u32 e = n_cand + static_cast<u32>(wave::popc64(pend & lanemask_lt(lane)));
-        const bool cont = lane > 0 ? ((pend >> (lane - 1)) & 1u) != 0 : carry_pending;
-        *((mine && e < cap) ? &q_k[e] : dump) =
-            k | (cont ? SEC_CONT : 0u) | (cw_occurred(bC) ? SEC_BOCC : 0u);
-      }
-      n_cand += static_cast<u32>(wave::popc64(pend));
-      carry_pending = (pend >> 63) != 0;
-      carry_pos = wave::bcast(P, 63);
-      carry_coll = wave::bcast(C, 63);
+      *((act[j] && M[j] != M0) ? &moves[k[j]] : dump) = M[j];
     }
+    // the blocker of a unit: the unit visited before it
+    const u32 pP_in = wave::shfl_up1(P[3]), pC_in = wave::shfl_up1(C[3]);
+    bool pot[4], bocc[4];
+    u32 fn = 2u;  // the lane's four steps composed (identity: p = 0, q = 1)
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j) {
+      const u32 bP = j == 0 ? (lane > 0 ? pP_in : carry_pos) : P[j - 1];
+      const u32 bC = j == 0 ? (lane > 0 ? pC_in : carry_coll) : C[j - 1];
+      const i32 kk = static_cast<i32>(k[j]);
+      const bool follower = do_secondary && act[j] && (FWD ? (kk <= f_first) : (kk >= f_first));
+      pot[j] = follower && !cw_occurred(C[j]) &&
+               (FWD ? static_cast<u64>(P[j]) + M[j] >= bP : static_cast<u64>(P[j]) - M[j] <= bP);
+      bocc[j] = cw_occurred(bC);
+      fn = sec_compose(fn, (pot[j] && bocc[j] ? 1u : 0u) | (pot[j] ? 2u : 0u));
+    }
+    // blocker stalled already, or itself a candidate (then it may become stalled in pass 2): the
+    // unit before the block counts as "may be stalled" when it is a candidate (its outcome is not
+    // known in this pass)
+    const u32 incl = wave_prefix_sec_compose(fn);
+    const u32 before_in = wave::shfl_up1(incl);
+    const u32 before = lane > 0 ? before_in : 2u;  // the lanes before this one, composed
+    bool x_prev = ((before & 1u) | ((before >> 1) & (carry_pending ? 1u : 0u))) != 0;
+    bool x[4], cont[4];
+    u32 lane_cnt = 0;
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j) {
+      cont[j] = x_prev;
+      x[j] = pot[j] && (bocc[j] || x_prev);
+      x_prev = x[j];
+      lane_cnt += x[j] ? 1u : 0u;
+    }
+    const u32 ps = wave_prefix_sum_u32(lane_cnt);
+    u32 e = n_cand + ps - lane_cnt;
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j) {
+      *((x[j] && e < cap) ? &q_k[e] : dump) = k[j] | (cont[j] ? SEC_CONT : 0u) | (bocc[j] ? SEC_BOCC : 0u);
+      e += x[j] ? 1u : 0u;
+    }
+    n_cand += wave::bcast(ps, 63);
+    carry_pending = wave::bcast(x[3], 63);
+    carry_pos = wave::bcast(P[3], 63);
+    carry_coll = wave::bcast(C[3], 63);
   }
 };
 
@@ -1522,7 +1546,7 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
                                          bool& overflow, bool correct_lef_bar, bool do_secondary) {
   SecondaryFilter<FWD> f;
   f.init(c, bc, list_cap, correct_lef_bar, do_secondary);
-  for (u32 bg = 0; bg < f.nbatch; bg += SecondaryFilter<FWD>::UX) f.step(bg);
+  for (u32 t = 0; t < f.nblk; ++t) f.step(t);
   wave::sync_mem();
   return secondary_resolve<FWD>(c, f.n_cand, list, list_cap, overflow);
 }
@@ -1537,9 +1561,9 @@ MODLE_DEV_NOINLINE void process_secondary_both(Cell& c, BoundaryCounts bc, u32* 
 #ifdef MODLE_PHASE_TIMERS
   const u64 t_pass1 = wave::clock();
 #endif
-  for (u32 bg = 0; bg < fr.nbatch; bg += SecondaryFilter<false>::UX) {
-    fr.step(bg);
-    ff.step(bg);
+  for (u32 t = 0; t < fr.nblk; ++t) {
+    fr.step(t);
+    ff.step(t);
   }
   wave::sync_mem();
 #ifdef MODLE_PHASE_TIMERS
