@@ -71,6 +71,11 @@ struct SimArgs {
   u32 max_lefs;
   u32 max_barriers;
   u32 active_waves;  // waves of every workgroup that pull tasks (diagnostic: MODLE_HIP_ACTIVE_WAVES)
+  // helper-wave mode (sim_pair.h), chosen by the host for launches with at most half as many tasks
+  // as wave slots: waves 0 .. pair_mains-1 of a workgroup pull tasks, wave 7-m is the helper of
+  // main wave m (waves are dealt to the four SIMDs in turn: with one or two main waves per
+  // workgroup every wave of a pair has a SIMD of its own); 0 = off
+  u32 pair_mains;
 };
 
 __device__ __forceinline__ Workspace device_carve(char* base, u32 max_lefs, u32 max_barriers, u32 hist_len) {
@@ -129,6 +134,7 @@ __device__ __forceinline__ WaveLds make_wave_lds(BlockLds& s, int wave_in_block)
   l.rng_state = s.rng_state[wave_in_block];
   l.rng_snap = s.rng_snap[wave_in_block];
   l.abort_flag = nullptr;
+  l.mbox = nullptr;
   l.jump_table = s.jump;
   l.zig_norm_x = s.zig;
   l.zig_norm_y = s.zig + 129;
@@ -145,6 +151,9 @@ __device__ __forceinline__ WaveLds make_wave_lds(BlockLds& s, int wave_in_block)
 }
 
 __device__ __forceinline__ void load_block_tables(BlockLds& s, const DeviceTables& t, int nthreads) {
+  // (the snapshot words double as the hand-over words of the helper-wave mode: sequence numbers
+  // start from zero on both sides)
+  for (u32 i = threadIdx.x; i < static_cast<u32>(kWavesPerBlock) * 8; i += nthreads) (&s.rng_snap[0][0])[i] = 0;
   const u64* jump = wave::as_global(t.jump);
   const f64* zig = wave::as_global(t.zig);
   for (u32 i = threadIdx.x; i < JUMP_TABLE_WORDS; i += nthreads) s.jump[i] = jump[i];
@@ -157,7 +166,31 @@ __global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs
   load_block_tables(s, a.tables, kThreadsPerBlock);
   const int wave_in_block = wave::uniform(static_cast<int>(threadIdx.x / 64));
   const u32 slot = blockIdx.x * kWavesPerBlock + wave_in_block;
-  const WaveLds lds = make_wave_lds(s, wave_in_block);
+  WaveLds lds = make_wave_lds(s, wave_in_block);
+  if (a.pair_mains != 0) {
+    static_assert(PAIR_WORDS * 4 <= sizeof(s.rng_snap[0]), "hand-over words live in the helper's snapshot words");
+    const int main_wave = wave_in_block < kWavesPerBlock / 2 ? wave_in_block : kWavesPerBlock - 1 - wave_in_block;
+    if (static_cast<u32>(main_wave) >= a.pair_mains) return;
+    u32* mbox = reinterpret_cast<u32*>(s.rng_snap[kWavesPerBlock - 1 - main_wave]);
+    if (wave_in_block != main_wave) {
+      // the helper: the main wave's generator, tables and workspace, its own staging buffer
+      Cell c;
+      c.p = &a.params;
+      c.lds = make_wave_lds(s, main_wave);
+      c.lds.stage = lds.stage;
+      c.ws = device_carve(a.workspace + static_cast<u64>(blockIdx.x * kWavesPerBlock + main_wave) * a.workspace_stride,
+                          a.max_lefs, a.max_barriers, a.params.hist_len);
+      c.g.ring = c.lds.ring;
+      c.g.jump = c.lds.jump_table;
+      c.g.state = c.lds.rng_state;
+      c.g.snap = c.lds.rng_snap;
+      c.n_hit[0] = 0;
+      c.n_hit[1] = 0;
+      pair_serve(c, wave::as_global(a.intervals), mbox);
+      return;
+    }
+    lds.mbox = mbox;
+  }
   const Workspace ws = device_carve(a.workspace + static_cast<u64>(slot) * a.workspace_stride,
                                     a.max_lefs, a.max_barriers, a.params.hist_len);
   if (static_cast<u32>(wave_in_block) >= a.active_waves) return;
@@ -181,7 +214,10 @@ __global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs
     }
     finished_interval = 0xFFFFFFFFu;
     t = wave::bcast(t, 0);  // scalar from here on: the queue loop is a scalar loop
-    if (t >= a.n_tasks) break;  // every wave leaves once the queue is empty
+    if (t >= a.n_tasks) {  // every wave leaves once the queue is empty
+      if (lds.mbox != nullptr) pair_dismiss(lds.mbox);
+      break;
+    }
     if (wave::uniform(wave::load_system_u32(wave::as_global(a.abort_flag))) != 0) {
       // cancelled: tasks that never started are reported as such (all lanes store the same word)
       CellResult none;
@@ -734,6 +770,19 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
   a.n_tasks = static_cast<u32>(sorted.size());
   a.max_lefs = max_lefs;
   a.max_barriers = max_barriers;
+  // helper-wave mode for launches that leave at least half of the wave slots empty (sim_pair.h);
+  // MODLE_HIP_PAIRED=0 / 1 turns it off / on whatever the number of tasks (tests, A/B runs)
+  a.pair_mains = 0;
+  {
+    constexpr size_t kMaxMains = kWavesPerBlock / 2;
+    bool paired = sorted.size() <= static_cast<size_t>(grid) * kMaxMains;
+    if (const char* pm = std::getenv("MODLE_HIP_PAIRED"); pm != nullptr && pm[0] != '\0') paired = pm[0] != '0';
+#ifdef MODLE_STAGE_TRACE
+    paired = false;  // (the stage trace records the generator position between the phases)
+#endif
+    if (paired)
+      a.pair_mains = static_cast<u32>(std::min(kMaxMains, (sorted.size() + static_cast<size_t>(grid) - 1) / grid));
+  }
   a.active_waves = kWavesPerBlock;
   if (const char* aw = std::getenv("MODLE_HIP_ACTIVE_WAVES"); aw != nullptr) {
     // diagnostic: how the kernel time scales with the waves in flight per CU

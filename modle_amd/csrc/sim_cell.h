@@ -54,6 +54,8 @@ struct Cell {
   // the secondary pass collects the LEFs of its avoided collisions in the LDS id filter (for the
   // rank lookups of fix_secondary)
   bool filter_on;
+  // helper-wave mode (sim_pair.h): sequence number of the last request posted to the helper
+  u32 pair_seq;
 #ifdef MODLE_PHASE_TIMERS
   u64 ph[16];     // profiling build: time spent per phase (wave::clock ticks)
 #endif
@@ -77,6 +79,21 @@ constexpr u32 ERR_LIST_OVERFLOW = 1;
 constexpr u32 ERR_TRIAL_OVERFLOW = 2;
 constexpr u32 ERR_INTERNAL = 3;
 constexpr u32 ERR_CANCELLED = 4;  // the host raised the abort word (reference: _ctx polled per epoch)
+
+// copy of an interval descriptor whose pointers are known to address device memory
+MODLE_DEV Interval interval_in_device_memory(const Interval& iv) {
+  Interval g = iv;
+  g.bar_pos = wave::as_global(iv.bar_pos);
+  g.bar_dir = wave::as_global(iv.bar_dir);
+  g.bar_stp_active = wave::as_global(iv.bar_stp_active);
+  g.bar_stp_inactive = wave::as_global(iv.bar_stp_inactive);
+  g.bar_occupancy = wave::as_global(iv.bar_occupancy);
+  g.contacts = wave::as_global(iv.contacts);
+  g.occupancy_1d = wave::as_global(iv.occupancy_1d);
+  g.missed_updates = wave::as_global(iv.missed_updates);
+  g.bar_bucket = wave::as_global(iv.bar_bucket);
+  return g;
+}
 
 template <class T>
 MODLE_DEV void swap_ptr(T*& a, T*& b) {

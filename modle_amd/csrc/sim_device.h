@@ -11,5 +11,6 @@
 #include "sim_release.h"           // extrude and release_lefs
 #include "sim_contacts.h"          // sample_and_register_contacts
 #include "sim_burnin.h"            // run_burnin: loop-size statistics and the stability test
+#include "sim_pair.h"             // helper-wave mode: a second wave of the workgroup draws the moves and the barrier states of a burn-in epoch
 #include "sim_epoch.h"             // the epoch loop of one cell (Simulation::simulate_one_cell)
 #include "sim_hooks.h"             // phase-level and unit-level test entry points (the reference's Simulation::test_* hooks)

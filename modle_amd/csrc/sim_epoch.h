@@ -49,21 +49,6 @@ MODLE_DEV void activate_lefs(Cell& c, u32 n_old, u32 n_new) {
   wave::sync_mem();
 }
 
-// copy of an interval descriptor whose pointers are known to address device memory
-MODLE_DEV Interval interval_in_device_memory(const Interval& iv) {
-  Interval g = iv;
-  g.bar_pos = wave::as_global(iv.bar_pos);
-  g.bar_dir = wave::as_global(iv.bar_dir);
-  g.bar_stp_active = wave::as_global(iv.bar_stp_active);
-  g.bar_stp_inactive = wave::as_global(iv.bar_stp_inactive);
-  g.bar_occupancy = wave::as_global(iv.bar_occupancy);
-  g.contacts = wave::as_global(iv.contacts);
-  g.occupancy_1d = wave::as_global(iv.occupancy_1d);
-  g.missed_updates = wave::as_global(iv.missed_updates);
-  g.bar_bucket = wave::as_global(iv.bar_bucket);
-  return g;
-}
-
 MODLE_DEV void init_cell(Cell& c, const Params& p, const Interval& iv, const Workspace& ws,
                          const WaveLds& lds, u32 n_lefs, const u64 prng[4]) {
   c.p = &p;
@@ -89,6 +74,8 @@ MODLE_DEV void init_cell(Cell& c, const Params& p, const Interval& iv, const Wor
   c.inv_valid[0] = true;  // (reset_cell_buffers / run_test_phases write complete permutations)
   c.inv_valid[1] = true;
   c.filter_on = false;
+  // (the helper keeps counting the requests across the tasks of its main wave)
+  c.pair_seq = lds.mbox != nullptr ? wave::uniform(lds.mbox[PAIR_REQ]) : 0u;
 #ifdef MODLE_PHASE_TIMERS
   for (int i = 0; i < 16; ++i) c.ph[i] = 0;
 #endif
@@ -277,10 +264,15 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
             c.n_bound = c.n_active;
           });
     trace_stage(c, epoch, 0);
+    // helper-wave mode (sim_pair.h), burn-in epochs (nothing draws between the bind phase and the
+    // moves): the helper draws the moves and the barrier states while this wave ranks the units
+    const bool offload = lds.mbox != nullptr && !burnin_completed;
+    if (offload) pair_request(c, burnin_completed, task.interval);
     PHASE(c, 2, rank_update<false>(c, false));
     PHASE(c, 3, rank_update<true>(c, false));
     trace_stage(c, epoch, 1);
     if (c.error != 0) {
+      if (offload) pair_take_back(c);
       status = c.error;
       break;
     }
@@ -295,9 +287,17 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
 
     sum_active += c.n_active;
     ++sim_epochs;
-    phase_generate_moves(c, burnin_completed);
-    trace_stage(c, epoch, 2);
-    PHASE(c, 7, barriers_next_state(c));
+    if (offload) {
+      c.max_fwd_move = 0xFFFFFFFFu;
+      PHASE(c, 5, pair_wait(c, PAIR_MOVES));
+      phase_adjust_moves_by_id(c);
+      trace_stage(c, epoch, 2);
+      PHASE(c, 7, pair_take_back(c));
+    } else {
+      phase_generate_moves(c, burnin_completed);
+      trace_stage(c, epoch, 2);
+      PHASE(c, 7, barriers_next_state(c));
+    }
     const bool coll_ok = phase_process_collisions(c);
     trace_stage(c, epoch, 3);
     if (!coll_ok) {

@@ -623,6 +623,19 @@ MODLE_DEV_NOINLINE void adjust_moves_both_x4(Cell& c, const u32* mv_rev, const u
 }
 
 // `all_bound`: every active LEF is bound (the epoch loop's invariant at this point)
+// the move adjustment on the id-ordered moves of ws.tmp[8] (rev) / ws.tmp[9] (fwd)
+MODLE_DEV void phase_adjust_moves_by_id(Cell& c) {
+  u32* mv_rev = c.ws.tmp[8];
+  u32* mv_fwd = c.ws.tmp[9];
+  if (wave::uniform(c.iv->end) < 0x7F000000u) {  // (the 32-bit scans apply: see adjust_moves_rev)
+    PHASE(c, 6, i64 vr; i64 vf; adjust_moves_both_x4(c, mv_rev, mv_fwd, vr, vf);
+          wave::sync_mem();
+          adjust_moves_rev(c, true, true, mv_rev, 0, &vr); adjust_moves_fwd(c, true, true, mv_fwd, 1, &vf));
+  } else {
+    PHASE(c, 6, adjust_moves_rev(c, true, true, mv_rev); adjust_moves_fwd(c, true, true, mv_fwd));
+  }
+}
+
 MODLE_DEV void phase_generate_moves(Cell& c, bool burnin_completed, bool all_bound = true) {
   const Params& p = *c.p;
   c.max_fwd_move = 0xFFFFFFFFu;  // (set by adjust_moves_both_x4 when it runs)
@@ -633,20 +646,14 @@ MODLE_DEV void phase_generate_moves(Cell& c, bool burnin_completed, bool all_bou
     PHASE(c, 6, adjust_moves_rev(c, true, true); adjust_moves_fwd(c, true, true));
     return;
   }
-  // id-ordered moves live in scratch that is idle until the secondary pass lists its avoided
-  // collisions there
-  u32* mv_rev = c.ws.tmp[5];
-  u32* mv_fwd = c.ws.tmp[6];
+  // id-ordered moves: two scratch arrays of their own (the helper wave of sim_pair.h fills them
+  // while the rank updates use the others)
+  u32* mv_rev = c.ws.tmp[8];
+  u32* mv_fwd = c.ws.tmp[9];
   PHASE(c, 5, generate_moves_by_id(c, burnin_completed ? p.rev_speed : p.rev_speed_burnin, p.rev_std, mv_rev);
         generate_moves_by_id(c, burnin_completed ? p.fwd_speed : p.fwd_speed_burnin, p.fwd_std, mv_fwd);
         wave::sync_mem());
-  if (wave::uniform(c.iv->end) < 0x7F000000u) {  // (the 32-bit scans apply: see adjust_moves_rev)
-    PHASE(c, 6, i64 vr; i64 vf; adjust_moves_both_x4(c, mv_rev, mv_fwd, vr, vf);
-          wave::sync_mem();
-          adjust_moves_rev(c, true, true, mv_rev, 0, &vr); adjust_moves_fwd(c, true, true, mv_fwd, 1, &vf));
-  } else {
-    PHASE(c, 6, adjust_moves_rev(c, true, true, mv_rev); adjust_moves_fwd(c, true, true, mv_fwd));
-  }
+  phase_adjust_moves_by_id(c);
 }
 
 }  // namespace modle_dev

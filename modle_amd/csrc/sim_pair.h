@@ -1,0 +1,112 @@
+// sim_pair.h -- part of sim_device.h (included by it, in this order): helper-wave mode.
+//
+// A launch with fewer tasks than half the wave slots of the GPU (BASELINE config 1: 512 cells of
+// chr1 on 2048 slots) lasts as long as its longest cell, and one wave runs a cell no faster than
+// a CPU core of the reference does (scheduler_simulate.cpp:190-271: one cell per worker).  In such
+// launches a second wave of the workgroup -- the helper -- takes over the part of a burn-in epoch
+// that depends on nothing but the PRNG stream: generate_moves (simulation.cpp:272-330) followed by
+// ExtrusionBarriers::next_state (extrusion_barriers.cpp:219-230), which come one after the other
+// in the stream, while the main wave runs the two rank updates (no draws) and then the move
+// adjustment.  The stream stays ONE stream consumed in the reference's order: the generator
+// (ring, lane states, snapshots: LDS of the main wave; position and end of the ring: handed over)
+// belongs to exactly one of the two waves at any time.
+//
+//   main:    bind | request | rank rev, rank fwd | wait moves | adjust moves | wait all | collisions ...
+//   helper:        | moves rev, moves fwd | signal moves | barrier states + stalling lists | signal all
+//
+#pragma once
+
+namespace modle_dev {
+
+// Hand-over words (u32, in LDS; the helper's own snapshot words, which it does not use):
+constexpr u32 PAIR_REQ = 0;        // main -> helper: sequence number of the request
+constexpr u32 PAIR_MOVES = 1;      // helper -> main: the moves of request <seq> are in device memory
+constexpr u32 PAIR_ALL = 2;        // helper -> main: barrier states, lists and generator are back
+constexpr u32 PAIR_N_ACTIVE = 3;   // request: active LEFs (PAIR_EXIT: the main wave has no more tasks)
+constexpr u32 PAIR_BURNIN_DONE = 4;
+constexpr u32 PAIR_INTERVAL = 5;   // request: index of the task's interval
+constexpr u32 PAIR_POS = 6;        // generator: stream position (2 words), there and back
+constexpr u32 PAIR_GEN_END = 8;    // generator: end of the ring (2 words), there and back
+constexpr u32 PAIR_N_HIT = 10;     // reply: entries of the two lists of stalling barriers
+constexpr u32 PAIR_WORDS = 12;
+constexpr u32 PAIR_EXIT = 0xFFFFFFFFu;
+
+MODLE_DEV void pair_put_u64(u32* m, u32 at, u64 v) {
+  m[at] = static_cast<u32>(v);
+  m[at + 1] = static_cast<u32>(v >> 32);
+}
+MODLE_DEV u64 pair_get_u64(const u32* m, u32 at) {
+  return wave::uniform(static_cast<u64>(m[at]) | (static_cast<u64>(m[at + 1]) << 32));
+}
+
+// main wave: hands the generator to the helper together with what the two phases need
+MODLE_DEV void pair_request(Cell& c, bool burnin_completed, u32 interval) {
+  u32* m = c.lds.mbox;
+  wave::lockstep();
+  if (wave::lane() == 0) {
+    m[PAIR_N_ACTIVE] = c.n_active;
+    m[PAIR_BURNIN_DONE] = burnin_completed ? 1u : 0u;
+    m[PAIR_INTERVAL] = interval;
+    pair_put_u64(m, PAIR_POS, c.g.pos);
+    pair_put_u64(m, PAIR_GEN_END, c.g.gen_end);
+  }
+  ++c.pair_seq;
+  wave::st_release_wg(&m[PAIR_REQ], c.pair_seq);
+}
+// main wave: waits until the helper has signalled `what` (PAIR_MOVES / PAIR_ALL) for the request
+MODLE_DEV void pair_wait(Cell& c, u32 what) {
+  const u32* m = c.lds.mbox;
+  while (wave::uniform(wave::ld_acquire_wg(&m[what])) != c.pair_seq) wave::nap();
+}
+// main wave: the generator and the lists of stalling barriers come back
+MODLE_DEV void pair_take_back(Cell& c) {
+  pair_wait(c, PAIR_ALL);
+  const u32* m = c.lds.mbox;
+  c.g.pos = pair_get_u64(m, PAIR_POS);
+  c.g.gen_end = pair_get_u64(m, PAIR_GEN_END);
+  c.n_hit[0] = wave::uniform(m[PAIR_N_HIT]);
+  c.n_hit[1] = wave::uniform(m[PAIR_N_HIT + 1]);
+}
+// main wave, once its task queue is empty: the helper leaves its loop
+MODLE_DEV void pair_dismiss(u32* m) {
+  const u32 seq = wave::uniform(m[PAIR_REQ]) + 1;
+  wave::lockstep();
+  if (wave::lane() == 0) m[PAIR_N_ACTIVE] = PAIR_EXIT;
+  wave::st_release_wg(&m[PAIR_REQ], seq);
+}
+
+// The helper's loop.  `c` is a cell context that shares the main wave's generator, tables and
+// workspace (moves, barrier states, lists) and has the helper's own staging buffer; `intervals`
+// is the launch's interval table.
+MODLE_DEV void pair_serve(Cell& c, const Interval* intervals, u32* m) {
+  u32 seen = wave::uniform(m[PAIR_REQ]);
+  for (;;) {
+    u32 seq;
+    while ((seq = wave::uniform(wave::ld_acquire_wg(&m[PAIR_REQ]))) == seen) wave::nap();
+    seen = seq;
+    const u32 n_active = wave::uniform(m[PAIR_N_ACTIVE]);
+    if (n_active == PAIR_EXIT) break;
+    const bool burnin_completed = wave::uniform(m[PAIR_BURNIN_DONE]) != 0;
+    const Interval ivg = interval_in_device_memory(intervals[wave::uniform(m[PAIR_INTERVAL])]);
+    c.iv = &ivg;
+    c.n_active = n_active;
+    c.g.pos = pair_get_u64(m, PAIR_POS);
+    c.g.gen_end = pair_get_u64(m, PAIR_GEN_END);
+    const Params& p = *c.p;
+    generate_moves_by_id(c, burnin_completed ? p.rev_speed : p.rev_speed_burnin, p.rev_std, c.ws.tmp[8]);
+    generate_moves_by_id(c, burnin_completed ? p.fwd_speed : p.fwd_speed_burnin, p.fwd_std, c.ws.tmp[9]);
+    wave::sync_mem();
+    wave::st_release_wg(&m[PAIR_MOVES], seq);
+    barriers_next_state(c);
+    wave::lockstep();
+    if (wave::lane() == 0) {
+      pair_put_u64(m, PAIR_POS, c.g.pos);
+      pair_put_u64(m, PAIR_GEN_END, c.g.gen_end);
+      m[PAIR_N_HIT] = c.n_hit[0];
+      m[PAIR_N_HIT + 1] = c.n_hit[1];
+    }
+    wave::st_release_wg(&m[PAIR_ALL], seq);
+  }
+}
+
+}  // namespace modle_dev

@@ -115,7 +115,7 @@ struct CellResult {
 // read and write contiguous memory.  What the reference indexes by LEF id (binding epoch, the
 // PRNG draw order of moves / release / bind) lives in id-ordered arrays, with the two inverse
 // permutations r_rank / f_rank connecting the views.
-constexpr u32 NUM_TMP = 8;
+constexpr u32 NUM_TMP = 10;
 struct Workspace {
   u32 *r_pos, *r_id, *r_move, *r_coll;  // rev units, by rev rank
   u32 *f_pos, *f_id, *f_move, *f_coll;  // fwd units, by fwd rank
@@ -149,6 +149,7 @@ struct WaveLds {
   u64* sort_lds;          // SORT_LDS_CAP keys (ranking of newly bound units)
   u32* stage;             // STAGE_CAP words (staged slice of sorted positions)
   u64* rng_snap;          // 2 x 4 words: generator state at the start of the two blocks in the ring
+  u32* mbox;              // helper-wave mode (sim_pair.h): the pair's hand-over words in LDS, or nullptr
   const u32* abort_flag;  // device word polled once per epoch (cancellation) or nullptr
   u64* trace;             // optional per-epoch trace (4 words per epoch) or nullptr
   u32 trace_cap;          // epochs the trace buffer holds

@@ -257,6 +257,18 @@ MODLE_DEV T ld_sel(const T* p, uint32_t k, bool ok, D dflt) {
 MODLE_DEV uint32_t load_system_u32(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// Words in LDS through which two waves of a workgroup hand work to each other (helper wave,
+// sim_pair.h): a release store publishes everything the wave has written before it -- device
+// memory included -- to the waves of its workgroup, an acquire load that sees the stored value
+// makes those writes visible to the reader.
+MODLE_DEV void st_release_wg(uint32_t* p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+MODLE_DEV uint32_t ld_acquire_wg(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// gives the issue slots of the SIMD to the other waves for a few dozen cycles (spin loops)
+MODLE_DEV void nap() { __builtin_amdgcn_s_sleep(2); }
 MODLE_DEV void atomic_inc_u32(uint32_t* p) { atomicAdd(p, 1u); }
 MODLE_DEV void atomic_add_u64(uint64_t* p, uint64_t v) {
   atomicAdd(reinterpret_cast<unsigned long long*>(p), static_cast<unsigned long long>(v));

@@ -120,3 +120,22 @@ def assert_same_outputs(a, b, what):
     assert np.array_equal(ca, cb), f"{what}: contact matrices differ"
     if oa is not None and ob is not None:
         assert np.array_equal(oa, ob), f"{what}: 1-D occupancy differs"
+
+
+def launch_modes():
+    """The two ways the kernel runs a cell (MODLE_HIP_PAIRED, read at every launch): "0" one wave
+    per cell, "1" a main wave and its helper (modle_amd/csrc/sim_pair.h).  Left alone the library
+    picks by the number of tasks, so a parity test states the mode and runs both: yields the mode
+    with the variable set, and restores it."""
+    import os
+
+    old = os.environ.get("MODLE_HIP_PAIRED")
+    try:
+        for mode in ("0", "1"):
+            os.environ["MODLE_HIP_PAIRED"] = mode
+            yield mode
+    finally:
+        if old is None:
+            os.environ.pop("MODLE_HIP_PAIRED", None)
+        else:
+            os.environ["MODLE_HIP_PAIRED"] = old

@@ -4,7 +4,7 @@ per-cell counter of the HIP path must equal the oracle's."""
 import pytest
 
 from fuzz_cases import random_case, random_case_v2, random_case_v3, random_case_v4
-from parity_cases import assert_same_outputs, assert_same_results
+from parity_cases import assert_same_outputs, assert_same_results, launch_modes
 
 pytestmark = pytest.mark.gpu
 
@@ -42,13 +42,14 @@ def _compare(oracle, case, label):
     oc, om, oo, ores = oracle.simulate_interval(
         cfg, chrom["start"], chrom["end"], chrom["bar_pos"], chrom["bar_dir"],
         case["stp_active"], case["stp_inactive"], tasks, nthreads=8, track_occupancy=track)
-    sim = api.Simulator(cfg, 0)
-    try:
-        gc, gm, go, gres = sim.simulate_interval(
-            chrom["start"], chrom["end"], chrom["bar_pos"], chrom["bar_dir"], case["stp_active"],
-            case["stp_inactive"], tasks)
-    finally:
-        sim.close()
-    what = f"{label}: {case['kw']}, size {case['size']}"
-    assert_same_results(ores, gres, what)
-    assert_same_outputs((oc, om, oo), (gc, gm, go if track else None), what)
+    for mode in launch_modes():
+        sim = api.Simulator(cfg, 0)
+        try:
+            gc, gm, go, gres = sim.simulate_interval(
+                chrom["start"], chrom["end"], chrom["bar_pos"], chrom["bar_dir"], case["stp_active"],
+                case["stp_inactive"], tasks)
+        finally:
+            sim.close()
+        what = f"{label} (helper waves {mode}): {case['kw']}, size {case['size']}"
+        assert_same_results(ores, gres, what)
+        assert_same_outputs((oc, om, oo), (gc, gm, go if track else None), what)

@@ -4,7 +4,7 @@ missed-update counter and per-cell (epochs, burn-in epochs, contacts, PRNG outpu
 import numpy as np
 import pytest
 
-from parity_cases import CASES, assert_same_outputs, assert_same_results, build_case
+from parity_cases import CASES, assert_same_outputs, assert_same_results, build_case, launch_modes
 
 pytestmark = pytest.mark.gpu
 
@@ -28,17 +28,18 @@ def test_gpu_matches_oracle(oracle, name):
         cfg, chrom["start"], chrom["end"], chrom["bar_pos"], chrom["bar_dir"],
         case["stp_active"], case["stp_inactive"], tasks, nthreads=8,
         track_occupancy=bool(cfg.track_1d_lef_position))
-    sim = api.Simulator(cfg, 0)
-    try:
-        gc, gm, go, gres = sim.simulate_interval(
-            chrom["start"], chrom["end"], chrom["bar_pos"], chrom["bar_dir"], case["stp_active"],
-            case["stp_inactive"], tasks)
-    finally:
-        sim.close()
-    assert_same_results(ores, gres, name)
-    if not cfg.track_1d_lef_position:
-        go = None
-    assert_same_outputs((oc, om, oo), (gc, gm, go), name)
+    for mode in launch_modes():
+        sim = api.Simulator(cfg, 0)
+        try:
+            gc, gm, go, gres = sim.simulate_interval(
+                chrom["start"], chrom["end"], chrom["bar_pos"], chrom["bar_dir"], case["stp_active"],
+                case["stp_inactive"], tasks)
+        finally:
+            sim.close()
+        assert_same_results(ores, gres, f"{name}, helper waves {mode}")
+        if not cfg.track_1d_lef_position:
+            go = None
+        assert_same_outputs((oc, om, oo), (gc, gm, go), f"{name}, helper waves {mode}")
     assert int(oc.sum()) + om == sum(r.num_contacts for r in ores)
 
 

@@ -42,6 +42,7 @@ struct LdsImage {
     l.rng_state = rng_state.data();
     l.rng_snap = rng_snap.data();
     l.abort_flag = nullptr;
+    l.mbox = nullptr;
     l.jump_table = jump.data();
     l.zig_norm_x = ZIG_NORM_X;
     l.zig_norm_y = ZIG_NORM_Y;
