@@ -151,9 +151,10 @@ __device__ __forceinline__ WaveLds make_wave_lds(BlockLds& s, int wave_in_block)
 }
 
 __device__ __forceinline__ void load_block_tables(BlockLds& s, const DeviceTables& t, int nthreads) {
-  // (the snapshot words double as the hand-over words of the helper-wave mode: sequence numbers
-  // start from zero on both sides)
-  for (u32 i = threadIdx.x; i < static_cast<u32>(kWavesPerBlock) * 8; i += nthreads) (&s.rng_snap[0][0])[i] = 0;
+  // (the first lane-state words of a helper double as the hand-over words of the helper-wave mode:
+  // sequence numbers start from zero on both sides)
+  for (u32 i = threadIdx.x; i < static_cast<u32>(kWavesPerBlock) * PAIR_WORDS; i += nthreads)
+    reinterpret_cast<u32*>(s.rng_state[i / PAIR_WORDS])[i % PAIR_WORDS] = 0;
   const u64* jump = wave::as_global(t.jump);
   const f64* zig = wave::as_global(t.zig);
   for (u32 i = threadIdx.x; i < JUMP_TABLE_WORDS; i += nthreads) s.jump[i] = jump[i];
@@ -168,16 +169,17 @@ __global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs
   const u32 slot = blockIdx.x * kWavesPerBlock + wave_in_block;
   WaveLds lds = make_wave_lds(s, wave_in_block);
   if (a.pair_mains != 0) {
-    static_assert(PAIR_WORDS * 4 <= sizeof(s.rng_snap[0]), "hand-over words live in the helper's snapshot words");
+    static_assert(PAIR_WORDS * 4 <= sizeof(s.rng_state[0]), "hand-over words live in the helper's lane-state words");
     const int main_wave = wave_in_block < kWavesPerBlock / 2 ? wave_in_block : kWavesPerBlock - 1 - wave_in_block;
     if (static_cast<u32>(main_wave) >= a.pair_mains) return;
-    u32* mbox = reinterpret_cast<u32*>(s.rng_snap[kWavesPerBlock - 1 - main_wave]);
+    u32* mbox = reinterpret_cast<u32*>(s.rng_state[kWavesPerBlock - 1 - main_wave]);
     if (wave_in_block != main_wave) {
-      // the helper: the main wave's generator, tables and workspace, its own staging buffer
+      // the helper: the main wave's generator, tables and workspace, its own staging and sort buffers
       Cell c;
       c.p = &a.params;
       c.lds = make_wave_lds(s, main_wave);
       c.lds.stage = lds.stage;
+      c.lds.sort_lds = lds.sort_lds;
       c.ws = device_carve(a.workspace + static_cast<u64>(blockIdx.x * kWavesPerBlock + main_wave) * a.workspace_stride,
                           a.max_lefs, a.max_barriers, a.params.hist_len);
       c.g.ring = c.lds.ring;
@@ -846,7 +848,7 @@ int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen) {
   {
     static const char* names[16] = {"burnin_stats", "bind", "rank_rev", "rank_fwd", "sample", "gen_moves",
                                     "adjust_moves", "barriers+clear", "boundaries", "lef_bar", "primary",
-                                    "secondary", "fix_secondary", "extrude_release", "sub_a", "sub_b"};
+                                    "secondary", "fix_secondary", "extrude_release", "lef_activation", "cell_total"};
     u64 ticks[16];
     HIP_TRY(hipMemcpy(ticks, h->d_phase_ticks.p, sizeof(ticks), hipMemcpyDeviceToHost));
     u64 total = 0;

@@ -38,13 +38,15 @@ MODLE_DEV bool stalling_lists_wanted(const Params& p) {
 constexpr u32 HITBAR_HARD = 0x80000000u;
 
 // appends the barriers of one batch (index i per lane, `on`: active) to the two lists; uniform
-MODLE_DEV void stalling_lists_append(Cell& c, u32 i, bool in, bool on, u32 bpos, u32 bdir) {
-  const Params& p = *c.p;
+// (major_hits / minor_hits: the blocking probability of that kind is 1 -- worked out once by the
+// caller: a Params field read inside the loop comes back as a sixteen-register reload per batch)
+MODLE_DEV void stalling_lists_append(Cell& c, u32 i, bool in, bool on, u32 bpos, u32 bdir,
+                                     bool major_hits, bool minor_hits) {
   const u32 lane = wave::lane();
 #pragma unroll
   for (u32 d = 0; d < 2; ++d) {
     const bool is_major = bdir == (d == 0 ? DIR_REV : DIR_FWD);
-    const bool hit = in && on && ((is_major ? p.pblock_major : p.pblock_minor) == 1.0);
+    const bool hit = in && on && (is_major ? major_hits : minor_hits);
     const u64 hm = wave::ballot(hit);
     if (hit) {
       const u32 slot = c.n_hit[d] + static_cast<u32>(wave::popc64(hm & lanemask_lt(lane)));
@@ -63,11 +65,12 @@ MODLE_DEV_NOINLINE void compact_stalling_barriers(Cell& c) {
   const u32 lane = wave::lane();
   c.n_hit[0] = 0;
   c.n_hit[1] = 0;
+  const bool major_hits = wave::uniform(c.p->pblock_major == 1.0), minor_hits = wave::uniform(c.p->pblock_minor == 1.0);
   for (u32 base = 0; base < nb; base += 64) {
     const u32 i = base + lane;
     const bool in = i < nb;
     stalling_lists_append(c, i, in, in && c.ws.bar_active[i] != 0, in ? iv.bar_pos[i] : 0,
-                          in ? iv.bar_dir[i] : 0);
+                          in ? iv.bar_dir[i] : 0, major_hits, minor_hits);
   }
   wave::sync_mem();
 }
@@ -77,6 +80,7 @@ MODLE_DEV_NOINLINE void barriers_next_state(Cell& c) {
   const u32 nb = wave::uniform(iv.n_barriers);
   const u32 lane = wave::lane();
   const bool lists = stalling_lists_wanted(*c.p);
+  const bool major_hits = wave::uniform(c.p->pblock_major == 1.0), minor_hits = wave::uniform(c.p->pblock_minor == 1.0);
   c.n_hit[0] = 0;
   c.n_hit[1] = 0;
   constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
@@ -124,7 +128,7 @@ MODLE_DEV_NOINLINE void barriers_next_state(Cell& c) {
         }
       }
       rng_advance(c.g, cnt);
-      if (lists) stalling_lists_append(c, i, i < nb, st != 0, g.P[u], g.D[u]);
+      if (lists) stalling_lists_append(c, i, i < nb, st != 0, g.P[u], g.D[u], major_hits, minor_hits);
     }
   }
   wave::sync_mem();

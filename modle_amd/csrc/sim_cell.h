@@ -56,6 +56,7 @@ struct Cell {
   bool filter_on;
   // helper-wave mode (sim_pair.h): sequence number of the last request posted to the helper
   u32 pair_seq;
+  u32 pair_interval;  // index of the task's interval (goes with every request)
 #ifdef MODLE_PHASE_TIMERS
   u64 ph[16];     // profiling build: time spent per phase (wave::clock ticks)
 #endif

@@ -1433,9 +1433,6 @@ MODLE_DEV_NOINLINE u32 secondary_resolve(Cell& c, u32 n_cand, u32* list, u32 lis
       }
       u64 hits = 0, avoids = 0;  // lanes that collide / whose collision is avoided
       u32 drawn = 0;             // outputs consumed
-#ifdef MODLE_PHASE_TIMERS
-      const u64 t_walk = wave::clock();
-#endif
       // Every lane takes the output its position among the drawing lanes gives it.  That is final
       // up to the first "avoid" that ends a chain with lanes still to draw behind it (those lanes
       // drop out, and every later lane moves to an earlier output): one round per such avoid, and
@@ -1460,9 +1457,6 @@ MODLE_DEV_NOINLINE u32 secondary_resolve(Cell& c, u32 n_cand, u32* list, u32 lis
         drawn += static_cast<u32>(wave::popc64(rem & upto));
         rem = e >= 63 ? u64(0) : rem & ~lanemask_lt(e + 1);
       }
-#ifdef MODLE_PHASE_TIMERS
-      c.ph[15] += wave::clock() - t_walk;
-#endif
       if (trials && drawn != 0) rng_advance(c.g, drawn);
       if ((avoids >> lane) & 1u) {
         C = cw_make(bId, EV_LEF_LEF_SECONDARY);
@@ -1558,17 +1552,11 @@ MODLE_DEV_NOINLINE void process_secondary_both(Cell& c, BoundaryCounts bc, u32* 
   SecondaryFilter<true> ff;
   fr.init(c, bc, list_cap, true, true);
   ff.init(c, bc, list_cap, true, true);
-#ifdef MODLE_PHASE_TIMERS
-  const u64 t_pass1 = wave::clock();
-#endif
   for (u32 t = 0; t < fr.nblk; ++t) {
     fr.step(t);
     ff.step(t);
   }
   wave::sync_mem();
-#ifdef MODLE_PHASE_TIMERS
-  c.ph[14] += wave::clock() - t_pass1;  // (sub_a: the filter pass; the rest of the phase is pass 2)
-#endif
   n_rev = secondary_resolve<false>(c, fr.n_cand, list_rev, list_cap, overflow);
   n_fwd = secondary_resolve<true>(c, ff.n_cand, list_fwd, list_cap, overflow);
 }
@@ -1778,7 +1766,14 @@ MODLE_DEV_NOINLINE void lookup_partner_ranks(Cell& c, bool want_r, bool want_f) 
 MODLE_DEV bool phase_process_collisions(Cell& c) {
   BoundaryCounts bc;
   PHASE(c, 8, bc = detect_boundaries(c));
-  PHASE(c, 9, detect_lef_bar<false>(c, bc); detect_lef_bar<true>(c, bc));
+  // helper-wave mode (sim_pair.h): without Bernoulli trials the two instances draw nothing and touch
+  // disjoint arrays; the helper takes the fwd one
+  const bool split = c.lds.mbox != nullptr && stalling_lists_wanted(*c.p) && wave::uniform(c.iv->n_barriers) != 0;
+  if (split) {
+    PHASE(c, 9, pair_request_lef_bar(c, bc.n5, bc.n3); detect_lef_bar<false>(c, bc); pair_wait(c, PAIR_ALL));
+  } else {
+    PHASE(c, 9, detect_lef_bar<false>(c, bc); detect_lef_bar<true>(c, bc));
+  }
   PHASE(c, 10, detect_primary(c, bc, true));
   bool overflow = false;
   // avoided secondary collisions are listed in device scratch: one entry per unit at most

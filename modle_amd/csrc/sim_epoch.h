@@ -209,8 +209,12 @@ MODLE_DEV void log_internal_state(Cell&, u64, bool) {}
 MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& task,
                             const Workspace& ws, const WaveLds& lds, CellResult& res) {
   Cell c;
+#ifdef MODLE_PHASE_TIMERS
+  const u64 t_cell = wave::clock();
+#endif
   const Interval ivg = interval_in_device_memory(iv);
   init_cell(c, p, ivg, ws, lds, task.num_lefs, task.prng);
+  c.pair_interval = task.interval;
   reset_cell_buffers(c);
 
   u64 epoch = 0, num_burnin_epochs = 0, num_contacts = 0;
@@ -245,9 +249,9 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
       do {
         ++num_burnin_epochs;
         if (c.n_active != c.n_lefs) {
-          const u64 k = poisson_exact(c.g, lef_binding_rate_burnin);
-          const u64 na = static_cast<u64>(c.n_active) + k;
-          activate_lefs(c, c.n_active, na < c.n_lefs ? static_cast<u32>(na) : c.n_lefs);
+          PHASE(c, 14, const u64 k = poisson_exact(c.g, lef_binding_rate_burnin);
+                const u64 na = static_cast<u64>(c.n_active) + k;
+                activate_lefs(c, c.n_active, na < c.n_lefs ? static_cast<u32>(na) : c.n_lefs));
         } else {
           PHASE(c, 0, compute_loop_size_stats(c); burnin_completed = evaluate_burnin(c));
           burnin_completed = burnin_completed && epoch > p.min_burnin_epochs;
@@ -311,6 +315,7 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
 
   trace_stage(c, epoch, 6);
 #ifdef MODLE_PHASE_TIMERS
+  c.ph[15] = wave::clock() - t_cell;  // (the whole cell: what the phases do not add up to is the glue between them)
   if (lds.phase_ticks != nullptr && wave::lane() == 0) {
     for (int i = 0; i < 16; ++i) wave::atomic_add_u64(lds.phase_ticks + i, c.ph[i]);
   }

@@ -166,7 +166,8 @@ MODLE_DEV_NOINLINE void generate_moves_dir(Cell& c, f64 speed, f64 std) {
 // box against the scattering form: 23 % fewer bytes written to the fabric and a kernel 0.7 %
 // faster -- the adjustment pass itself takes twice as long (dependent gathers), every other pass
 // gains from the lighter write traffic.
-MODLE_DEV_NOINLINE void generate_moves_by_id(Cell& c, f64 speed, f64 std, u32* mv_by_id) {
+MODLE_DEV_NOINLINE void generate_moves_by_id(Cell& c, f64 speed_in, f64 std_in, u32* mv_by_id) {
+  const f64 speed = wave::own_regs(speed_in), std = wave::own_regs(std_in);
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
   if (std == 0.0) {

@@ -11,14 +11,23 @@
 // (ring, lane states, snapshots: LDS of the main wave; position and end of the ring: handed over)
 // belongs to exactly one of the two waves at any time.
 //
-//   main:    bind | request | rank rev, rank fwd | wait moves | adjust moves | wait all | collisions ...
+//   main:    bind | request | rank rev, rank fwd | wait moves | adjust moves | wait all | ...
 //   helper:        | moves rev, moves fwd | signal moves | barrier states + stalling lists | signal all
+//
+// Second kind of request, in every epoch: LEF-BAR detection without Bernoulli trials draws nothing
+// and its rev and fwd instances touch disjoint arrays (simulation_detect_collisions.cpp:122-247):
+// the helper runs the fwd instance while the main wave runs the rev instance.
+//
+//   main:    ... boundaries | request | LEF-BAR rev | wait all | primary LEF-LEF ...
+//   helper:                 | LEF-BAR fwd | signal all
+//
+// This file holds the main wave's side; the helper's loop is in sim_helper.h.
 //
 #pragma once
 
 namespace modle_dev {
 
-// Hand-over words (u32, in LDS; the helper's own snapshot words, which it does not use):
+// Hand-over words (u32, in LDS; the helper's own lane-state words, which it does not use):
 constexpr u32 PAIR_REQ = 0;        // main -> helper: sequence number of the request
 constexpr u32 PAIR_MOVES = 1;      // helper -> main: the moves of request <seq> are in device memory
 constexpr u32 PAIR_ALL = 2;        // helper -> main: barrier states, lists and generator are back
@@ -27,9 +36,14 @@ constexpr u32 PAIR_BURNIN_DONE = 4;
 constexpr u32 PAIR_INTERVAL = 5;   // request: index of the task's interval
 constexpr u32 PAIR_POS = 6;        // generator: stream position (2 words), there and back
 constexpr u32 PAIR_GEN_END = 8;    // generator: end of the ring (2 words), there and back
-constexpr u32 PAIR_N_HIT = 10;     // reply: entries of the two lists of stalling barriers
-constexpr u32 PAIR_WORDS = 12;
+constexpr u32 PAIR_N_HIT = 10;     // reply: entries of the two lists of stalling barriers (2 words)
+constexpr u32 PAIR_KIND = 12;      // request: PAIR_KIND_MOVES / PAIR_KIND_LEF_BAR
+constexpr u32 PAIR_BC = 13;        // LEF-BAR request: BoundaryCounts (2 words)
+constexpr u32 PAIR_F_POS = 16;     // LEF-BAR request: the fwd position / move arrays (the rank updates
+constexpr u32 PAIR_F_MOVE = 18;    // and the move adjustment swap workspace pointers) (2 words each)
+constexpr u32 PAIR_WORDS = 20;
 constexpr u32 PAIR_EXIT = 0xFFFFFFFFu;
+constexpr u32 PAIR_KIND_MOVES = 0, PAIR_KIND_LEF_BAR = 1;
 
 MODLE_DEV void pair_put_u64(u32* m, u32 at, u64 v) {
   m[at] = static_cast<u32>(v);
@@ -42,13 +56,32 @@ MODLE_DEV u64 pair_get_u64(const u32* m, u32 at) {
 // main wave: hands the generator to the helper together with what the two phases need
 MODLE_DEV void pair_request(Cell& c, bool burnin_completed, u32 interval) {
   u32* m = c.lds.mbox;
+  c.pair_interval = interval;
   wave::lockstep();
   if (wave::lane() == 0) {
     m[PAIR_N_ACTIVE] = c.n_active;
     m[PAIR_BURNIN_DONE] = burnin_completed ? 1u : 0u;
     m[PAIR_INTERVAL] = interval;
+    m[PAIR_KIND] = PAIR_KIND_MOVES;
     pair_put_u64(m, PAIR_POS, c.g.pos);
     pair_put_u64(m, PAIR_GEN_END, c.g.gen_end);
+  }
+  ++c.pair_seq;
+  wave::st_release_wg(&m[PAIR_REQ], c.pair_seq);
+}
+// main wave: the fwd instance of LEF-BAR detection goes to the helper (n5, n3: BoundaryCounts)
+MODLE_DEV void pair_request_lef_bar(Cell& c, u32 n5, u32 n3) {
+  u32* m = c.lds.mbox;
+  wave::lockstep();
+  if (wave::lane() == 0) {
+    m[PAIR_N_ACTIVE] = c.n_active;
+    m[PAIR_INTERVAL] = c.pair_interval;
+    m[PAIR_KIND] = PAIR_KIND_LEF_BAR;
+    m[PAIR_BC] = n5;
+    m[PAIR_BC + 1] = n3;
+    m[PAIR_N_HIT + 1] = c.n_hit[1];
+    pair_put_u64(m, PAIR_F_POS, reinterpret_cast<u64>(c.ws.f_pos));
+    pair_put_u64(m, PAIR_F_MOVE, reinterpret_cast<u64>(c.ws.f_move));
   }
   ++c.pair_seq;
   wave::st_release_wg(&m[PAIR_REQ], c.pair_seq);
@@ -73,40 +106,6 @@ MODLE_DEV void pair_dismiss(u32* m) {
   wave::lockstep();
   if (wave::lane() == 0) m[PAIR_N_ACTIVE] = PAIR_EXIT;
   wave::st_release_wg(&m[PAIR_REQ], seq);
-}
-
-// The helper's loop.  `c` is a cell context that shares the main wave's generator, tables and
-// workspace (moves, barrier states, lists) and has the helper's own staging buffer; `intervals`
-// is the launch's interval table.
-MODLE_DEV void pair_serve(Cell& c, const Interval* intervals, u32* m) {
-  u32 seen = wave::uniform(m[PAIR_REQ]);
-  for (;;) {
-    u32 seq;
-    while ((seq = wave::uniform(wave::ld_acquire_wg(&m[PAIR_REQ]))) == seen) wave::nap();
-    seen = seq;
-    const u32 n_active = wave::uniform(m[PAIR_N_ACTIVE]);
-    if (n_active == PAIR_EXIT) break;
-    const bool burnin_completed = wave::uniform(m[PAIR_BURNIN_DONE]) != 0;
-    const Interval ivg = interval_in_device_memory(intervals[wave::uniform(m[PAIR_INTERVAL])]);
-    c.iv = &ivg;
-    c.n_active = n_active;
-    c.g.pos = pair_get_u64(m, PAIR_POS);
-    c.g.gen_end = pair_get_u64(m, PAIR_GEN_END);
-    const Params& p = *c.p;
-    generate_moves_by_id(c, burnin_completed ? p.rev_speed : p.rev_speed_burnin, p.rev_std, c.ws.tmp[8]);
-    generate_moves_by_id(c, burnin_completed ? p.fwd_speed : p.fwd_speed_burnin, p.fwd_std, c.ws.tmp[9]);
-    wave::sync_mem();
-    wave::st_release_wg(&m[PAIR_MOVES], seq);
-    barriers_next_state(c);
-    wave::lockstep();
-    if (wave::lane() == 0) {
-      pair_put_u64(m, PAIR_POS, c.g.pos);
-      pair_put_u64(m, PAIR_GEN_END, c.g.gen_end);
-      m[PAIR_N_HIT] = c.n_hit[0];
-      m[PAIR_N_HIT + 1] = c.n_hit[1];
-    }
-    wave::st_release_wg(&m[PAIR_ALL], seq);
-  }
 }
 
 }  // namespace modle_dev

@@ -157,6 +157,15 @@ MODLE_DEV void lockstep() { __builtin_amdgcn_wave_barrier(); }
 // the value has to exist in a register at this point of the program: keeps the optimizer from
 // sinking the computation that produces it (sched_fence only binds the instruction scheduler)
 MODLE_DEV void pin(uint32_t& v) { asm volatile("" : "+v"(v)); }
+// A wave-uniform value in scalar registers OF ITS OWN.  Fields of a struct that reaches the kernel
+// as an argument are loaded sixteen registers at a time, and a field used inside a loop keeps the
+// whole group alive: when the group is spilled, every iteration reloads all sixteen registers
+// (v_readlane each) for the two it needs.
+MODLE_DEV double own_regs(double v) {
+  v = uniform(v);
+  asm volatile("" : "+s"(v));
+  return v;
+}
 // a ^ b ^ c in one instruction (v_bitop3_b32)
 MODLE_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
   return static_cast<uint32_t>(__builtin_amdgcn_bitop3_b32(a, b, c, 0x96));

@@ -247,6 +247,7 @@ MODLE_DEV uint32_t load_system_u32(const uint32_t* p) { return __atomic_load_n(p
 MODLE_DEV void st_release_wg(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 MODLE_DEV uint32_t ld_acquire_wg(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 MODLE_DEV void nap() {}
+MODLE_DEV double own_regs(double v) { return v; }
 MODLE_DEV void atomic_inc_u32(uint32_t* p) { __atomic_fetch_add(p, 1u, __ATOMIC_RELAXED); }
 MODLE_DEV void atomic_add_u64(uint64_t* p, uint64_t v) {
   __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
