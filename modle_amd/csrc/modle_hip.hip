@@ -170,8 +170,23 @@ __global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs
   WaveLds lds = make_wave_lds(s, wave_in_block);
   if (a.pair_mains != 0) {
     static_assert(PAIR_WORDS * 4 <= sizeof(s.rng_state[0]), "hand-over words live in the helper's lane-state words");
+    // with one or two main waves per workgroup there are waves to spare: wave 2 + m produces the
+    // PRNG blocks for the helper of main wave m while that helper draws the moves (pair_feed)
+    u32* feed = nullptr;
+#ifndef MODLE_RNG_PHILOX
+    if (a.pair_mains <= 2 && wave_in_block >= 2 && wave_in_block < 4) {
+      const int m = wave_in_block - 2;
+      if (static_cast<u32>(m) >= a.pair_mains) return;
+      const WaveLds lm = make_wave_lds(s, m);
+      pair_feed(lm.ring, lm.jump_table, lm.rng_state, lm.rng_snap, reinterpret_cast<u32*>(s.rng_state[wave_in_block]));
+      return;
+    }
+#endif
     const int main_wave = wave_in_block < kWavesPerBlock / 2 ? wave_in_block : kWavesPerBlock - 1 - wave_in_block;
     if (static_cast<u32>(main_wave) >= a.pair_mains) return;
+#ifndef MODLE_RNG_PHILOX
+    if (a.pair_mains <= 2) feed = reinterpret_cast<u32*>(s.rng_state[2 + main_wave]);
+#endif
     u32* mbox = reinterpret_cast<u32*>(s.rng_state[kWavesPerBlock - 1 - main_wave]);
     if (wave_in_block != main_wave) {
       // the helper: the main wave's generator, tables and workspace, its own staging and sort buffers
@@ -188,7 +203,8 @@ __global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs
       c.g.snap = c.lds.rng_snap;
       c.n_hit[0] = 0;
       c.n_hit[1] = 0;
-      pair_serve(c, wave::as_global(a.intervals), mbox);
+      c.g.feed = nullptr;
+      pair_serve(c, wave::as_global(a.intervals), mbox, feed);
       return;
     }
     lds.mbox = mbox;

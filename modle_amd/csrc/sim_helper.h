@@ -7,14 +7,24 @@ namespace modle_dev {
 // The helper's loop.  `c` is a cell context that shares the main wave's generator, tables and
 // workspace (moves, barrier states, lists, unit arrays) and has the helper's own staging and sort
 // buffers; `intervals` is the launch's interval table.
-MODLE_DEV void pair_serve(Cell& c, const Interval* intervals, u32* m) {
+// `feed`: hand-over words of the wave that produces the PRNG blocks while the helper draws the moves
+// (pair_feed below), or nullptr when the workgroup has no wave to spare for it.
+MODLE_DEV void pair_serve(Cell& c, const Interval* intervals, u32* m, u32* feed) {
   u32 seen = wave::uniform(m[PAIR_REQ]);
+  u32 fseq = 0;
   for (;;) {
     u32 seq;
     while ((seq = wave::uniform(wave::ld_acquire_wg(&m[PAIR_REQ]))) == seen) wave::nap();
     seen = seq;
     const u32 n_active = wave::uniform(m[PAIR_N_ACTIVE]);
-    if (n_active == PAIR_EXIT) break;
+    if (n_active == PAIR_EXIT) {
+      if (feed != nullptr) {
+        wave::lockstep();
+        if (wave::lane() == 0) feed[FEED_EXIT] = 1;
+        wave::st_release_wg(&feed[FEED_START], fseq + 1);
+      }
+      break;
+    }
     const Interval ivg = interval_in_device_memory(intervals[wave::uniform(m[PAIR_INTERVAL])]);
     c.iv = &ivg;
     c.n_active = n_active;
@@ -33,8 +43,27 @@ MODLE_DEV void pair_serve(Cell& c, const Interval* intervals, u32* m) {
     c.g.pos = pair_get_u64(m, PAIR_POS);
     c.g.gen_end = pair_get_u64(m, PAIR_GEN_END);
     const Params& p = *c.p;
+    if (feed != nullptr) {
+      // the blocks of the stream come from the producer wave while the moves are drawn
+      wave::lockstep();
+      if (wave::lane() == 0) {
+        feed[FEED_POS] = static_cast<u32>(c.g.pos);
+        feed[FEED_GEN_END] = static_cast<u32>(c.g.gen_end);
+      }
+      ++fseq;
+      wave::st_release_wg(&feed[FEED_START], fseq);
+      c.g.feed = feed;
+    }
     generate_moves_by_id(c, burnin_completed ? p.rev_speed : p.rev_speed_burnin, p.rev_std, c.ws.tmp[8]);
     generate_moves_by_id(c, burnin_completed ? p.fwd_speed : p.fwd_speed_burnin, p.fwd_std, c.ws.tmp[9]);
+    if (feed != nullptr) {
+      // the producer stops (it may be a block ahead: the ring then ends where it says)
+      wave::st_release_wg(&feed[FEED_STOP], fseq);
+      while (wave::uniform(wave::ld_acquire_wg(&feed[FEED_ACK])) != fseq) wave::nap();
+      const u32 ahead = wave::uniform(feed[FEED_GEN_END]) - static_cast<u32>(c.g.gen_end);
+      c.g.gen_end = wave::known_uniform(c.g.gen_end + ahead);
+      c.g.feed = nullptr;
+    }
     wave::sync_mem();
     wave::st_release_wg(&m[PAIR_MOVES], seq);
     barriers_next_state(c);
@@ -48,5 +77,35 @@ MODLE_DEV void pair_serve(Cell& c, const Interval* intervals, u32* m) {
     wave::st_release_wg(&m[PAIR_ALL], seq);
   }
 }
+
+#ifndef MODLE_RNG_PHILOX
+// The producer's loop: blocks of the main wave's stream (ring, jump table, lane states, snapshots:
+// LDS of the main wave) for the helper that draws the moves, one block ahead of it at most.
+MODLE_DEV void pair_feed(u64* ring, const u64* jump, u64* state, u64* snap, u32* f) {
+  u32 seen = 0;
+  for (;;) {
+    u32 seq;
+    while ((seq = wave::uniform(wave::ld_acquire_wg(&f[FEED_START]))) == seen) wave::nap();
+    seen = seq;
+    if (wave::uniform(f[FEED_EXIT]) != 0) break;
+    u32 gen_end = wave::uniform(f[FEED_GEN_END]);
+    for (;;) {
+      if (wave::uniform(wave::ld_acquire_wg(&f[FEED_STOP])) == seq) break;
+      const u32 pos = wave::uniform(wave::ld_acquire_wg(&f[FEED_POS]));
+      if (static_cast<i32>(gen_end - pos) <= static_cast<i32>(RNG_BLOCK - FEED_MARGIN)) {
+        wave::lockstep();
+        rng_gen_block_call((MODLE_LDS u64*)ring, (const MODLE_LDS u64*)jump, (MODLE_LDS u64*)state,
+                           (MODLE_LDS u64*)snap, ((gen_end / RNG_BLOCK) & 1u) * RNG_BLOCK);
+        gen_end += RNG_BLOCK;
+        wave::sync_lds();
+        wave::st_release_wg(&f[FEED_GEN_END], gen_end);
+      } else {
+        wave::nap();
+      }
+    }
+    wave::st_release_wg(&f[FEED_ACK], seq);
+  }
+}
+#endif
 
 }  // namespace modle_dev

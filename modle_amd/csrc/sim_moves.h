@@ -30,6 +30,8 @@ MODLE_DEV u32 draw_moves_step(Cell& c, f64 speed, f64 std, u32 tail) {
   Rng& g = c.g;
   u32* q_move = c.lds.stage;
   u32* q_end = c.lds.stage + MOVQ_CAP;
+  // (fed stream: the producer learns how far this consumer has come)
+  if (g.feed != nullptr) wave::st_release_wg(&g.feed[FEED_POS], static_cast<u32>(g.pos));
   rng_ensure(g, 65);
   u32 bucket;
   const f64 u = int_float_pair8(rng_peek(g, g.pos + lane), bucket);

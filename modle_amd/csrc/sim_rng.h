@@ -135,7 +135,20 @@ struct Rng {
                        // of the block with parity b at snap[4 * b + w] (LDS)
   u64 gen_end;         // uniform: raws [gen_end - RNG_RING, gen_end) are in the ring
   u64 pos;             // uniform: stream position of the next raw to be consumed
+  u32* feed;           // helper-wave mode: hand-over words of the wave that produces the blocks for
+                       // this consumer (rng_take_fed_block), or nullptr: the consumer produces them
 };
+// Hand-over words between a consumer of the stream and the wave that produces its blocks (u32, LDS;
+// helper-wave mode, sim_helper.h).  The producer replaces the older block of the ring once the
+// consumer's published position is FEED_MARGIN outputs into the newer one (a consumer hands back
+// up to 66 outputs at the end of a direction of generate_moves: they must still be in the ring).
+constexpr u32 FEED_START = 0;    // consumer -> producer: sequence number of the session
+constexpr u32 FEED_STOP = 1;     // consumer -> producer: the session ends
+constexpr u32 FEED_ACK = 2;      // producer -> consumer: it has (no block in the making)
+constexpr u32 FEED_POS = 3;      // consumer -> producer: low word of its position
+constexpr u32 FEED_GEN_END = 4;  // low word of the end of the ring (consumer at the start, then the producer)
+constexpr u32 FEED_EXIT = 5;     // consumer -> producer, with a new session number: leave
+constexpr u32 FEED_MARGIN = 128;
 
 MODLE_DEV u64 rotl64(u64 x, int k) { return (x << k) | (x >> (64 - k)); }
 
@@ -241,7 +254,25 @@ MODLE_DEV void philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1, u32
 }
 
 #ifndef MODLE_RNG_PHILOX
+// consumer side of a fed stream: publishes the position and waits for the producer's next block
+MODLE_DEV void rng_take_fed_block(Rng& g) {
+  u32* f = g.feed;
+  wave::st_release_wg(&f[FEED_POS], static_cast<u32>(g.pos));
+  for (;;) {
+    const u32 fed = wave::uniform(wave::ld_acquire_wg(&f[FEED_GEN_END]));
+    const u32 ahead = fed - static_cast<u32>(g.gen_end);  // (the producer is less than 2^31 outputs ahead)
+    if (ahead != 0) {
+      g.gen_end = wave::known_uniform(g.gen_end + ahead);
+      return;
+    }
+    wave::nap();
+  }
+}
 MODLE_DEV void rng_gen_block(Rng& g) {
+  if (g.feed != nullptr) {
+    rng_take_fed_block(g);
+    return;
+  }
   wave::lockstep();  // other lanes may still be reading the block that is about to be replaced
   rng_gen_block_call((MODLE_LDS u64*)g.ring, (const MODLE_LDS u64*)g.jump, (MODLE_LDS u64*)g.state,
                      (MODLE_LDS u64*)g.snap, ((static_cast<u32>(g.gen_end) / RNG_BLOCK) & 1u) * RNG_BLOCK);
@@ -263,6 +294,7 @@ MODLE_DEV void rng_init(Rng& g, const u64 state[4]) {
   g.state[3 * 64 + lane] = s3;
   g.gen_end = 0;
   g.pos = 0;
+  g.feed = nullptr;
   wave::sync_lds();
 }
 #else
@@ -319,6 +351,7 @@ MODLE_DEV void rng_init(Rng& g, const u64 state[4]) {
   }
   g.gen_end = 0;
   g.pos = 0;
+  g.feed = nullptr;
   wave::sync_lds();
 }
 #endif

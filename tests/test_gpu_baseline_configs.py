@@ -100,17 +100,26 @@ def test_whole_genome_sample_matches_oracle(oracle, name, k):
     for e in plan:
         n = len(e["tasks"])
         e["tasks"] = api.slice_tasks(e["tasks"], n - k, n)
-    sim, ids, tensors, missed = _launch(cfg, plan)
-    try:
-        for entry, iid, t, m in zip(plan, ids, tensors, missed):
-            iv = entry["interval"]
-            stp_a, stp_i = api.barrier_stps(cfg, iv["bar_occupancy"])
-            oc, om, oo, ores = oracle.simulate_interval(cfg, iv["start"], iv["end"], iv["bar_pos"],
-                                                        iv["bar_dir"], stp_a, stp_i, entry["tasks"],
-                                                        nthreads=k)
-            gc = t[0].cpu().numpy().view(np.uint32)
-            go = t[1].cpu().numpy().view(np.uint64)
-            assert_same_results(ores, sim.results(iid), f"{name}/{iv['name']}")
-            assert_same_outputs((oc, om, oo), (gc, m, go), f"{name}/{iv['name']}")
-    finally:
-        sim.close()
+    # the oracle once, the launch in both modes (one wave per cell / main wave + helper: a launch
+    # this small would otherwise always take the second)
+    from parity_cases import launch_modes
+
+    expected = []
+    for entry in plan:
+        iv = entry["interval"]
+        stp_a, stp_i = api.barrier_stps(cfg, iv["bar_occupancy"])
+        expected.append(oracle.simulate_interval(cfg, iv["start"], iv["end"], iv["bar_pos"],
+                                                 iv["bar_dir"], stp_a, stp_i, entry["tasks"],
+                                                 nthreads=k))
+    for mode in launch_modes():
+        sim, ids, tensors, missed = _launch(cfg, plan)
+        try:
+            for entry, iid, t, m, (oc, om, oo, ores) in zip(plan, ids, tensors, missed, expected):
+                iv = entry["interval"]
+                gc = t[0].cpu().numpy().view(np.uint32)
+                go = t[1].cpu().numpy().view(np.uint64)
+                what = f"{name}/{iv['name']}, helper waves {mode}"
+                assert_same_results(ores, sim.results(iid), what)
+                assert_same_outputs((oc, om, oo), (gc, m, go), what)
+        finally:
+            sim.close()
