@@ -175,7 +175,12 @@ int modle_hip_add_interval(modle_hip_handle* h, uint64_t start, uint64_t end,
 int modle_hip_submit_tasks(modle_hip_handle* h, int interval_id, const modle_hip_task* tasks,
                            size_t n_tasks, char* err, size_t errlen);
 /* Launches every pending task on `stream` (a hipStream_t, NULL = default stream) and returns
- * without waiting. */
+ * without waiting.  One wavefront simulates one cell -- the reference's one cell per worker thread,
+ * scheduler_simulate.cpp:190-271 -- except when the launch leaves at least half of the GPU's wave
+ * slots empty (at most 4 tasks per compute unit): a cell then gets a helper wave, and a third wave
+ * for its PRNG blocks when there are at most 2 tasks per compute unit.  The
+ * results do not depend on the mode; the environment variable MODLE_HIP_PAIRED=0 / 1, read at every
+ * launch, forces it off / on (tests, A/B measurements). */
 int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen);
 /* Waits for the launch and collects per-task results (the counterpart of _ctx.shutdown(),
  * scheduler_simulate.cpp:162). */

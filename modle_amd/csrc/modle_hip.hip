@@ -76,6 +76,9 @@ struct SimArgs {
   // main wave m (waves are dealt to the four SIMDs in turn: with one or two main waves per
   // workgroup every wave of a pair has a SIMD of its own); 0 = off
   u32 pair_mains;
+  // launches that fill the slots: a wave that finds the queue empty becomes the helper of a main
+  // wave of its workgroup that is still running (sim_pair.h: PAIR_STATE); 0 = off
+  u32 tail_helpers;
 };
 
 __device__ __forceinline__ Workspace device_carve(char* base, u32 max_lefs, u32 max_barriers, u32 hist_len) {
@@ -126,6 +129,7 @@ struct BlockLds {
   u64 rng_snap[kWavesPerBlock][8];
   u64 sort_keys[kWavesPerBlock][SORT_LDS_CAP];
   u32 stage[kWavesPerBlock][STAGE_CAP];
+  u32 pairbox[kWavesPerBlock][PAIR_WORDS];  // helper-wave mode: hand-over words of main wave w (sim_pair.h)
 };
 
 __device__ __forceinline__ WaveLds make_wave_lds(BlockLds& s, int wave_in_block) {
@@ -135,6 +139,7 @@ __device__ __forceinline__ WaveLds make_wave_lds(BlockLds& s, int wave_in_block)
   l.rng_snap = s.rng_snap[wave_in_block];
   l.abort_flag = nullptr;
   l.mbox = nullptr;
+  l.pair_dynamic = false;
   l.jump_table = s.jump;
   l.zig_norm_x = s.zig;
   l.zig_norm_y = s.zig + 129;
@@ -151,10 +156,12 @@ __device__ __forceinline__ WaveLds make_wave_lds(BlockLds& s, int wave_in_block)
 }
 
 __device__ __forceinline__ void load_block_tables(BlockLds& s, const DeviceTables& t, int nthreads) {
-  // (the first lane-state words of a helper double as the hand-over words of the helper-wave mode:
-  // sequence numbers start from zero on both sides)
-  for (u32 i = threadIdx.x; i < static_cast<u32>(kWavesPerBlock) * PAIR_WORDS; i += nthreads)
+  // (hand-over words of the helper-wave mode -- the first lane-state words of a producer wave double
+  // as its own: sequence numbers start from zero on both sides, no main wave is running yet)
+  for (u32 i = threadIdx.x; i < static_cast<u32>(kWavesPerBlock) * PAIR_WORDS; i += nthreads) {
+    s.pairbox[i / PAIR_WORDS][i % PAIR_WORDS] = 0;
     reinterpret_cast<u32*>(s.rng_state[i / PAIR_WORDS])[i % PAIR_WORDS] = 0;
+  }
   const u64* jump = wave::as_global(t.jump);
   const f64* zig = wave::as_global(t.zig);
   for (u32 i = threadIdx.x; i < JUMP_TABLE_WORDS; i += nthreads) s.jump[i] = jump[i];
@@ -162,56 +169,14 @@ __device__ __forceinline__ void load_block_tables(BlockLds& s, const DeviceTable
   __syncthreads();
 }
 
-__global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs a) {
-  __shared__ BlockLds s;
-  load_block_tables(s, a.tables, kThreadsPerBlock);
-  const int wave_in_block = wave::uniform(static_cast<int>(threadIdx.x / 64));
-  const u32 slot = blockIdx.x * kWavesPerBlock + wave_in_block;
-  WaveLds lds = make_wave_lds(s, wave_in_block);
-  if (a.pair_mains != 0) {
-    static_assert(PAIR_WORDS * 4 <= sizeof(s.rng_state[0]), "hand-over words live in the helper's lane-state words");
-    // with one or two main waves per workgroup there are waves to spare: wave 2 + m produces the
-    // PRNG blocks for the helper of main wave m while that helper draws the moves (pair_feed)
-    u32* feed = nullptr;
-#ifndef MODLE_RNG_PHILOX
-    if (a.pair_mains <= 2 && wave_in_block >= 2 && wave_in_block < 4) {
-      const int m = wave_in_block - 2;
-      if (static_cast<u32>(m) >= a.pair_mains) return;
-      const WaveLds lm = make_wave_lds(s, m);
-      pair_feed(lm.ring, lm.jump_table, lm.rng_state, lm.rng_snap, reinterpret_cast<u32*>(s.rng_state[wave_in_block]));
-      return;
-    }
-#endif
-    const int main_wave = wave_in_block < kWavesPerBlock / 2 ? wave_in_block : kWavesPerBlock - 1 - wave_in_block;
-    if (static_cast<u32>(main_wave) >= a.pair_mains) return;
-#ifndef MODLE_RNG_PHILOX
-    if (a.pair_mains <= 2) feed = reinterpret_cast<u32*>(s.rng_state[2 + main_wave]);
-#endif
-    u32* mbox = reinterpret_cast<u32*>(s.rng_state[kWavesPerBlock - 1 - main_wave]);
-    if (wave_in_block != main_wave) {
-      // the helper: the main wave's generator, tables and workspace, its own staging and sort buffers
-      Cell c;
-      c.p = &a.params;
-      c.lds = make_wave_lds(s, main_wave);
-      c.lds.stage = lds.stage;
-      c.lds.sort_lds = lds.sort_lds;
-      c.ws = device_carve(a.workspace + static_cast<u64>(blockIdx.x * kWavesPerBlock + main_wave) * a.workspace_stride,
-                          a.max_lefs, a.max_barriers, a.params.hist_len);
-      c.g.ring = c.lds.ring;
-      c.g.jump = c.lds.jump_table;
-      c.g.state = c.lds.rng_state;
-      c.g.snap = c.lds.rng_snap;
-      c.n_hit[0] = 0;
-      c.n_hit[1] = 0;
-      c.g.feed = nullptr;
-      pair_serve(c, wave::as_global(a.intervals), mbox, feed);
-      return;
-    }
-    lds.mbox = mbox;
-  }
+// The task loop of a main wave.
+__device__ __forceinline__ void simulate_tasks(const SimArgs& a, const WaveLds& lds, u32 slot, int wave_in_block) {
   const Workspace ws = device_carve(a.workspace + static_cast<u64>(slot) * a.workspace_stride,
                                     a.max_lefs, a.max_barriers, a.params.hist_len);
-  if (static_cast<u32>(wave_in_block) >= a.active_waves) return;
+  if (lds.pair_dynamic) {
+    // this main wave is running: an idle wave of the workgroup may become its helper
+    wave::st_release_wg(&lds.mbox[PAIR_STATE], PAIR_OPEN);
+  }
   u32 finished_interval = 0xFFFFFFFFu;  // interval of the task this wave has just completed
   for (;;) {
     // Pop one task.  Only lane 0 touches the counter, so this block branches on the lane id; the
@@ -233,7 +198,18 @@ __global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs
     finished_interval = 0xFFFFFFFFu;
     t = wave::bcast(t, 0);  // scalar from here on: the queue loop is a scalar loop
     if (t >= a.n_tasks) {  // every wave leaves once the queue is empty
-      if (lds.mbox != nullptr) pair_dismiss(lds.mbox);
+      if (lds.mbox == nullptr) break;
+      if (!lds.pair_dynamic) {
+        pair_dismiss(lds.mbox);
+      } else {
+        // no more hand-overs: the word goes back to PAIR_IDLE; a helper that had claimed it is dismissed
+        wave::lockstep();
+        u32 leader2 = wave::lane();
+        asm volatile("" : "+v"(leader2));
+        u32 old = PAIR_IDLE;
+        if (leader2 == 0) old = wave::exchange_wg(&lds.mbox[PAIR_STATE], PAIR_IDLE);
+        if (wave::bcast(old, 0) == PAIR_TAKEN) pair_dismiss(lds.mbox);
+      }
       break;
     }
     if (wave::uniform(wave::load_system_u32(wave::as_global(a.abort_flag))) != 0) {
@@ -267,6 +243,92 @@ __global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs
     // contact increments (memory-side atomics) and the result words are performed before the
     // completion count of the interval drops
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  }
+}
+
+__global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs a) {
+  __shared__ BlockLds s;
+  load_block_tables(s, a.tables, kThreadsPerBlock);
+  const int wave_in_block = wave::uniform(static_cast<int>(threadIdx.x / 64));
+  const u32 slot = blockIdx.x * kWavesPerBlock + wave_in_block;
+  WaveLds lds = make_wave_lds(s, wave_in_block);
+  // Roles (sim_pair.h).  Launches that leave wave slots empty (pair_mains != 0): fixed trios of
+  // main wave / helper / PRNG producer.  Launches that fill the slots: every wave is a main wave
+  // (one cell per wave) until the queue is empty, and then the helper of a main wave of its
+  // workgroup that is still running.
+  const bool fixed = a.pair_mains != 0;
+  const bool dynamic = !fixed && a.tail_helpers != 0;
+  int serve_main = -1;  // >= 0: this wave is the helper of that main wave
+  u32* feed = nullptr;
+  if (fixed) {
+    // with one or two main waves per workgroup there are waves to spare: wave 2 + m produces the
+    // PRNG blocks for the helper of main wave m while that helper draws the moves (pair_feed)
+#ifndef MODLE_RNG_PHILOX
+    if (a.pair_mains <= 2 && wave_in_block >= 2 && wave_in_block < 4) {
+      const int m = wave_in_block - 2;
+      if (static_cast<u32>(m) >= a.pair_mains) return;
+      const WaveLds lm = make_wave_lds(s, m);
+      pair_feed(lm.ring, lm.jump_table, lm.rng_state, lm.rng_snap, reinterpret_cast<u32*>(s.rng_state[wave_in_block]));
+      return;
+    }
+#endif
+    const int main_wave = wave_in_block < kWavesPerBlock / 2 ? wave_in_block : kWavesPerBlock - 1 - wave_in_block;
+    if (static_cast<u32>(main_wave) >= a.pair_mains) return;
+#ifndef MODLE_RNG_PHILOX
+    if (a.pair_mains <= 2) feed = reinterpret_cast<u32*>(s.rng_state[2 + main_wave]);
+#endif
+    if (wave_in_block != main_wave) serve_main = main_wave;
+  }
+  if (serve_main < 0) {
+    if (static_cast<u32>(wave_in_block) >= a.active_waves) return;
+    if (fixed || dynamic) lds.mbox = s.pairbox[wave_in_block];
+    lds.pair_dynamic = dynamic;
+    simulate_tasks(a, lds, slot, wave_in_block);
+    if (!dynamic) return;
+  }
+  for (;;) {
+    u32* mbox = nullptr;
+    u32 seen = 0;  // (fixed roles: the request counter starts from zero)
+    if (dynamic) {
+      // the queue is empty: claim a main wave of this workgroup that is still running without a
+      // helper (its request counter is read BEFORE the claim: the main wave posts requests only once
+      // it has seen the claim)
+      serve_main = -1;
+      for (int w = 0; w < kWavesPerBlock && serve_main < 0; ++w) {
+        u32* m = s.pairbox[w];
+        if (w == wave_in_block || wave::uniform(wave::ld_acquire_wg(&m[PAIR_STATE])) != PAIR_OPEN) continue;
+        seen = wave::uniform(m[PAIR_REQ]);
+        wave::lockstep();
+        u32 leader = wave::lane();
+        asm volatile("" : "+v"(leader));
+        u32 won = 0;
+        if (leader == 0) won = wave::cas_wg(&m[PAIR_STATE], PAIR_OPEN, PAIR_TAKEN) ? 1u : 0u;
+        if (wave::bcast(won, 0) != 0) serve_main = w;
+      }
+      if (serve_main < 0) return;
+      mbox = s.pairbox[serve_main];
+    } else {
+      mbox = s.pairbox[serve_main];
+    }
+    {
+      // the helper: the main wave's generator, tables and workspace, its own staging and sort buffers
+      Cell c;
+      c.p = &a.params;
+      c.lds = make_wave_lds(s, serve_main);
+      c.lds.stage = lds.stage;
+      c.lds.sort_lds = lds.sort_lds;
+      c.ws = device_carve(a.workspace + static_cast<u64>(blockIdx.x * kWavesPerBlock + serve_main) * a.workspace_stride,
+                          a.max_lefs, a.max_barriers, a.params.hist_len);
+      c.g.ring = c.lds.ring;
+      c.g.jump = c.lds.jump_table;
+      c.g.state = c.lds.rng_state;
+      c.g.snap = c.lds.rng_snap;
+      c.n_hit[0] = 0;
+      c.n_hit[1] = 0;
+      c.g.feed = nullptr;
+      pair_serve(c, wave::as_global(a.intervals), mbox, feed, seen);
+    }
+    if (!dynamic) return;
   }
 }
 
@@ -801,6 +863,11 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
     if (paired)
       a.pair_mains = static_cast<u32>(std::min(kMaxMains, (sorted.size() + static_cast<size_t>(grid) - 1) / grid));
   }
+  a.tail_helpers = a.pair_mains == 0 ? 1u : 0u;
+  if (const char* th = std::getenv("MODLE_HIP_TAIL_HELPERS"); th != nullptr && th[0] == '0') a.tail_helpers = 0;
+#ifdef MODLE_STAGE_TRACE
+  a.tail_helpers = 0;
+#endif
   a.active_waves = kWavesPerBlock;
   if (const char* aw = std::getenv("MODLE_HIP_ACTIVE_WAVES"); aw != nullptr) {
     // diagnostic: how the kernel time scales with the waves in flight per CU

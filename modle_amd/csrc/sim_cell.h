@@ -57,6 +57,7 @@ struct Cell {
   // helper-wave mode (sim_pair.h): sequence number of the last request posted to the helper
   u32 pair_seq;
   u32 pair_interval;  // index of the task's interval (goes with every request)
+  bool pair_on;       // a helper serves this epoch's requests (sampled once per epoch)
 #ifdef MODLE_PHASE_TIMERS
   u64 ph[16];     // profiling build: time spent per phase (wave::clock ticks)
 #endif

@@ -1768,7 +1768,7 @@ MODLE_DEV bool phase_process_collisions(Cell& c) {
   PHASE(c, 8, bc = detect_boundaries(c));
   // helper-wave mode (sim_pair.h): without Bernoulli trials the two instances draw nothing and touch
   // disjoint arrays; the helper takes the fwd one
-  const bool split = c.lds.mbox != nullptr && stalling_lists_wanted(*c.p) && wave::uniform(c.iv->n_barriers) != 0;
+  const bool split = c.pair_on && stalling_lists_wanted(*c.p) && wave::uniform(c.iv->n_barriers) != 0;
   if (split) {
     PHASE(c, 9, pair_request_lef_bar(c, bc.n5, bc.n3); detect_lef_bar<false>(c, bc); pair_wait(c, PAIR_ALL));
   } else {

@@ -76,6 +76,7 @@ MODLE_DEV void init_cell(Cell& c, const Params& p, const Interval& iv, const Wor
   c.filter_on = false;
   // (the helper keeps counting the requests across the tasks of its main wave)
   c.pair_seq = lds.mbox != nullptr ? wave::uniform(lds.mbox[PAIR_REQ]) : 0u;
+  c.pair_on = false;
 #ifdef MODLE_PHASE_TIMERS
   for (int i = 0; i < 16; ++i) c.ph[i] = 0;
 #endif
@@ -270,7 +271,8 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
     trace_stage(c, epoch, 0);
     // helper-wave mode (sim_pair.h), burn-in epochs (nothing draws between the bind phase and the
     // moves): the helper draws the moves and the barrier states while this wave ranks the units
-    const bool offload = lds.mbox != nullptr && !burnin_completed;
+    c.pair_on = pair_helper_present(lds);
+    const bool offload = c.pair_on && !burnin_completed;
     if (offload) pair_request(c, burnin_completed, task.interval);
     PHASE(c, 2, rank_update<false>(c, false));
     PHASE(c, 3, rank_update<true>(c, false));

@@ -9,8 +9,11 @@ namespace modle_dev {
 // buffers; `intervals` is the launch's interval table.
 // `feed`: hand-over words of the wave that produces the PRNG blocks while the helper draws the moves
 // (pair_feed below), or nullptr when the workgroup has no wave to spare for it.
-MODLE_DEV void pair_serve(Cell& c, const Interval* intervals, u32* m, u32* feed) {
-  u32 seen = wave::uniform(m[PAIR_REQ]);
+// `seen`: the request counter as it was when this wave became the helper -- zero at the start of the
+// kernel, read BEFORE the claim for a helper that attaches later (read here, a request or the
+// dismissal that the main wave posted in between would be taken for an old one: the helper would
+// wait for ever).
+MODLE_DEV void pair_serve(Cell& c, const Interval* intervals, u32* m, u32* feed, u32 seen) {
   u32 fseq = 0;
   for (;;) {
     u32 seq;

@@ -41,9 +41,19 @@ constexpr u32 PAIR_KIND = 12;      // request: PAIR_KIND_MOVES / PAIR_KIND_LEF_B
 constexpr u32 PAIR_BC = 13;        // LEF-BAR request: BoundaryCounts (2 words)
 constexpr u32 PAIR_F_POS = 16;     // LEF-BAR request: the fwd position / move arrays (the rank updates
 constexpr u32 PAIR_F_MOVE = 18;    // and the move adjustment swap workspace pointers) (2 words each)
-constexpr u32 PAIR_WORDS = 20;
+constexpr u32 PAIR_STATE = 20;     // launches that fill the slots: PAIR_IDLE / PAIR_OPEN / PAIR_TAKEN (below)
+constexpr u32 PAIR_WORDS = 24;
 constexpr u32 PAIR_EXIT = 0xFFFFFFFFu;
 constexpr u32 PAIR_KIND_MOVES = 0, PAIR_KIND_LEF_BAR = 1;
+// Launches that fill the wave slots have an idle tail (the queue is empty, the last cells are still
+// running: 4.7 % of the slot time of BASELINE config 2).  A wave that finds the queue empty then
+// becomes the helper of a main wave of its workgroup that is still running and has none:
+//   PAIR_IDLE   the main wave is not running a task loop (never started, or left it)
+//   PAIR_OPEN   it is, and has no helper: an idle wave may claim it (compare-and-swap to PAIR_TAKEN)
+//   PAIR_TAKEN  a helper is attached; the main wave looks at the word once per epoch and hands work
+//               over from then on; when it leaves its task loop it swaps PAIR_IDLE in and, if the
+//               word was PAIR_TAKEN, dismisses the helper (which then looks for another main wave)
+constexpr u32 PAIR_IDLE = 0, PAIR_OPEN = 1, PAIR_TAKEN = 2;
 
 MODLE_DEV void pair_put_u64(u32* m, u32 at, u64 v) {
   m[at] = static_cast<u32>(v);
@@ -99,6 +109,12 @@ MODLE_DEV void pair_take_back(Cell& c) {
   c.g.gen_end = pair_get_u64(m, PAIR_GEN_END);
   c.n_hit[0] = wave::uniform(m[PAIR_N_HIT]);
   c.n_hit[1] = wave::uniform(m[PAIR_N_HIT + 1]);
+}
+// main wave, once per epoch: is there a helper to hand work to?
+MODLE_DEV bool pair_helper_present(const WaveLds& lds) {
+  if (lds.mbox == nullptr) return false;
+  if (!lds.pair_dynamic) return true;
+  return wave::uniform(wave::ld_acquire_wg(&lds.mbox[PAIR_STATE])) == PAIR_TAKEN;
 }
 // main wave, once its task queue is empty: the helper leaves its loop
 MODLE_DEV void pair_dismiss(u32* m) {

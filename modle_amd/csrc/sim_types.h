@@ -150,6 +150,7 @@ struct WaveLds {
   u32* stage;             // STAGE_CAP words (staged slice of sorted positions)
   u64* rng_snap;          // 2 x 4 words: generator state at the start of the two blocks in the ring
   u32* mbox;              // helper-wave mode (sim_pair.h): the pair's hand-over words in LDS, or nullptr
+  bool pair_dynamic;      // ... the helper may attach while the cell runs (PAIR_STATE says whether one has)
   const u32* abort_flag;  // device word polled once per epoch (cancellation) or nullptr
   u64* trace;             // optional per-epoch trace (4 words per epoch) or nullptr
   u32 trace_cap;          // epochs the trace buffer holds

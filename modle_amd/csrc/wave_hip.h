@@ -276,6 +276,14 @@ MODLE_DEV void st_release_wg(uint32_t* p, uint32_t v) {
 MODLE_DEV uint32_t ld_acquire_wg(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// One lane's compare-and-swap / exchange on such a word (call from ONE lane; workgroup scope)
+MODLE_DEV bool cas_wg(uint32_t* p, uint32_t expected, uint32_t desired) {
+  return __hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+MODLE_DEV uint32_t exchange_wg(uint32_t* p, uint32_t v) {
+  return __hip_atomic_exchange(p, v, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 // gives the issue slots of the SIMD to the other waves for a few dozen cycles (spin loops)
 MODLE_DEV void nap() { __builtin_amdgcn_s_sleep(2); }
 MODLE_DEV void atomic_inc_u32(uint32_t* p) { atomicAdd(p, 1u); }

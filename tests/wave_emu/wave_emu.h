@@ -246,6 +246,10 @@ MODLE_DEV uint32_t load_system_u32(const uint32_t* p) { return __atomic_load_n(p
 // (hand-over words of the helper-wave mode: the emulator runs one wave, the mode is never on)
 MODLE_DEV void st_release_wg(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 MODLE_DEV uint32_t ld_acquire_wg(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+MODLE_DEV bool cas_wg(uint32_t* p, uint32_t expected, uint32_t desired) {
+  return __atomic_compare_exchange_n(p, &expected, desired, false, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED);
+}
+MODLE_DEV uint32_t exchange_wg(uint32_t* p, uint32_t v) { return __atomic_exchange_n(p, v, __ATOMIC_ACQ_REL); }
 MODLE_DEV void nap() {}
 MODLE_DEV double own_regs(double v) { return v; }
 MODLE_DEV void atomic_inc_u32(uint32_t* p) { __atomic_fetch_add(p, 1u, __ATOMIC_RELAXED); }

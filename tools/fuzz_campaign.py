@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzz campaign on the GPU: python tools/fuzz_campaign.py FIRST_SEED N_SEEDS [v2|v3|v4]
-(random set-ups of tests/fuzz_cases.py, HIP path vs oracle, all outputs and per-cell counters)."""
+(random set-ups of tests/fuzz_cases.py, HIP path vs oracle, all outputs and per-cell counters; every
+set-up is launched in both modes: one wave per cell, and main wave + helper -- MODLE_HIP_PAIRED)."""
 import os
 import sys
 import time
@@ -33,15 +34,18 @@ for seed in range(first, first + count):
     oc, om, oo, ores = oracle.simulate_interval(
         cfg, chrom["start"], chrom["end"], chrom["bar_pos"], chrom["bar_dir"],
         case["stp_active"], case["stp_inactive"], tasks, nthreads=8, track_occupancy=track)
-    sim = api.Simulator(cfg, 0)
-    gc, gm, go, gres = sim.simulate_interval(
-        chrom["start"], chrom["end"], chrom["bar_pos"], chrom["bar_dir"], case["stp_active"],
-        case["stp_inactive"], tasks)
-    sim.close()
-    ok = np.array_equal(oc, gc) and om == gm and (not track or np.array_equal(oo, go))
-    for a, b in zip(ores, gres):
-        ok = ok and (a.epochs, a.burnin_epochs, a.num_contacts, a.raws_consumed, list(a.prng_final)) == (
-            b.epochs, b.burnin_epochs, b.num_contacts, b.raws_consumed, list(b.prng_final))
+    ok = True
+    for mode in ("0", "1"):
+        os.environ["MODLE_HIP_PAIRED"] = mode
+        sim = api.Simulator(cfg, 0)
+        gc, gm, go, gres = sim.simulate_interval(
+            chrom["start"], chrom["end"], chrom["bar_pos"], chrom["bar_dir"], case["stp_active"],
+            case["stp_inactive"], tasks)
+        sim.close()
+        ok = ok and np.array_equal(oc, gc) and om == gm and (not track or np.array_equal(oo, go))
+        for a, b in zip(ores, gres):
+            ok = ok and (a.epochs, a.burnin_epochs, a.num_contacts, a.raws_consumed, list(a.prng_final)) == (
+                b.epochs, b.burnin_epochs, b.num_contacts, b.raws_consumed, list(b.prng_final))
     if (seed - first) % 25 == 24:
         print(f"  .. seed {seed}, {time.time() - t0:.0f} s", flush=True)
     if not ok:
