@@ -34,6 +34,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def launch_mode(n_tasks):
+    """How modle_hip_launch runs this many tasks on an MI355X (256 compute units; the rule of
+    modle_amd/csrc/modle_hip.hip), for the bench line's `config`."""
+    import os
+
+    forced = os.environ.get("MODLE_HIP_PAIRED", "")
+    paired = n_tasks <= 4 * 256 if forced == "" else forced[0] != "0"
+    if paired:
+        mains = min(4, -(-n_tasks // min(256, max(n_tasks, 1))))
+        return ("main wave + helper + PRNG producer" if mains <= 2 else "main wave + helper") + \
+               " (launch leaves wave slots empty)"
+    tail = os.environ.get("MODLE_HIP_TAIL_HELPERS", "1")[:1] != "0"
+    return "one wave per cell" + (", idle waves help in the tail of the launch" if tail else "")
+
+
 def measured_traffic(workload_key):
     """HBM bytes per launch of the simulation kernel, from the PMC passes committed under
     profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same workload,
@@ -405,6 +420,7 @@ def main():
                        "total_cells": total_cells, "tasks_per_gpu": n_tasks,
                        "cell_epochs_per_gpu_step": epochs,
                        "longest_cell_epochs": longest, "mean_cell_epochs": epochs / max(n_tasks, 1), "seed": 0,
+                       "waves_per_cell": launch_mode(n_tasks),
                        "parallelism": f"cells sharded over {world} GPU(s); per-interval "
                                       + ("RCCL" if args.dist_backend == "nccl" else "gloo (host copies)")
                                       + " sum-reduce issued on a side stream as intervals complete"},

@@ -3,7 +3,8 @@
 #   kernel_stats.csv           rocprofv3 --kernel-trace --stats of the same command (+ its bench line)
 #   pmc_*                      separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / L2 hits / SQ)
 #   phase_breakdown.txt        profiling build (per-phase wave time)
-#   bench_chr1_512.json (+ kernel stats)   BASELINE config 1
+#   bench_chr1_512.json (+ kernel stats)   BASELINE config 1 (helper-wave mode), ..._one_wave.json without it
+#   bench_no_tail_helpers.json             the default workload with MODLE_HIP_TAIL_HELPERS=0
 set -e
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${PROFILE_TAG:-r02}; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err; cat $O/bench.json
@@ -18,5 +19,8 @@ MODLE_HIP_LIB=libmodle_hip_prof.so python3 $R/bench.py --steps 1 --warmup 0 --no
 grep -v amdgpu $O/phase_breakdown.txt
 python3 $R/bench.py --workload chr1 --cells 512 > $O/bench_chr1_512.json 2> $O/bench_chr1_512.err; cat $O/bench_chr1_512.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_chr1 -- python3 $R/bench.py --workload chr1 --cells 512 --no-cpu-baseline > $O/bench_chr1_512_under_rocprof.json 2> $O/rocprof_chr1.err
+# the same launch with one wave per cell (helper waves off), and the default launch without tail helpers
+MODLE_HIP_PAIRED=0 MODLE_HIP_TAIL_HELPERS=0 python3 $R/bench.py --workload chr1 --cells 512 --no-cpu-baseline > $O/bench_chr1_512_one_wave.json 2> $O/bench_chr1_512_one_wave.err; cat $O/bench_chr1_512_one_wave.json
+MODLE_HIP_TAIL_HELPERS=0 python3 $R/bench.py --no-cpu-baseline --steps 5 --warmup 1 > $O/bench_no_tail_helpers.json 2> $O/bench_no_tail_helpers.err; cat $O/bench_no_tail_helpers.json
 python3 $R/bench.py --rng philox --no-cpu-baseline > $O/bench_philox.json 2> $O/bench_philox.err; cat $O/bench_philox.json
 ls -R $O | head -60
