@@ -1548,17 +1548,27 @@ MODLE_DEV_NOINLINE u32 process_secondary(Cell& c, BoundaryCounts bc, u32* list, 
 // both directions: the two filters in one loop, then the rev and the fwd resolve pass (draw order)
 MODLE_DEV_NOINLINE void process_secondary_both(Cell& c, BoundaryCounts bc, u32* list_rev, u32* list_fwd,
                                                u32 list_cap, bool& overflow, u32& n_rev, u32& n_fwd) {
+  // helper-wave mode (sim_pair.h): the fwd filter runs on the helper during the rev filter and
+  // the rev resolve pass (the resolve passes draw: rev first, then fwd, both on this wave)
   SecondaryFilter<false> fr;
-  SecondaryFilter<true> ff;
   fr.init(c, bc, list_cap, true, true);
-  ff.init(c, bc, list_cap, true, true);
-  for (u32 t = 0; t < fr.nblk; ++t) {
-    fr.step(t);
-    ff.step(t);
+  u32 n_cand_fwd = 0;
+  if (c.pair_on) {
+    pair_request_sec_filter(c, bc.n5, bc.n3, list_cap);
+    for (u32 t = 0; t < fr.nblk; ++t) fr.step(t);
+  } else {
+    SecondaryFilter<true> ff;
+    ff.init(c, bc, list_cap, true, true);
+    for (u32 t = 0; t < fr.nblk; ++t) {
+      fr.step(t);
+      ff.step(t);
+    }
+    n_cand_fwd = ff.n_cand;
   }
   wave::sync_mem();
   n_rev = secondary_resolve<false>(c, fr.n_cand, list_rev, list_cap, overflow);
-  n_fwd = secondary_resolve<true>(c, ff.n_cand, list_fwd, list_cap, overflow);
+  if (c.pair_on) n_cand_fwd = pair_take_sec_filter(c);
+  n_fwd = secondary_resolve<true>(c, n_cand_fwd, list_fwd, list_cap, overflow);
 }
 
 // fix_secondary_lef_lef_collisions (reference: simulation_detect_collisions.cpp:517-644).

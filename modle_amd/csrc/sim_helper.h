@@ -42,6 +42,22 @@ MODLE_DEV void pair_serve(Cell& c, const Interval* intervals, u32* m, u32* feed,
       wave::st_release_wg(&m[PAIR_ALL], seq);
       continue;
     }
+    if (wave::uniform(m[PAIR_KIND]) == PAIR_KIND_SEC_FILTER) {
+      BoundaryCounts bc;
+      bc.n5 = wave::uniform(m[PAIR_BC]);
+      bc.n3 = wave::uniform(m[PAIR_BC + 1]);
+      c.ws.f_pos = wave::as_global(reinterpret_cast<u32*>(pair_get_u64(m, PAIR_F_POS)));
+      c.ws.f_move = wave::as_global(reinterpret_cast<u32*>(pair_get_u64(m, PAIR_F_MOVE)));
+      c.ws.tmp[1] = wave::as_global(reinterpret_cast<u32*>(pair_get_u64(m, PAIR_Q)));
+      SecondaryFilter<true> ff;
+      ff.init(c, bc, wave::uniform(m[PAIR_LIST_CAP]), true, true);
+      for (u32 t = 0; t < ff.nblk; ++t) ff.step(t);
+      wave::sync_mem();
+      wave::lockstep();
+      if (wave::lane() == 0) m[PAIR_N_HIT] = ff.n_cand;
+      wave::st_release_wg(&m[PAIR_ALL], seq);
+      continue;
+    }
     const bool burnin_completed = wave::uniform(m[PAIR_BURNIN_DONE]) != 0;
     c.g.pos = pair_get_u64(m, PAIR_POS);
     c.g.gen_end = pair_get_u64(m, PAIR_GEN_END);

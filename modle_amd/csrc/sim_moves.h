@@ -252,8 +252,10 @@ struct AdjustSweepX4 {
     Workspace& ws = c.ws;
     n = wave::uniform(c.n_active);
     lane = wave::lane();
-    start = c.iv->start;
-    last = c.iv->end - 1;
+    // (registers of their own: as fields of the interval descriptor they come back from a spill
+    // sixteen registers at a time, once per block)
+    start = wave::own_regs(c.iv->start);
+    last = wave::own_regs(c.iv->end - 1);
     pos = FWD ? ws.f_pos : ws.r_pos;
     uid = FWD ? ws.f_id : ws.r_id;
     mv_in = FWD ? ws.f_move : ws.r_move;

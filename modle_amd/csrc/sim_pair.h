@@ -21,6 +21,14 @@
 //   main:    ... boundaries | request | LEF-BAR rev | wait all | primary LEF-LEF ...
 //   helper:                 | LEF-BAR fwd | signal all
 //
+// Third kind, in every epoch: the filter pass of the secondary LEF-LEF pass (LEF-BAR move
+// corrections + the list of candidates; no draws, one direction's arrays).  The helper runs the
+// fwd filter while the main wave runs the rev filter AND the rev resolve pass (which draws, and
+// touches rev arrays only); the fwd resolve pass then takes the helper's list.
+//
+//   main:    ... primary | request | rev filter | rev resolve | wait all | fwd resolve ...
+//   helper:              | fwd filter | signal all (number of candidates)
+//
 // This file holds the main wave's side; the helper's loop is in sim_helper.h.
 //
 #pragma once
@@ -41,10 +49,12 @@ constexpr u32 PAIR_KIND = 12;      // request: PAIR_KIND_MOVES / PAIR_KIND_LEF_B
 constexpr u32 PAIR_BC = 13;        // LEF-BAR request: BoundaryCounts (2 words)
 constexpr u32 PAIR_F_POS = 16;     // LEF-BAR request: the fwd position / move arrays (the rank updates
 constexpr u32 PAIR_F_MOVE = 18;    // and the move adjustment swap workspace pointers) (2 words each)
+constexpr u32 PAIR_LIST_CAP = 21;  // secondary-filter request: capacity of the candidate list
+constexpr u32 PAIR_Q = 22;         // secondary-filter request: the fwd candidate list (2 words)
 constexpr u32 PAIR_STATE = 20;     // launches that fill the slots: PAIR_IDLE / PAIR_OPEN / PAIR_TAKEN (below)
 constexpr u32 PAIR_WORDS = 24;
 constexpr u32 PAIR_EXIT = 0xFFFFFFFFu;
-constexpr u32 PAIR_KIND_MOVES = 0, PAIR_KIND_LEF_BAR = 1;
+constexpr u32 PAIR_KIND_MOVES = 0, PAIR_KIND_LEF_BAR = 1, PAIR_KIND_SEC_FILTER = 2;
 // Launches that fill the wave slots have an idle tail (the queue is empty, the last cells are still
 // running: 4.7 % of the slot time of BASELINE config 2).  A wave that finds the queue empty then
 // becomes the helper of a main wave of its workgroup that is still running and has none:
@@ -95,6 +105,30 @@ MODLE_DEV void pair_request_lef_bar(Cell& c, u32 n5, u32 n3) {
   }
   ++c.pair_seq;
   wave::st_release_wg(&m[PAIR_REQ], c.pair_seq);
+}
+MODLE_DEV void pair_wait(Cell& c, u32 what);
+// main wave: the fwd filter of the secondary pass goes to the helper
+MODLE_DEV void pair_request_sec_filter(Cell& c, u32 n5, u32 n3, u32 list_cap) {
+  u32* m = c.lds.mbox;
+  wave::lockstep();
+  if (wave::lane() == 0) {
+    m[PAIR_N_ACTIVE] = c.n_active;
+    m[PAIR_INTERVAL] = c.pair_interval;
+    m[PAIR_KIND] = PAIR_KIND_SEC_FILTER;
+    m[PAIR_BC] = n5;
+    m[PAIR_BC + 1] = n3;
+    m[PAIR_LIST_CAP] = list_cap;
+    pair_put_u64(m, PAIR_F_POS, reinterpret_cast<u64>(c.ws.f_pos));
+    pair_put_u64(m, PAIR_F_MOVE, reinterpret_cast<u64>(c.ws.f_move));
+    pair_put_u64(m, PAIR_Q, reinterpret_cast<u64>(c.ws.tmp[1]));
+  }
+  ++c.pair_seq;
+  wave::st_release_wg(&m[PAIR_REQ], c.pair_seq);
+}
+// ... and its answer: the number of candidates it listed
+MODLE_DEV u32 pair_take_sec_filter(Cell& c) {
+  pair_wait(c, PAIR_ALL);
+  return wave::uniform(c.lds.mbox[PAIR_N_HIT]);
 }
 // main wave: waits until the helper has signalled `what` (PAIR_MOVES / PAIR_ALL) for the request
 MODLE_DEV void pair_wait(Cell& c, u32 what) {

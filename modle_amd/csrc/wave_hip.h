@@ -166,6 +166,11 @@ MODLE_DEV double own_regs(double v) {
   asm volatile("" : "+s"(v));
   return v;
 }
+MODLE_DEV uint32_t own_regs(uint32_t v) {
+  v = uniform(v);
+  asm volatile("" : "+s"(v));
+  return v;
+}
 // a ^ b ^ c in one instruction (v_bitop3_b32)
 MODLE_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
   return static_cast<uint32_t>(__builtin_amdgcn_bitop3_b32(a, b, c, 0x96));

@@ -252,6 +252,7 @@ MODLE_DEV bool cas_wg(uint32_t* p, uint32_t expected, uint32_t desired) {
 MODLE_DEV uint32_t exchange_wg(uint32_t* p, uint32_t v) { return __atomic_exchange_n(p, v, __ATOMIC_ACQ_REL); }
 MODLE_DEV void nap() {}
 MODLE_DEV double own_regs(double v) { return v; }
+MODLE_DEV uint32_t own_regs(uint32_t v) { return v; }
 MODLE_DEV void atomic_inc_u32(uint32_t* p) { __atomic_fetch_add(p, 1u, __ATOMIC_RELAXED); }
 MODLE_DEV void atomic_add_u64(uint64_t* p, uint64_t v) {
   __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
