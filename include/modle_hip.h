@@ -180,7 +180,9 @@ int modle_hip_submit_tasks(modle_hip_handle* h, int interval_id, const modle_hip
  * slots empty (at most 4 tasks per compute unit): a cell then gets a helper wave, and a third wave
  * for its PRNG blocks when there are at most 2 tasks per compute unit.  The
  * results do not depend on the mode; the environment variable MODLE_HIP_PAIRED=0 / 1, read at every
- * launch, forces it off / on (tests, A/B measurements). */
+ * launch, forces it off / on (tests, A/B measurements).  In a launch that fills the slots, a wave
+ * that finds the task queue empty helps a cell of its workgroup that is still running
+ * (MODLE_HIP_TAIL_HELPERS=0 turns that off). */
 int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen);
 /* Waits for the launch and collects per-task results (the counterpart of _ctx.shutdown(),
  * scheduler_simulate.cpp:162). */

@@ -18,6 +18,7 @@ from oracle import binding as oracle  # noqa: E402
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
 gen = {"v2": random_case_v2, "v3": random_case_v3, "v4": random_case_v4}.get(sys.argv[3] if len(sys.argv) > 3 else "", random_case)
+progress = open(os.environ["FUZZ_PROGRESS"], "w") if os.environ.get("FUZZ_PROGRESS") else None
 bad = 0
 skipped = 0
 t0 = time.time()
@@ -37,6 +38,12 @@ for seed in range(first, first + count):
     ok = True
     for mode in ("0", "1"):
         os.environ["MODLE_HIP_PAIRED"] = mode
+        if progress is not None:
+            # (what is about to be launched: a launch that hangs is then known by its seed and mode)
+            progress.seek(0)
+            progress.write(f"{seed} {mode} {case['kw']} size {case['size']}\n")
+            progress.truncate()
+            progress.flush()
         sim = api.Simulator(cfg, 0)
         gc, gm, go, gres = sim.simulate_interval(
             chrom["start"], chrom["end"], chrom["bar_pos"], chrom["bar_dir"], case["stp_active"],
