@@ -256,8 +256,12 @@ __global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs
   // main wave / helper / PRNG producer.  Launches that fill the slots: every wave is a main wave
   // (one cell per wave) until the queue is empty, and then the helper of a main wave of its
   // workgroup that is still running.
+#ifdef MODLE_NO_HELPERS  // (measurement: what the helper and producer loops cost the main path by being in the kernel)
+  const bool fixed = false, dynamic = false;
+#else
   const bool fixed = a.pair_mains != 0;
   const bool dynamic = !fixed && a.tail_helpers != 0;
+#endif
   int serve_main = -1;  // >= 0: this wave is the helper of that main wave
   u32* feed = nullptr;
   if (fixed) {

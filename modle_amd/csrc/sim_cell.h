@@ -62,6 +62,13 @@ struct Cell {
   u64 ph[16];     // profiling build: time spent per phase (wave::clock ticks)
 #endif
 };
+// (slot 14: LEF activation; a sub-phase measurement may claim slots 14 and 15 and sends the
+// activation time to slot 1 with the bind phase)
+#ifdef MODLE_SUBTIMER_LEFBAR
+#define MODLE_PH_ACTIVATION 1
+#else
+#define MODLE_PH_ACTIVATION 14
+#endif
 // Profiling build (make prof): PHASE(c, i, call) accumulates the time of `call` in c.ph[i].
 #ifdef MODLE_PHASE_TIMERS
 #define PHASE(c, i, ...)                          \

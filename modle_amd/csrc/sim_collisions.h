@@ -363,6 +363,9 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
     // keys the block spans (sweep order holds ascending positions for rev, descending for fwd)
     const u32 need_lo = FWD ? wave::bcast(lo_l, l_last) : wave::bcast(lo_f, l_first);
     const u32 need_hi = FWD ? wave::bcast(hi_f, l_first) : wave::bcast(hi_l, l_last);
+#ifdef MODLE_SUBTIMER_LEFBAR
+    const u64 t_stage = wave::clock();
+#endif
     if (need_lo < lo_cover || need_hi > hi_cover) {
       // Move the window along the list to where this block starts (one coalesced load of
       // positions and indices).  Entries the window has already passed are dropped by counting;
@@ -411,6 +414,10 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
         if (!beyond || ++moved > 64) break;  // (a block that is still not covered is looked up in device memory)
       }
     }
+#ifdef MODLE_SUBTIMER_LEFBAR
+    c.ph[14] += wave::clock() - t_stage;
+    const u64 t_search = wave::clock();
+#endif
     u32 winner[4], bpos[4];
     bool hard[4];
 #pragma unroll
@@ -560,6 +567,9 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
       lo_cover = 1;
       hi_cover = 0;
     }
+#ifdef MODLE_SUBTIMER_LEFBAR
+    c.ph[15] += wave::clock() - t_search;
+#endif
     if (wave::any((winner[0] & winner[1] & winner[2] & winner[3]) != 0xFFFFFFFFu)) {
 #pragma unroll
       for (u32 j = 0; j < 4; ++j) {

@@ -250,7 +250,7 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
       do {
         ++num_burnin_epochs;
         if (c.n_active != c.n_lefs) {
-          PHASE(c, 14, const u64 k = poisson_exact(c.g, lef_binding_rate_burnin);
+          PHASE(c, MODLE_PH_ACTIVATION, const u64 k = poisson_exact(c.g, lef_binding_rate_burnin);
                 const u64 na = static_cast<u64>(c.n_active) + k;
                 activate_lefs(c, c.n_active, na < c.n_lefs ? static_cast<u32>(na) : c.n_lefs));
         } else {
@@ -317,7 +317,9 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
 
   trace_stage(c, epoch, 6);
 #ifdef MODLE_PHASE_TIMERS
+#ifndef MODLE_SUBTIMER_LEFBAR
   c.ph[15] = wave::clock() - t_cell;  // (the whole cell: what the phases do not add up to is the glue between them)
+#endif
   if (lds.phase_ticks != nullptr && wave::lane() == 0) {
     for (int i = 0; i < 16; ++i) wave::atomic_add_u64(lds.phase_ticks + i, c.ph[i]);
   }

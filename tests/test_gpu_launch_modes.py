@@ -59,8 +59,8 @@ def test_tail_helpers_do_not_change_the_results(cells):
     wave runs cells; the waves that find the queue empty attach to the cells still running."""
     from modle_amd import api, synthetic
 
-    genome = [synthetic.synthetic_chromosome("chrA", 3_000_000, seed=11),
-              synthetic.synthetic_chromosome("chrB", 1_500_000, seed=12)]
+    genome = [synthetic.synthetic_chromosome("chrA", 14_000_000, seed=11),
+              synthetic.synthetic_chromosome("chrB", 5_000_000, seed=12)]
     cfg = api.make_config(num_cells=cells // 2, seed=3, track_1d_lef_position=1)
     plain = _launch(cfg, genome, {"MODLE_HIP_PAIRED": "0", "MODLE_HIP_TAIL_HELPERS": "0"})
     tail = _launch(cfg, genome, {"MODLE_HIP_PAIRED": "0", "MODLE_HIP_TAIL_HELPERS": "1"})
@@ -74,7 +74,7 @@ def test_fixed_roles_do_not_change_the_results(cells):
     """One, two and three-to-four main waves per workgroup (with and without the PRNG producer)."""
     from modle_amd import api, synthetic
 
-    genome = [synthetic.synthetic_chromosome("chrA", 4_000_000, seed=21)]
+    genome = [synthetic.synthetic_chromosome("chrA", 16_000_000, seed=21)]
     cfg = api.make_config(num_cells=cells, seed=5)
     plain = _launch(cfg, genome, {"MODLE_HIP_PAIRED": "0", "MODLE_HIP_TAIL_HELPERS": "0"})
     fixed = _launch(cfg, genome, {"MODLE_HIP_PAIRED": "1"})
