@@ -453,6 +453,10 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
   const u32 n_old = n - n_new;
   const u32 m2 = n_new != 0 ? pow2_ceil(n_new) : 0;
   for (u32 k = n_new + lane; k < m2; k += 64) keys[k] = ~u64(0);
+  // (a key of all ones behind the last one, also when n_new is a power of two: a step of the
+  // searches below that overshoots reads it, through one `v_min` on the index, instead of testing
+  // its range; n_new <= STAGE_CAP < SORT_LDS_CAP)
+  if (lane == 0) keys[n_new] = ~u64(0);
   for (u32 j = lane; j < n_new; j += 64) cnt_lds[j] = n_old;
   wave::sync_lds();
   if (m2 > 1) bitonic_sort_u64<true>(keys, m2);
@@ -519,25 +523,24 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
     for (u32 j = 0; j < 4; ++j) {
       lo[j] = carried[j] ? carry_lo : 0u;
       // (position, previous rank): units and keys with equal positions merge in the order of their
-      // previous ranks, which is what lets rank_finish order them by binding epoch alone
-      thr[j] = (static_cast<u64>(pp[j]) << 32) | (w + j);
+      // previous ranks, which is what lets rank_finish order them by binding epoch alone; a unit
+      // that takes no part has the key nothing lies below
+      thr[j] = carried[j] ? (static_cast<u64>(pp[j]) << 32) | (w + j) : u64(0);
     }
 #pragma unroll
     for (u32 sft = 8; sft >= 1; sft >>= 1) {
       // (the four reads of a round are issued together: left alone the compiler waits for each)
       u32 jx[4];
-      bool in[4];
       u64 kv[4];
 #pragma unroll
       for (u32 j = 0; j < 4; ++j) {
         jx[j] = lo[j] + sft;
-        in[j] = carried[j] & (jx[j] <= n_new);
-        kv[j] = keys[in[j] ? jx[j] - 1 : 0];  // (no branch around the read)
+        kv[j] = (keys - 1)[umin(jx[j], n_new + 1)];  // (beyond the keys: the sentinel)
       }
       wave::sched_fence();
 #pragma unroll
       for (u32 j = 0; j < 4; ++j) {
-        if (in[j] & (kv[j] < thr[j])) lo[j] = jx[j];
+        if (kv[j] < thr[j]) lo[j] = jx[j];
       }
       wave::sched_fence();
     }

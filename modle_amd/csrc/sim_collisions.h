@@ -277,8 +277,14 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
   const u32* moves = FWD ? ws.f_move : ws.r_move;
   u32* coll = FWD ? ws.f_coll : ws.r_coll;
   u32* barpos = stalling_barrier_positions<FWD>(ws);
-  u32* cp = reinterpret_cast<u32*>(c.lds.sort_lds);  // positions of the compacted barriers
-  u32* ci = cp + BAR_WIN;                              // their indices (| HITBAR_HARD)
+  // positions of the compacted barriers and their indices (| HITBAR_HARD): at most BAR_FILL entries,
+  // with a sentinel next to them so that the fixed-step searches need no range test -- rev: a word
+  // of all ones behind the last entry (cp[cnt]; a step that overshoots reads it through one
+  // `v_min` on the index); fwd: a zero in front of the first entry (the window starts one word into
+  // the buffer; a step that undershoots reads cp[-1] through one `v_max`)
+  constexpr u32 BAR_FILL = BAR_WIN - 1;
+  u32* cp = reinterpret_cast<u32*>(c.lds.sort_lds) + (FWD ? 1 : 0);
+  u32* ci = cp + BAR_WIN;
   const u32 j_rev0 = bc.n5 == 0 ? 0 : bc.n5 - 1;
   const u32 j_fwd0 = bc.n3 == 0 ? n - 1 : n - bc.n3;
   u32 carry_pos = 0;
@@ -334,7 +340,9 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
       const u32 nbr = j == 0 ? nbr0 : P[j - 1];
       // see detect_lef_bar; 32-bit keys: positions lie below 2^32 - 2 (the host rejects longer
       // intervals), and a reach beyond that is as good as 2^32 - 2
-      lo_key[j] = 0;
+      // (units that take no part: keys no window entry compares with -- nothing lies below 0,
+      // nothing at or above 2^32 - 1)
+      lo_key[j] = FWD ? 0xFFFFFFFFu : 0u;
       hi_key[j] = 0;
       if (bnd[j]) {
         if (!FWD) {
@@ -391,9 +399,9 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
           if (FWD) g1 = nh; else g0 = 0;
         }
         if (!FWD) {
-          g1 = umin(g0 + BAR_WIN, nh);
+          g1 = umin(g0 + BAR_FILL, nh);
         } else {
-          g0 = g1 > BAR_WIN ? g1 - BAR_WIN : 0;
+          g0 = g1 > BAR_FILL ? g1 - BAR_FILL : 0;
         }
         cnt = g1 - g0;
         wave::lockstep();
@@ -403,6 +411,9 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
           const u32 edge_lo = g0 > 0 ? hpos[g0 - 1] : 0;
           const u32 edge_hi = g1 < nh ? hpos[g1] : 0;
           stage_stalling_window_call((MODLE_LDS u32*)cp, (MODLE_LDS u32*)ci, hpos + g0, hidx + g0, cnt);
+          if (lane == 0) {
+            if (FWD) cp[-1] = 0u; else cp[cnt] = 0xFFFFFFFFu;  // (the sentinel of the searches)
+          }
           lo_cover = g0 > 0 ? wave::uniform(edge_lo) + 1 : 0;
           hi_cover = g1 < nh ? wave::uniform(edge_hi) : 0xFFFFFFFFu;
         }
@@ -437,17 +448,15 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
         for (u32 sft = 64; sft >= 1; sft >>= 1) {
           // (the four reads of a round are issued together: left alone the compiler waits for each)
           u32 jx[4], kv[4];
-          bool in[4];
 #pragma unroll
           for (u32 j = 0; j < 4; ++j) {
             jx[j] = q[j] + sft;
-            in[j] = bnd[j] & (jx[j] <= cnt);
-            kv[j] = cp[c0 + (in[j] ? jx[j] - 1 : 0)];  // (no branch around the read)
+            kv[j] = (cp - 1)[umin(jx[j], cnt + 1)];  // (beyond the window: the sentinel)
           }
           wave::sched_fence();
 #pragma unroll
           for (u32 j = 0; j < 4; ++j) {
-            if (in[j] & (kv[j] < hi_key[j])) q[j] = jx[j];
+            if (kv[j] < hi_key[j]) q[j] = jx[j];
           }
           wave::sched_fence();
         }
@@ -490,16 +499,16 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
 #pragma unroll
         for (u32 sft = 64; sft >= 1; sft >>= 1) {
           u32 kv[4];
-          bool in[4];
+          i32 tq[4];
 #pragma unroll
           for (u32 j = 0; j < 4; ++j) {
-            in[j] = bnd[j] & (q[j] >= sft);
-            kv[j] = cp[c0 + (in[j] ? q[j] - sft : 0)];  // (no branch around the read)
+            tq[j] = static_cast<i32>(q[j]) - static_cast<i32>(sft);
+            kv[j] = cp[tq[j] > -1 ? tq[j] : -1];  // (before the window: the sentinel)
           }
           wave::sched_fence();
 #pragma unroll
           for (u32 j = 0; j < 4; ++j) {
-            if (in[j] & (kv[j] >= lo_key[j])) q[j] -= sft;
+            if (kv[j] >= lo_key[j]) q[j] = static_cast<u32>(tq[j]);
           }
           wave::sched_fence();
         }
