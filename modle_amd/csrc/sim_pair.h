@@ -35,7 +35,7 @@
 
 namespace modle_dev {
 
-// Hand-over words (u32, in LDS; the helper's own lane-state words, which it does not use):
+// Hand-over words of main wave w (u32, in LDS: BlockLds::pairbox[w] in modle_hip.hip):
 constexpr u32 PAIR_REQ = 0;        // main -> helper: sequence number of the request
 constexpr u32 PAIR_MOVES = 1;      // helper -> main: the moves of request <seq> are in device memory
 constexpr u32 PAIR_ALL = 2;        // helper -> main: barrier states, lists and generator are back
@@ -44,14 +44,15 @@ constexpr u32 PAIR_BURNIN_DONE = 4;
 constexpr u32 PAIR_INTERVAL = 5;   // request: index of the task's interval
 constexpr u32 PAIR_POS = 6;        // generator: stream position (2 words), there and back
 constexpr u32 PAIR_GEN_END = 8;    // generator: end of the ring (2 words), there and back
-constexpr u32 PAIR_N_HIT = 10;     // reply: entries of the two lists of stalling barriers (2 words)
-constexpr u32 PAIR_KIND = 12;      // request: PAIR_KIND_MOVES / PAIR_KIND_LEF_BAR
+constexpr u32 PAIR_N_HIT = 10;     // reply: entries of the two lists of stalling barriers (2 words);
+                                   // secondary-filter reply: the number of candidates (first word)
+constexpr u32 PAIR_KIND = 12;      // request: PAIR_KIND_MOVES / PAIR_KIND_LEF_BAR / PAIR_KIND_SEC_FILTER
 constexpr u32 PAIR_BC = 13;        // LEF-BAR request: BoundaryCounts (2 words)
 constexpr u32 PAIR_F_POS = 16;     // LEF-BAR request: the fwd position / move arrays (the rank updates
 constexpr u32 PAIR_F_MOVE = 18;    // and the move adjustment swap workspace pointers) (2 words each)
+constexpr u32 PAIR_STATE = 20;     // launches that fill the slots: PAIR_IDLE / PAIR_OPEN / PAIR_TAKEN (below)
 constexpr u32 PAIR_LIST_CAP = 21;  // secondary-filter request: capacity of the candidate list
 constexpr u32 PAIR_Q = 22;         // secondary-filter request: the fwd candidate list (2 words)
-constexpr u32 PAIR_STATE = 20;     // launches that fill the slots: PAIR_IDLE / PAIR_OPEN / PAIR_TAKEN (below)
 constexpr u32 PAIR_WORDS = 24;
 constexpr u32 PAIR_EXIT = 0xFFFFFFFFu;
 constexpr u32 PAIR_KIND_MOVES = 0, PAIR_KIND_LEF_BAR = 1, PAIR_KIND_SEC_FILTER = 2;
