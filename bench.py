@@ -34,19 +34,14 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def launch_mode(n_tasks):
-    """How modle_hip_launch runs this many tasks on an MI355X (256 compute units; the rule of
-    modle_amd/csrc/modle_hip.hip), for the bench line's `config`."""
-    import os
-
-    forced = os.environ.get("MODLE_HIP_PAIRED", "")
-    paired = n_tasks <= 4 * 256 if forced == "" else forced[0] != "0"
-    if paired:
-        mains = min(4, -(-n_tasks // min(256, max(n_tasks, 1))))
-        return ("main wave + helper + PRNG producer" if mains <= 2 else "main wave + helper") + \
+def launch_mode(info):
+    """How the last launch ran its tasks, from the library's own record of it
+    (modle_hip_last_launch_info; the rule is in modle_amd/csrc/modle_hip.hip),
+    for the bench line's `config`."""
+    if info["helper_waves"]:
+        return ("main wave + helper + PRNG producer" if info["prng_producer_waves"] else "main wave + helper") + \
                " (launch leaves wave slots empty)"
-    tail = os.environ.get("MODLE_HIP_TAIL_HELPERS", "1")[:1] != "0"
-    return "one wave per cell" + (", idle waves help in the tail of the launch" if tail else "")
+    return "one wave per cell" + (", idle waves help in the tail of the launch" if info["tail_helpers"] else "")
 
 
 def measured_traffic(workload_key):
@@ -59,13 +54,26 @@ def measured_traffic(workload_key):
         with open(path) as f:
             table = json.load(f)
     except (OSError, ValueError):
-        return None
-    entry = table.get(workload_key)
+        return None, None
+    entry = table.get(workload_key) if isinstance(table, dict) else None
     if not entry:
         return None, None
-    # where and on which kernel it was measured: the figure is a committed measurement of another
-    # run (PMC counters cannot be collected from inside the benchmark), and the JSON line says so
+    # The figure is a committed measurement of ANOTHER run (PMC counters cannot be collected from
+    # inside the benchmark): it describes the kernel it was measured on.  The entry records a hash
+    # of the device sources (tools/csrc_hash.py); when the sources of this run hash differently the
+    # figure is stale and the line says `traffic: null` rather than quote it.
+    measured_on = entry.get("csrc_sha256")
+    if measured_on is None or measured_on != csrc_hash():
+        return None, (f"stale: {entry.get('source', 'profiles/')} was measured on device sources "
+                      f"{str(measured_on)[:12]}, this run is {csrc_hash()[:12]}")
     return entry["bytes_per_launch"], f"{entry.get('source', 'profiles/')}; {entry.get('kernel', '')}"
+
+
+def csrc_hash():
+    """sha256 over the device sources of the simulation kernel (what `roofline.traffic` is tied to)"""
+    from tools.csrc_hash import csrc_sha256
+
+    return csrc_sha256(ROOT)
 
 
 def parse_args():
@@ -91,8 +99,10 @@ def parse_args():
     ap.add_argument("--checksum-out", default=None,
                     help="rank 0 writes {interval: [sum, position-weighted sum]} of the final (reduced) "
                          "matrices and occupancy tracks of the last step to this JSON file")
-    ap.add_argument("--poll-timeout", type=float, default=1800.0,
-                    help="seconds to wait for an interval of the launch in flight before giving up")
+    ap.add_argument("--poll-timeout", type=float, default=900.0,
+                    help="deadline of one launch in seconds, single-GPU and distributed paths alike: past "
+                         "it the launch is aborted (modle_hip_set_wait_timeout: the abort word is raised, "
+                         "the kernel drains) and the job fails instead of hanging the box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=None)
     return ap.parse_args()
@@ -227,12 +237,13 @@ def main():
         unit = f"{args.chrom}-cells/s"
     elif args.workload == "grch38":
         genome = synthetic.grch38_like(seed=42)
-        workload = (f"GRCh38-shaped genome (24 chromosomes, synthetic H1-like barriers), "
+        workload = (f"GRCh38-shaped genome (24 chromosomes, synthetic H1-like barriers: the bundled file's "
+                    f"count per chromosome), "
                     f"{cells_txt}, reference defaults (BASELINE configs[2]/[3])")
         unit = "genome-cells/s"
     else:
         genome = synthetic.grch38_like(seed=42, chroms={"chr1"})
-        workload = (f"chr1-shaped interval (248 956 422 bp, 3129 synthetic barriers), "
+        workload = (f"chr1-shaped interval (248 956 422 bp, {len(genome[0]['bar_pos'])} synthetic barriers), "
                     f"{cells_txt}, reference defaults (BASELINE configs[1])")
         unit = "chr1-cells/s"
     cfg = api.make_config(num_cells=total_cells, seed=0)
@@ -250,6 +261,7 @@ def main():
         buffers.append((c.data_ptr(), o.data_ptr()))
         tensors.append((c, o))
     sim = api.Simulator(cfg, local_rank)
+    sim.set_wait_timeout(args.poll_timeout)  # (a launch that hangs fails the job: api.ERR_TIMEOUT)
     ids = driver.enqueue_plan(sim, cfg, plan, buffers)  # uploads barriers, enqueues step 0
     stream = torch.cuda.current_stream(dev)
 
@@ -359,8 +371,13 @@ def main():
         epochs += sum(r.epochs for r in last)
         longest = max(longest, max((r.epochs for r in last), default=0))
         n_tasks += k
-    avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3 if kernel_ms else float("nan")
-    achieved = step_bytes / avg_kernel_s / 1e9
+    import math
+
+    # (an event that could not be recorded leaves NaN: the line then says null instead of NaN,
+    # which is not JSON)
+    timed = [ms for ms in kernel_ms if math.isfinite(ms) and ms > 0]
+    avg_kernel_s = (sum(timed) / len(timed)) / 1e3 if timed else None
+    achieved = step_bytes / avg_kernel_s / 1e9 if avg_kernel_s else None
 
     # verify the outputs of the last step (every rank checks its own shard; a violation raises
     # and fails the job: the number printed below comes from a launch whose results were looked at)
@@ -420,15 +437,15 @@ def main():
                        "total_cells": total_cells, "tasks_per_gpu": n_tasks,
                        "cell_epochs_per_gpu_step": epochs,
                        "longest_cell_epochs": longest, "mean_cell_epochs": epochs / max(n_tasks, 1), "seed": 0,
-                       "waves_per_cell": launch_mode(n_tasks),
+                       "waves_per_cell": launch_mode(sim.launch_info()),
                        "parallelism": f"cells sharded over {world} GPU(s); per-interval "
                                       + ("RCCL" if args.dist_backend == "nccl" else "gloo (host copies)")
                                       + " sum-reduce issued on a side stream as intervals complete"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved is not None else None,
                          "traffic": traffic_bytes, "traffic_source": traffic_source,
                          "kernel": "modle_simulate_cells",
-                         "kernel_ms": avg_kernel_s * 1e3,
+                         "kernel_ms": avg_kernel_s * 1e3 if avg_kernel_s else None,
                          "algorithmic_bytes_per_launch": step_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -28,6 +28,7 @@ extern "C" {
 #define MODLE_HIP_ERR_UNSUPPORTED (-3)
 #define MODLE_HIP_ERR_STATE (-4)
 #define MODLE_HIP_ERR_CANCELLED (-5)
+#define MODLE_HIP_ERR_TIMEOUT (-6)
 
 /* contact_sampling_strategy flags (reference: simulation_config.hpp:33-38) */
 #define MODLE_HIP_CS_NOISIFY 1u
@@ -185,8 +186,31 @@ int modle_hip_submit_tasks(modle_hip_handle* h, int interval_id, const modle_hip
  * (MODLE_HIP_TAIL_HELPERS=0 turns that off). */
 int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen);
 /* Waits for the launch and collects per-task results (the counterpart of _ctx.shutdown(),
- * scheduler_simulate.cpp:162). */
+ * scheduler_simulate.cpp:162).  The wait is bounded: when the launch has been running for longer
+ * than the handle's deadline (default 3600 s; environment variable MODLE_HIP_WAIT_TIMEOUT_S at
+ * modle_hip_create, or modle_hip_set_wait_timeout) the abort word of modle_hip_cancel is raised --
+ * the waves read it every sixteenth epoch and inside every spin loop of the helper-wave protocol, so
+ * a wave whose partner has stopped answering leaves too -- and the call returns
+ * MODLE_HIP_ERR_TIMEOUT once the kernel has drained: the outputs are incomplete, the handle is
+ * usable again after modle_hip_reset.  A kernel that does not drain within
+ * MODLE_HIP_DRAIN_TIMEOUT_S (default 60 s) is a hung device: MODLE_HIP_ERR_DEVICE, the launch stays
+ * in flight and the process should exit (reference semantics: `_ctx` polled every epoch,
+ * simulation.cpp:933; workers never wait for each other, scheduler_simulate.cpp:264-270). */
 int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen);
+/* Deadline of modle_hip_wait in seconds, counted from modle_hip_launch (> 0). */
+int modle_hip_set_wait_timeout(modle_hip_handle* h, double seconds);
+/* How the last launch was laid out on the GPU (what `MODLE_HIP_PAIRED` / the task count chose). */
+typedef struct modle_hip_launch_info {
+  uint64_t n_tasks;
+  uint64_t num_cus;                  /* compute units of the device */
+  uint64_t workgroups;               /* persistent workgroups launched (one per compute unit at most) */
+  uint64_t waves_per_workgroup;
+  uint64_t main_waves_per_workgroup; /* waves that pull tasks */
+  uint64_t helper_waves;             /* per main wave: 1 in helper-wave mode, else 0 */
+  uint64_t prng_producer_waves;      /* per main wave: 1 when a third wave produces the PRNG blocks */
+  uint64_t tail_helpers;             /* 1: waves that find the queue empty help running cells */
+} modle_hip_launch_info;
+int modle_hip_last_launch_info(modle_hip_handle* h, modle_hip_launch_info* info);
 /* Asks a launch in flight to stop (the counterpart of the `_ctx` flag the reference polls once
  * per epoch, simulation.cpp:933; here every sixteenth epoch, the word being in host-mapped memory
  * so that it can be raised while the kernel holds every CU): every cell leaves at the top of one of its next epochs, cells that

@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-from .params import CellResult, Config, Task
+from .params import CellResult, Config, LaunchInfo, Task
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, os.environ.get("MODLE_HIP_LIB", "libmodle_hip.so"))
@@ -24,7 +24,8 @@ EXPORTS = [
     "modle_hip_interval_outputs", "modle_hip_copy_outputs", "modle_hip_reset",
     "modle_hip_simulate_interval", "modle_hip_test_phases", "modle_hip_sort_barriers",
     "modle_hip_cancel", "modle_hip_test_units", "modle_hip_interval_done",
-    "modle_hip_enable_state_log", "modle_hip_get_state_log",
+    "modle_hip_enable_state_log", "modle_hip_get_state_log", "modle_hip_set_wait_timeout",
+    "modle_hip_last_launch_info",
 ]
 
 u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
@@ -85,6 +86,8 @@ def lib():
     L.modle_hip_submit_tasks.argtypes = [C.c_void_p, C.c_int, P(Task), C.c_size_t] + err
     L.modle_hip_launch.argtypes = [C.c_void_p, C.c_void_p] + err
     L.modle_hip_wait.argtypes = [C.c_void_p] + err
+    L.modle_hip_set_wait_timeout.argtypes = [C.c_void_p, C.c_double]
+    L.modle_hip_last_launch_info.argtypes = [C.c_void_p, P(LaunchInfo)]
     L.modle_hip_last_kernel_ms.argtypes = [C.c_void_p, P(C.c_float)]
     L.modle_hip_get_results.argtypes = [C.c_void_p, C.c_int, P(CellResult), C.c_size_t]
     L.modle_hip_interval_outputs.argtypes = [C.c_void_p, C.c_int, P(C.c_void_p), P(C.c_void_p),

@@ -10,19 +10,26 @@ import ctypes as C
 import numpy as np
 
 from ._lib import lib
-from .params import CellResult, Config, Task
+from .params import CellResult, Config, LaunchInfo, Task
 
 
 Config = Config  # re-exported: `api.Config` is the ctypes mirror of modle_hip_config
 
 
+ERR_ARG, ERR_DEVICE, ERR_UNSUPPORTED, ERR_STATE, ERR_CANCELLED, ERR_TIMEOUT = -1, -2, -3, -4, -5, -6
+
+
 class ModleHipError(RuntimeError):
-    pass
+    """a negative return code of the C ABI (`code`: MODLE_HIP_ERR_*)"""
+
+    def __init__(self, message, code=None):
+        super().__init__(message)
+        self.code = code
 
 
 def _check(rc, err):
     if rc < 0:
-        raise ModleHipError(f"modle_hip error {rc}: {err.value.decode(errors='replace')}")
+        raise ModleHipError(f"modle_hip error {rc}: {err.value.decode(errors='replace')}", rc)
     return rc
 
 
@@ -180,8 +187,21 @@ class Simulator:
         _check(self._L.modle_hip_launch(self._h, stream, err, len(err)), err)
 
     def wait(self):
+        """collects the launch; raises ModleHipError with code ERR_TIMEOUT when the launch ran into
+        the deadline (set_wait_timeout / MODLE_HIP_WAIT_TIMEOUT_S) and was aborted"""
         err = _errbuf()
         _check(self._L.modle_hip_wait(self._h, err, len(err)), err)
+
+    def set_wait_timeout(self, seconds):
+        if self._L.modle_hip_set_wait_timeout(self._h, float(seconds)) < 0:
+            raise ModleHipError("modle_hip_set_wait_timeout: the deadline must be positive", ERR_ARG)
+
+    def launch_info(self):
+        """layout of the last launch (modle_hip_launch_info) as a dict"""
+        info = LaunchInfo()
+        if self._L.modle_hip_last_launch_info(self._h, C.byref(info)) < 0:
+            raise ModleHipError("modle_hip_last_launch_info failed")
+        return {name: int(getattr(info, name)) for name, _ in LaunchInfo._fields_}
 
     def enable_state_log(self, max_epochs_per_task):
         """--log-model-internal-state: needs the diagnostic build (MODLE_HIP_LIB=

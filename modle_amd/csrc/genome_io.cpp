@@ -293,10 +293,17 @@ int modle_genome_import(const char* chrom_sizes, size_t chrom_sizes_len, const c
         const double sa = b.score != 0.0 ? modle_hip_stp_active_from_occupancy(puu, b.score) : pbb;
         for (Interval& iv : g->intervals) {
           if (iv.chrom_id != it->second) continue;
-          // A barrier belongs to the interval its position (the record's midpoint) falls in.  (A
-          // record that straddles an interval's edge with its midpoint outside trips the assert of
-          // GenomicInterval::add_extrusion_barriers, genome.cpp:288-297, in the reference's debug
-          // builds; it is left out here.)
+          // A barrier belongs to the interval its position (the record's midpoint) falls in.
+          // DELIBERATE DIVERGENCE ("Known divergences"): a record that overlaps an
+          // interval while its midpoint lies outside it -- a record straddling the edge of a
+          // --genomic-intervals window, or a 1-bp record on the last base of a chromosome, whose
+          // midpoint (s + e + 1) / 2 equals the chromosome's end -- is KEPT by the reference's release
+          // builds: map_barriers_to_intervals hands every find_overlaps hit to
+          // GenomicInterval::add_extrusion_barriers(vector), which only asserts the range (debug
+          // builds; genome.cpp:288-297, 470-489).  Such a barrier can never stall a unit (units stay
+          // inside the interval) but it draws a state per epoch, so against a release reference the
+          // PRNG streams of that interval's cells differ.  Here it is left out: the device layout
+          // takes barrier positions inside the interval only (modle_hip_add_interval).
           if (pos < iv.start || pos >= iv.end) continue;
           iv.pos.push_back(pos);
           iv.dir.push_back(b.strand == '+' ? MODLE_HIP_DIR_REV : MODLE_HIP_DIR_FWD);

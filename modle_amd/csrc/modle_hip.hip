@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <mutex>
 #include <cstdio>
@@ -24,6 +25,7 @@
 #include <memory>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "modle_hip.h"
@@ -79,6 +81,8 @@ struct SimArgs {
   // launches that fill the slots: a wave that finds the queue empty becomes the helper of a main
   // wave of its workgroup that is still running (sim_pair.h: PAIR_STATE); 0 = off
   u32 tail_helpers;
+  // tests only (MODLE_HIP_TEST_FAULT): a fault injected into the hand-over protocol (sim_helper.h)
+  u32 test_fault;
 };
 
 __device__ __forceinline__ Workspace device_carve(char* base, u32 max_lefs, u32 max_barriers, u32 hist_len) {
@@ -173,10 +177,7 @@ __device__ __forceinline__ void load_block_tables(BlockLds& s, const DeviceTable
 __device__ __forceinline__ void simulate_tasks(const SimArgs& a, const WaveLds& lds, u32 slot, int wave_in_block) {
   const Workspace ws = device_carve(a.workspace + static_cast<u64>(slot) * a.workspace_stride,
                                     a.max_lefs, a.max_barriers, a.params.hist_len);
-  if (lds.pair_dynamic) {
-    // this main wave is running: an idle wave of the workgroup may become its helper
-    wave::st_release_wg(&lds.mbox[PAIR_STATE], PAIR_OPEN);
-  }
+  if (lds.pair_dynamic) pair_open(lds.mbox);  // this main wave is running: an idle wave may become its helper
   u32 finished_interval = 0xFFFFFFFFu;  // interval of the task this wave has just completed
   for (;;) {
     // Pop one task.  Only lane 0 touches the counter, so this block branches on the lane id; the
@@ -202,13 +203,7 @@ __device__ __forceinline__ void simulate_tasks(const SimArgs& a, const WaveLds& 
       if (!lds.pair_dynamic) {
         pair_dismiss(lds.mbox);
       } else {
-        // no more hand-overs: the word goes back to PAIR_IDLE; a helper that had claimed it is dismissed
-        wave::lockstep();
-        u32 leader2 = wave::lane();
-        asm volatile("" : "+v"(leader2));
-        u32 old = PAIR_IDLE;
-        if (leader2 == 0) old = wave::exchange_wg(&lds.mbox[PAIR_STATE], PAIR_IDLE);
-        if (wave::bcast(old, 0) == PAIR_TAKEN) pair_dismiss(lds.mbox);
+        pair_close(lds.mbox);  // no more hand-overs; a helper that had claimed this wave is dismissed
       }
       break;
     }
@@ -272,7 +267,8 @@ __global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs
       const int m = wave_in_block - 2;
       if (static_cast<u32>(m) >= a.pair_mains) return;
       const WaveLds lm = make_wave_lds(s, m);
-      pair_feed(lm.ring, lm.jump_table, lm.rng_state, lm.rng_snap, reinterpret_cast<u32*>(s.rng_state[wave_in_block]));
+      pair_feed(lm.ring, lm.jump_table, lm.rng_state, lm.rng_snap, reinterpret_cast<u32*>(s.rng_state[wave_in_block]),
+                wave::as_global(a.abort_flag));
       return;
     }
 #endif
@@ -295,20 +291,8 @@ __global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs
     u32 seen = 0;  // (fixed roles: the request counter starts from zero)
     if (dynamic) {
       // the queue is empty: claim a main wave of this workgroup that is still running without a
-      // helper (its request counter is read BEFORE the claim: the main wave posts requests only once
-      // it has seen the claim)
-      serve_main = -1;
-      for (int w = 0; w < kWavesPerBlock && serve_main < 0; ++w) {
-        u32* m = s.pairbox[w];
-        if (w == wave_in_block || wave::uniform(wave::ld_acquire_wg(&m[PAIR_STATE])) != PAIR_OPEN) continue;
-        seen = wave::uniform(m[PAIR_REQ]);
-        wave::lockstep();
-        u32 leader = wave::lane();
-        asm volatile("" : "+v"(leader));
-        u32 won = 0;
-        if (leader == 0) won = wave::cas_wg(&m[PAIR_STATE], PAIR_OPEN, PAIR_TAKEN) ? 1u : 0u;
-        if (wave::bcast(won, 0) != 0) serve_main = w;
-      }
+      // helper (sim_pair.h: pair_claim)
+      serve_main = pair_claim(&s.pairbox[0][0], kWavesPerBlock, wave_in_block, seen);
       if (serve_main < 0) return;
       mbox = s.pairbox[serve_main];
     } else {
@@ -316,21 +300,20 @@ __global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs
     }
     {
       // the helper: the main wave's generator, tables and workspace, its own staging and sort buffers
-      Cell c;
+      // (every other field of the context zero: no list, no filter, no error)
+      Cell c{};
       c.p = &a.params;
       c.lds = make_wave_lds(s, serve_main);
       c.lds.stage = lds.stage;
       c.lds.sort_lds = lds.sort_lds;
+      c.lds.abort_flag = wave::as_global(a.abort_flag);
       c.ws = device_carve(a.workspace + static_cast<u64>(blockIdx.x * kWavesPerBlock + serve_main) * a.workspace_stride,
                           a.max_lefs, a.max_barriers, a.params.hist_len);
       c.g.ring = c.lds.ring;
       c.g.jump = c.lds.jump_table;
       c.g.state = c.lds.rng_state;
       c.g.snap = c.lds.rng_snap;
-      c.n_hit[0] = 0;
-      c.n_hit[1] = 0;
-      c.g.feed = nullptr;
-      pair_serve(c, wave::as_global(a.intervals), mbox, feed, seen);
+      pair_serve(c, wave::as_global(a.intervals), mbox, feed, seen, a.test_fault);
     }
     if (!dynamic) return;
   }
@@ -495,6 +478,12 @@ struct modle_hip_handle {
   size_t n_launched = 0;
   std::vector<std::pair<int, size_t>> launch_map;  // launch task -> (interval, submission idx)
   float last_ms = 0.0f;
+  // deadline of modle_hip_wait, counted from the launch (MODLE_HIP_WAIT_TIMEOUT_S /
+  // modle_hip_set_wait_timeout), and how long an aborted launch gets to drain
+  double wait_timeout_s = 3600.0;
+  double drain_timeout_s = 60.0;
+  std::chrono::steady_clock::time_point launched_at;
+  modle_hip_launch_info last_launch{};
 };
 
 extern "C" {
@@ -533,6 +522,10 @@ modle_hip_handle* modle_hip_create(const modle_hip_config* c, int device, char* 
   h->params = modle_host::make_params(*c);
   h->device = device;
   h->num_cus = prop.multiProcessorCount;
+  if (const char* e = std::getenv("MODLE_HIP_WAIT_TIMEOUT_S"); e != nullptr && std::atof(e) > 0.0)
+    h->wait_timeout_s = std::atof(e);
+  if (const char* e = std::getenv("MODLE_HIP_DRAIN_TIMEOUT_S"); e != nullptr && std::atof(e) > 0.0)
+    h->drain_timeout_s = std::atof(e);
   const std::vector<uint64_t> jump = modle_host::build_jump_table(RNG_BLOCK);
   std::vector<f64> zig;
   zig.insert(zig.end(), ZIG_NORM_X, ZIG_NORM_X + 129);
@@ -872,6 +865,9 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
 #ifdef MODLE_STAGE_TRACE
   a.tail_helpers = 0;
 #endif
+  a.test_fault = 0;
+  if (const char* tf = std::getenv("MODLE_HIP_TEST_FAULT"); tf != nullptr && std::strcmp(tf, "stuck_helper") == 0)
+    a.test_fault = TEST_FAULT_STUCK_HELPER;  // (tests/test_gpu_wait_deadline.py)
   a.active_waves = kWavesPerBlock;
   if (const char* aw = std::getenv("MODLE_HIP_ACTIVE_WAVES"); aw != nullptr) {
     // diagnostic: how the kernel time scales with the waves in flight per CU
@@ -900,6 +896,19 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
     h->launch_map.swap(sorted_map);
     h->n_launched = sorted.size();
     h->in_flight = true;
+    h->launched_at = std::chrono::steady_clock::now();
+    h->last_launch.n_tasks = sorted.size();
+    h->last_launch.num_cus = static_cast<uint64_t>(h->num_cus);
+    h->last_launch.workgroups = static_cast<uint64_t>(grid);
+    h->last_launch.waves_per_workgroup = kWavesPerBlock;
+    h->last_launch.main_waves_per_workgroup = a.pair_mains != 0 ? a.pair_mains : a.active_waves;
+    h->last_launch.helper_waves = a.pair_mains != 0 ? 1 : 0;
+#ifdef MODLE_RNG_PHILOX
+    h->last_launch.prng_producer_waves = 0;
+#else
+    h->last_launch.prng_producer_waves = (a.pair_mains != 0 && a.pair_mains <= 2) ? 1 : 0;
+#endif
+    h->last_launch.tail_helpers = a.tail_helpers;
     const bool ev1 = hipEventRecord(h->ev_stop, h->stream) == hipSuccess;
     h->timing_valid = ev0 && ev1;
     if (!h->timing_valid) (void)hipGetLastError();  // (clears the sticky error of the failed record)
@@ -921,10 +930,64 @@ int modle_hip_cancel(modle_hip_handle* h, char* err, size_t errlen) {
   return MODLE_HIP_OK;
 }
 
+int modle_hip_set_wait_timeout(modle_hip_handle* h, double seconds) {
+  if (h == nullptr || !(seconds > 0.0)) return MODLE_HIP_ERR_ARG;
+  h->wait_timeout_s = seconds;
+  return MODLE_HIP_OK;
+}
+
+int modle_hip_last_launch_info(modle_hip_handle* h, modle_hip_launch_info* info) {
+  if (h == nullptr || info == nullptr) return MODLE_HIP_ERR_ARG;
+  *info = h->last_launch;
+  return MODLE_HIP_OK;
+}
+
 int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen) {
   if (h == nullptr) return MODLE_HIP_ERR_ARG;
   if (!h->in_flight) return MODLE_HIP_OK;
   HIP_TRY(hipSetDevice(h->device));
+  // Bounded wait.  The stream is polled (no HIP call waits with a deadline); when the launch has
+  // been running for longer than the deadline the abort word is raised -- every wave reads it at the
+  // top of every sixteenth epoch and in every spin loop of the hand-over protocols (sim_rng.h:
+  // spin_nap_aborted) -- and the kernel gets `drain_timeout_s` to drain.  A launch that drains is
+  // reported as MODLE_HIP_ERR_TIMEOUT with the handle usable again (modle_hip_reset); one that does
+  // not is a hung device: MODLE_HIP_ERR_DEVICE, the launch stays in flight and the process should
+  // exit (never re-exec a process that has touched the GPU).
+  bool timed_out = false;
+  {
+    using clock = std::chrono::steady_clock;
+    const auto deadline = h->launched_at + std::chrono::duration_cast<clock::duration>(
+                                               std::chrono::duration<double>(h->wait_timeout_s));
+    clock::time_point drain_deadline{};
+    unsigned polls = 0;
+    for (;;) {
+      const hipError_t q = hipStreamQuery(h->stream);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) {
+        set_err(err, errlen, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+        return MODLE_HIP_ERR_DEVICE;
+      }
+      const auto now = clock::now();
+      if (!timed_out && now > deadline) {
+        std::lock_guard<std::mutex> lock(h->abort_mu);
+        __atomic_store_n(h->h_abort, 1u, __ATOMIC_RELEASE);
+        timed_out = true;
+        drain_deadline = now + std::chrono::duration_cast<clock::duration>(
+                                   std::chrono::duration<double>(h->drain_timeout_s));
+      } else if (timed_out && now > drain_deadline) {
+        set_err(err, errlen, "the launch exceeded the wait deadline of " + std::to_string(h->wait_timeout_s) +
+                                 " s and did not drain within " + std::to_string(h->drain_timeout_s) +
+                                 " s of the abort word being raised: the device is hung");
+        return MODLE_HIP_ERR_DEVICE;
+      }
+      // short launches (tests) end within the first polls; long ones are polled every 200 us
+      if (++polls < 4096) {
+        std::this_thread::yield();
+      } else {
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+      }
+    }
+  }
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->in_flight = false;
   if (!h->timing_valid || hipEventElapsedTime(&h->last_ms, h->ev_start, h->ev_stop) != hipSuccess) {
@@ -968,6 +1031,12 @@ int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen) {
                   std::to_string(status[i]) + " (internal capacity exceeded)");
       rc = MODLE_HIP_ERR_STATE;
     }
+  }
+  if (timed_out) {
+    set_err(err, errlen, "the launch exceeded the wait deadline of " + std::to_string(h->wait_timeout_s) +
+                             " s (MODLE_HIP_WAIT_TIMEOUT_S / modle_hip_set_wait_timeout): it was aborted and has "
+                             "drained; its outputs are incomplete");
+    return MODLE_HIP_ERR_TIMEOUT;
   }
   return rc;
 }

@@ -87,7 +87,8 @@ constexpr u32 REL_CAP = 2 * SORT_LDS_CAP;  // u32 entries in the LDS sort buffer
 constexpr u32 ERR_LIST_OVERFLOW = 1;
 constexpr u32 ERR_TRIAL_OVERFLOW = 2;
 constexpr u32 ERR_INTERNAL = 3;
-constexpr u32 ERR_CANCELLED = 4;  // the host raised the abort word (reference: _ctx polled per epoch)
+// (ERR_CANCELLED = 4, sim_rng.h: the host raised the abort word -- modle_hip_cancel, or the deadline
+// of modle_hip_wait)
 
 // copy of an interval descriptor whose pointers are known to address device memory
 MODLE_DEV Interval interval_in_device_memory(const Interval& iv) {

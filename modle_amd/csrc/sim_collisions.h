@@ -1799,7 +1799,9 @@ MODLE_DEV bool phase_process_collisions(Cell& c) {
   // disjoint arrays; the helper takes the fwd one
   const bool split = c.pair_on && stalling_lists_wanted(*c.p) && wave::uniform(c.iv->n_barriers) != 0;
   if (split) {
-    PHASE(c, 9, pair_request_lef_bar(c, bc.n5, bc.n3); detect_lef_bar<false>(c, bc); pair_wait(c, PAIR_ALL));
+    bool handed = false;
+    PHASE(c, 9, pair_request_lef_bar(c, bc.n5, bc.n3); detect_lef_bar<false>(c, bc); handed = pair_wait(c, PAIR_ALL));
+    if (!handed) return false;  // (c.error says why: sim_pair.h)
   } else {
     PHASE(c, 9, detect_lef_bar<false>(c, bc); detect_lef_bar<true>(c, bc));
   }

@@ -278,8 +278,9 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
     PHASE(c, 3, rank_update<true>(c, false));
     trace_stage(c, epoch, 1);
     if (c.error != 0) {
-      if (offload) pair_take_back(c);
-      status = c.error;
+      const u32 first_error = c.error;
+      if (offload) (void)pair_take_back(c);
+      status = first_error;
       break;
     }
 
@@ -294,11 +295,22 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
     sum_active += c.n_active;
     ++sim_epochs;
     if (offload) {
+      // (a wait that fails -- the host raised the abort word, or the helper reported an error -- ends
+      // the cell: what the helper was to deliver is not there)
       c.max_fwd_move = 0xFFFFFFFFu;
-      PHASE(c, 5, pair_wait(c, PAIR_MOVES));
+      bool handed = false;
+      PHASE(c, 5, handed = pair_wait(c, PAIR_MOVES));
+      if (!handed) {
+        status = c.error;
+        break;
+      }
       phase_adjust_moves_by_id(c);
       trace_stage(c, epoch, 2);
-      PHASE(c, 7, pair_take_back(c));
+      PHASE(c, 7, handed = pair_take_back(c));
+      if (!handed) {
+        status = c.error;
+        break;
+      }
     } else {
       phase_generate_moves(c, burnin_completed);
       trace_stage(c, epoch, 2);

@@ -48,6 +48,8 @@ constexpr u32 PAIR_N_HIT = 10;     // reply: entries of the two lists of stallin
                                    // secondary-filter reply: the number of candidates (first word)
 constexpr u32 PAIR_KIND = 12;      // request: PAIR_KIND_MOVES / PAIR_KIND_LEF_BAR / PAIR_KIND_SEC_FILTER
 constexpr u32 PAIR_BC = 13;        // LEF-BAR request: BoundaryCounts (2 words)
+constexpr u32 PAIR_ERR = 15;       // reply: error status of the helper's side of the request (0 = none); written
+                                   // before PAIR_MOVES / PAIR_ALL, folded into the cell's status by the main wave
 constexpr u32 PAIR_F_POS = 16;     // LEF-BAR request: the fwd position / move arrays (the rank updates
 constexpr u32 PAIR_F_MOVE = 18;    // and the move adjustment swap workspace pointers) (2 words each)
 constexpr u32 PAIR_STATE = 20;     // launches that fill the slots: PAIR_IDLE / PAIR_OPEN / PAIR_TAKEN (below)
@@ -66,6 +68,7 @@ constexpr u32 PAIR_KIND_MOVES = 0, PAIR_KIND_LEF_BAR = 1, PAIR_KIND_SEC_FILTER =
 //               word was PAIR_TAKEN, dismisses the helper (which then looks for another main wave)
 constexpr u32 PAIR_IDLE = 0, PAIR_OPEN = 1, PAIR_TAKEN = 2;
 
+// (every spin loop below is bounded by the host through spin_nap_aborted, sim_rng.h)
 MODLE_DEV void pair_put_u64(u32* m, u32 at, u64 v) {
   m[at] = static_cast<u32>(v);
   m[at + 1] = static_cast<u32>(v >> 32);
@@ -107,7 +110,7 @@ MODLE_DEV void pair_request_lef_bar(Cell& c, u32 n5, u32 n3) {
   ++c.pair_seq;
   wave::st_release_wg(&m[PAIR_REQ], c.pair_seq);
 }
-MODLE_DEV void pair_wait(Cell& c, u32 what);
+MODLE_DEV bool pair_wait(Cell& c, u32 what);
 // main wave: the fwd filter of the secondary pass goes to the helper
 MODLE_DEV void pair_request_sec_filter(Cell& c, u32 n5, u32 n3, u32 list_cap) {
   u32* m = c.lds.mbox;
@@ -126,24 +129,41 @@ MODLE_DEV void pair_request_sec_filter(Cell& c, u32 n5, u32 n3, u32 list_cap) {
   ++c.pair_seq;
   wave::st_release_wg(&m[PAIR_REQ], c.pair_seq);
 }
-// ... and its answer: the number of candidates it listed
+// ... and its answer: the number of candidates it listed (0 with c.error set when the wait failed)
 MODLE_DEV u32 pair_take_sec_filter(Cell& c) {
-  pair_wait(c, PAIR_ALL);
+  if (!pair_wait(c, PAIR_ALL)) return 0;
   return wave::uniform(c.lds.mbox[PAIR_N_HIT]);
 }
-// main wave: waits until the helper has signalled `what` (PAIR_MOVES / PAIR_ALL) for the request
-MODLE_DEV void pair_wait(Cell& c, u32 what) {
+// main wave: waits until the helper has signalled `what` (PAIR_MOVES / PAIR_ALL) for the request.
+// false (and c.error set) when the host raised the abort word meanwhile or the helper reported an
+// error of its own (reported with PAIR_ALL): what the helper was to produce is then not there, the
+// caller leaves the epoch.
+MODLE_DEV bool pair_wait(Cell& c, u32 what) {
   const u32* m = c.lds.mbox;
-  while (wave::uniform(wave::ld_acquire_wg(&m[what])) != c.pair_seq) wave::nap();
+  u32 spins = 0;
+  while (wave::uniform(wave::ld_acquire_wg(&m[what])) != c.pair_seq) {
+    if (spin_nap_aborted(c.lds.abort_flag, spins)) {
+      c.error = ERR_CANCELLED;
+      return false;
+    }
+  }
+  // the helper's status of the request comes with PAIR_ALL (it writes the word once per request)
+  const u32 helper_error = what == PAIR_ALL ? wave::uniform(m[PAIR_ERR]) : 0u;
+  if (helper_error != 0) {
+    c.error = helper_error;
+    return false;
+  }
+  return true;
 }
 // main wave: the generator and the lists of stalling barriers come back
-MODLE_DEV void pair_take_back(Cell& c) {
-  pair_wait(c, PAIR_ALL);
+MODLE_DEV bool pair_take_back(Cell& c) {
+  if (!pair_wait(c, PAIR_ALL)) return false;
   const u32* m = c.lds.mbox;
   c.g.pos = pair_get_u64(m, PAIR_POS);
   c.g.gen_end = pair_get_u64(m, PAIR_GEN_END);
   c.n_hit[0] = wave::uniform(m[PAIR_N_HIT]);
   c.n_hit[1] = wave::uniform(m[PAIR_N_HIT + 1]);
+  return true;
 }
 // main wave, once per epoch: is there a helper to hand work to?
 MODLE_DEV bool pair_helper_present(const WaveLds& lds) {
@@ -155,8 +175,52 @@ MODLE_DEV bool pair_helper_present(const WaveLds& lds) {
 MODLE_DEV void pair_dismiss(u32* m) {
   const u32 seq = wave::uniform(m[PAIR_REQ]) + 1;
   wave::lockstep();
-  if (wave::lane() == 0) m[PAIR_N_ACTIVE] = PAIR_EXIT;
+  // (an atomic store: a main wave that gives up on a request -- the abort word -- dismisses a helper
+  // that may still be reading that request's words)
+  wave::st_release_wg(&m[PAIR_N_ACTIVE], PAIR_EXIT);
   wave::st_release_wg(&m[PAIR_REQ], seq);
+}
+// main wave of a launch that fills the slots, when it enters / leaves its task loop: an idle wave of
+// the workgroup may claim it while the word says PAIR_OPEN; on leaving the word goes back to
+// PAIR_IDLE, and a helper that had claimed it is dismissed
+MODLE_DEV void pair_open(u32* m) { wave::st_release_wg(&m[PAIR_STATE], PAIR_OPEN); }
+MODLE_DEV void pair_close(u32* m) {
+  wave::lockstep();
+  u32 leader = wave::lane();
+  wave::launder(leader);
+  u32 old = PAIR_IDLE;
+  if (leader == 0) old = wave::exchange_wg(&m[PAIR_STATE], PAIR_IDLE);
+  if (wave::bcast(old, 0) == PAIR_TAKEN) pair_dismiss(m);
+}
+// An idle wave (`self`: its index in the workgroup) looks for a main wave of its workgroup that is
+// running without a helper and claims it: returns the main wave's index or -1.  `boxes`: the
+// workgroup's hand-over words, PAIR_WORDS per wave.  `seen` = the main wave's request counter as it
+// was BEFORE the claim: the main wave posts requests (or the dismissal) only once it has seen the
+// claim, so nothing the helper must serve carries a number at or below `seen`.  Read after the
+// compare-and-swap instead, a request posted in between is taken for an old one and both waves wait
+// for ever (the race that cost a 15-minute hang in round 3: tests/protocol_model keeps it as a
+// regression case, -DMODLE_MODEL_SEEN_AFTER_CLAIM).
+MODLE_DEV int pair_claim(u32* boxes, int n_waves, int self, u32& seen) {
+  for (int w = 0; w < n_waves; ++w) {
+    u32* m = boxes + static_cast<u32>(w) * PAIR_WORDS;
+    if (w == self || wave::uniform(wave::ld_acquire_wg(&m[PAIR_STATE])) != PAIR_OPEN) continue;
+#ifndef MODLE_MODEL_SEEN_AFTER_CLAIM
+    seen = wave::uniform(wave::ld_acquire_wg(&m[PAIR_REQ]));
+#endif
+    wave::lockstep();
+    u32 leader = wave::lane();
+    wave::launder(leader);
+    u32 won = 0;
+    if (leader == 0) won = wave::cas_wg(&m[PAIR_STATE], PAIR_OPEN, PAIR_TAKEN) ? 1u : 0u;
+    if (wave::bcast(won, 0) != 0) {
+#ifdef MODLE_MODEL_SEEN_AFTER_CLAIM
+      wave::model_delay();  // (the window in which the main wave posts its first request)
+      seen = wave::uniform(wave::ld_acquire_wg(&m[PAIR_REQ]));
+#endif
+      return w;
+    }
+  }
+  return -1;
 }
 
 }  // namespace modle_dev

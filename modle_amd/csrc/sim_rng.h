@@ -137,6 +137,9 @@ struct Rng {
   u64 pos;             // uniform: stream position of the next raw to be consumed
   u32* feed;           // helper-wave mode: hand-over words of the wave that produces the blocks for
                        // this consumer (rng_take_fed_block), or nullptr: the consumer produces them
+  const u32* feed_abort;  // fed stream: the host's abort word, read while waiting for a block (or nullptr)
+  u32 feed_error;      // fed stream: non-zero once a wait for the producer was abandoned (the outputs
+                       // consumed since are not the stream's: the consumer reports the status)
 };
 // Hand-over words between a consumer of the stream and the wave that produces its blocks (u32, LDS;
 // helper-wave mode, sim_helper.h).  The producer replaces the older block of the ring once the
@@ -149,6 +152,23 @@ constexpr u32 FEED_POS = 3;      // consumer -> producer: low word of its positi
 constexpr u32 FEED_GEN_END = 4;  // low word of the end of the ring (consumer at the start, then the producer)
 constexpr u32 FEED_EXIT = 5;     // consumer -> producer, with a new session number: leave
 constexpr u32 FEED_MARGIN = 128;
+
+// Every spin loop of the hand-over protocols (this file: a consumer waiting for its producer;
+// sim_pair.h / sim_helper.h: main wave, helper, producer) is bounded by the host: a waiting wave reads
+// the abort word (host memory, one round trip over the fabric) every SPIN_POLL naps and leaves its
+// loop when the host has raised it -- modle_hip_cancel, or modle_hip_wait once its deadline has
+// passed.  A wave whose partner has stopped answering (a protocol bug) therefore costs the launch, not
+// the box.  (The reference polls `_ctx` once per epoch, simulation.cpp:933; its workers never wait
+// for each other: scheduler_simulate.cpp:264-270.)
+constexpr u32 SPIN_POLL = 1024;
+constexpr u32 ERR_CANCELLED = 4;  // the host raised the abort word (reference: _ctx polled per epoch)
+// one step of a spin loop: naps, and every SPIN_POLL steps says whether the host has raised the abort
+// word (`spins`: the loop's step counter; `abort_flag` may be nullptr: never aborted)
+MODLE_DEV bool spin_nap_aborted(const u32* abort_flag, u32& spins) {
+  wave::nap();
+  if ((++spins & (SPIN_POLL - 1)) != 0 || abort_flag == nullptr) return false;
+  return wave::uniform(wave::load_system_u32(abort_flag)) != 0;
+}
 
 MODLE_DEV u64 rotl64(u64 x, int k) { return (x << k) | (x >> (64 - k)); }
 
@@ -258,6 +278,7 @@ MODLE_DEV void philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1, u32
 MODLE_DEV void rng_take_fed_block(Rng& g) {
   u32* f = g.feed;
   wave::st_release_wg(&f[FEED_POS], static_cast<u32>(g.pos));
+  u32 spins = 0;
   for (;;) {
     const u32 fed = wave::uniform(wave::ld_acquire_wg(&f[FEED_GEN_END]));
     const u32 ahead = fed - static_cast<u32>(g.gen_end);  // (the producer is less than 2^31 outputs ahead)
@@ -265,7 +286,13 @@ MODLE_DEV void rng_take_fed_block(Rng& g) {
       g.gen_end = wave::known_uniform(g.gen_end + ahead);
       return;
     }
-    wave::nap();
+    if (g.feed_error != 0 || spin_nap_aborted(g.feed_abort, spins)) {
+      // abandoned: the consumer goes on over whatever the ring holds (every loop that draws ends
+      // with probability one on any data), nothing it computes from here on is used
+      g.feed_error = ERR_CANCELLED;
+      g.gen_end = wave::known_uniform(g.gen_end + RNG_BLOCK);
+      return;
+    }
   }
 }
 MODLE_DEV void rng_gen_block(Rng& g) {
@@ -295,6 +322,8 @@ MODLE_DEV void rng_init(Rng& g, const u64 state[4]) {
   g.gen_end = 0;
   g.pos = 0;
   g.feed = nullptr;
+  g.feed_abort = nullptr;
+  g.feed_error = 0;
   wave::sync_lds();
 }
 #else
@@ -352,6 +381,8 @@ MODLE_DEV void rng_init(Rng& g, const u64 state[4]) {
   g.gen_end = 0;
   g.pos = 0;
   g.feed = nullptr;
+  g.feed_abort = nullptr;
+  g.feed_error = 0;
   wave::sync_lds();
 }
 #endif

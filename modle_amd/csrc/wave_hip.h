@@ -154,6 +154,9 @@ MODLE_DEV void sync_lds() {
 // lane overwrites data another lane has just read.  (The emulator yields here.)
 MODLE_DEV void lockstep() { __builtin_amdgcn_wave_barrier(); }
 
+// an opaque copy of a lane-dependent value (see simulate_tasks in modle_hip.hip: keeps jump threading
+// from routing lanes around a lane-0 block along a second back edge)
+MODLE_DEV void launder(uint32_t& v) { asm volatile("" : "+v"(v)); }
 // the value has to exist in a register at this point of the program: keeps the optimizer from
 // sinking the computation that produces it (sched_fence only binds the instruction scheduler)
 MODLE_DEV void pin(uint32_t& v) { asm volatile("" : "+v"(v)); }

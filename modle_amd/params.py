@@ -91,3 +91,17 @@ class CellResult(C.Structure):
         ("sampling_events", C.c_uint64),
         ("sim_epochs", C.c_uint64),
     ]
+
+
+class LaunchInfo(C.Structure):
+    """`modle_hip_launch_info`: how the last launch was laid out on the GPU"""
+    _fields_ = [
+        ("n_tasks", C.c_uint64),
+        ("num_cus", C.c_uint64),
+        ("workgroups", C.c_uint64),
+        ("waves_per_workgroup", C.c_uint64),
+        ("main_waves_per_workgroup", C.c_uint64),
+        ("helper_waves", C.c_uint64),
+        ("prng_producer_waves", C.c_uint64),
+        ("tail_helpers", C.c_uint64),
+    ]

@@ -1,0 +1,56 @@
+"""bench.py's small helpers that do not need a GPU: the committed traffic figure is quoted only
+for the kernel it was measured on, and a missing / malformed profiles/traffic.json costs the
+`traffic` field, not the benchmark line."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+from tools.csrc_hash import csrc_sha256  # noqa: E402
+
+
+@pytest.fixture
+def fake_root(tmp_path, monkeypatch):
+    (tmp_path / "profiles").mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    # the hash is still the one of the real sources
+    monkeypatch.setattr(bench, "csrc_hash", lambda: csrc_sha256(ROOT))
+    return tmp_path
+
+
+def test_traffic_file_absent_gives_a_pair_of_nones(fake_root):
+    assert bench.measured_traffic("grch38:2048") == (None, None)
+
+
+def test_traffic_file_malformed_gives_a_pair_of_nones(fake_root):
+    (fake_root / "profiles" / "traffic.json").write_text("{ not json")
+    assert bench.measured_traffic("grch38:2048") == (None, None)
+    (fake_root / "profiles" / "traffic.json").write_text("[1, 2]")
+    assert bench.measured_traffic("grch38:2048") == (None, None)
+
+
+def test_traffic_of_another_kernel_is_not_quoted(fake_root):
+    entry = {"bytes_per_launch": 1.0e12, "source": "profiles/rXX", "kernel": "k", "csrc_sha256": "0" * 64}
+    (fake_root / "profiles" / "traffic.json").write_text(json.dumps({"grch38:2048": entry}))
+    value, source = bench.measured_traffic("grch38:2048")
+    assert value is None and source.startswith("stale")
+    entry["csrc_sha256"] = csrc_sha256(ROOT)
+    (fake_root / "profiles" / "traffic.json").write_text(json.dumps({"grch38:2048": entry}))
+    value, source = bench.measured_traffic("grch38:2048")
+    assert value == 1.0e12 and "profiles/rXX" in source
+    assert bench.measured_traffic("chr1:512") == (None, None)
+
+
+def test_launch_mode_words_follow_the_library_record():
+    one = dict(helper_waves=0, prng_producer_waves=0, tail_helpers=1)
+    assert bench.launch_mode(one) == "one wave per cell, idle waves help in the tail of the launch"
+    assert bench.launch_mode(dict(one, tail_helpers=0)) == "one wave per cell"
+    assert bench.launch_mode(dict(helper_waves=1, prng_producer_waves=1, tail_helpers=0)).startswith(
+        "main wave + helper + PRNG producer")
+    assert bench.launch_mode(dict(helper_waves=1, prng_producer_waves=0, tail_helpers=0)).startswith(
+        "main wave + helper (")

@@ -225,3 +225,21 @@ def test_records_outside_the_simulated_intervals_are_not_validated():
         genome.import_genome_text(cfg(), sizes, "chr1\t49990\t50030\tq\t9\t+\n", "chr1\t0\t50000\n")
     _, ivs, stats = genome.import_genome_text(cfg(), sizes, "chr1\t49990\t50030\tq\t0.9\t+\n", "chr1\t0\t50000\n")
     assert ivs[0]["bar_pos"].tolist() == [] and stats["barriers_imported"] == 0
+
+
+def test_record_straddling_an_interval_edge_is_left_out():
+    """Known divergence from the reference's RELEASE builds: a record that
+    overlaps an interval while its midpoint lies outside is kept there (add_extrusion_barriers only
+    asserts, genome.cpp:288-297, 470-489) and draws a barrier state per epoch; the importer leaves it
+    out, because the device layout takes barrier positions inside the interval only."""
+    sizes = "chr1\t100000\n"
+    windows = "chr1\t0\t50000\nchr1\t50000\t100000\n"
+    # midpoint (49990 + 50030 + 1) / 2 = 50010: inside the second window, outside the first although
+    # the record overlaps both; the 1-bp record on the last base has its midpoint AT the end
+    bed = "chr1\t49990\t50030\tedge\t0.9\t+\nchr1\t99999\t100000\tlast\t0.8\t-\nchr1\t10\t30\tin\t0.7\t+\n"
+    _, ivs, stats = genome.import_genome_text(cfg(), sizes, bed, windows)
+    assert [(i["start"], i["end"], i["bar_pos"].tolist()) for i in ivs] == [(0, 50000, [20]), (50000, 100000, [50010])]
+    assert stats["barriers_imported"] == 2
+    # ... and what comes out is accepted by the device path's own range check as is
+    for iv in ivs:
+        assert all(iv["start"] <= p < iv["end"] for p in iv["bar_pos"].tolist())

@@ -4,7 +4,7 @@
   shards a 2-GPU run would produce (one after the other on this GPU); the summed shard outputs
   must equal the single-rank outputs word for word.  Together with tests/test_sharding_gloo.py
   (the reduction itself, on CPU) this covers the N > 1 path without a second GPU.
-* Full-size properties (BASELINE config 1 scale: a chr1-shaped interval, 4979 LEFs, 3129
+* Full-size properties (BASELINE config 1 scale: a chr1-shaped interval, 4979 LEFs, 3518
   barriers): the oracle would need minutes per cell there, so the checks are size independent:
   the run is reproducible bit for bit, every registered contact is in the matrix or counted as
   missed, the occupancy track holds two entries per sampling event that hit the interval, and
@@ -125,7 +125,7 @@ def test_chr1_scale_properties():
     (0, 3, dict(number_of_lefs_per_mbp=64.0, lef_bar_minor_collision_pblock=0.3,
                 soft_stall_lef_stability_multiplier=2.0, num_cells=4096))])
 def test_chr1_scale_matches_oracle(oracle, skip_burnin, ncells, extra):
-    """BASELINE config 1 shape (chr1: 4979 LEFs, 3129 barriers) against the oracle, cell by cell.
+    """BASELINE config 1 shape (chr1: 4979 LEFs, 3518 barriers) against the oracle, cell by cell.
     With burn-in skipped every LEF binds in epoch 0: the ranking sorts 4979 new keys in device
     memory instead of LDS, and barrier windows / staged slices are re-staged many times."""
     from modle_amd import api, synthetic

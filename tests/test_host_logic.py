@@ -199,24 +199,3 @@ def test_sort_barriers_is_stable_and_matches_the_oracle(oracle):
     L.mo_sort_barriers(n, p3, d3, a3, i3)
     assert np.array_equal(p2, p3) and np.array_equal(d2, d3)
     assert np.array_equal(a2, a3) and np.array_equal(i2, i3)
-
-
-def test_bench_names_the_launch_mode_by_the_library_rule(monkeypatch):
-    """bench.py's `config.waves_per_cell` restates the rule of modle_hip_launch
-    (modle_amd/csrc/modle_hip.hip: fixed roles up to 4 tasks per compute unit, a PRNG producer wave
-    up to 2; above that one wave per cell with tail helpers) and its two environment switches."""
-    import bench
-
-    monkeypatch.delenv("MODLE_HIP_PAIRED", raising=False)
-    monkeypatch.delenv("MODLE_HIP_TAIL_HELPERS", raising=False)
-    assert bench.launch_mode(512).startswith("main wave + helper + PRNG producer")
-    assert bench.launch_mode(513).startswith("main wave + helper (")
-    assert bench.launch_mode(1024).startswith("main wave + helper (")
-    assert bench.launch_mode(1025) == "one wave per cell, idle waves help in the tail of the launch"
-    assert bench.launch_mode(49152) == "one wave per cell, idle waves help in the tail of the launch"
-    monkeypatch.setenv("MODLE_HIP_TAIL_HELPERS", "0")
-    assert bench.launch_mode(49152) == "one wave per cell"
-    monkeypatch.setenv("MODLE_HIP_PAIRED", "0")
-    assert bench.launch_mode(512) == "one wave per cell"
-    monkeypatch.setenv("MODLE_HIP_PAIRED", "1")
-    assert bench.launch_mode(49152).startswith("main wave + helper (")

@@ -179,6 +179,7 @@ MODLE_DEV void lockstep(int line = __builtin_LINE()) { (void)wave_emu::collectiv
 
 MODLE_DEV uint64_t clock() { return 0; }
 MODLE_DEV void pin(uint32_t&) {}
+MODLE_DEV void launder(uint32_t&) {}
 MODLE_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }
 struct LdsRow {
   uint32_t h[8];

@@ -47,6 +47,11 @@ def main():
         res["wave_cycles_waiting_fraction"] = per_launch.get("SQ_WAIT_ANY", 0.0) / wc
         res["wave_cycles_issuing_fraction"] = per_launch.get("SQ_ACTIVE_INST_ANY", 0.0) / wc
         res["wave_cycles_issue_stalled_fraction"] = per_launch.get("SQ_WAIT_INST_ANY", 0.0) / wc
+    # the device sources the counters were taken on (bench.py quotes `traffic` only while they match)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools.csrc_hash import csrc_sha256
+
+    res["csrc_sha256"] = csrc_sha256(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res, indent=1))
