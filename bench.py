@@ -81,7 +81,11 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["grch38", "chr1"], default="grch38")
+    ap.add_argument("--workload", choices=["grch38", "chr1", "grch38-dense"], default="grch38",
+                    help="grch38: BASELINE configs[2] (the headline); chr1: configs[1]; grch38-dense: configs[4], the "
+                         "collision-heavy stress (4096 cells, 64 LEFs/Mb, minor-collision trials, soft stalls) -- "
+                         "with one GPU the shard of rank 0 of 8 (512 cells of every chromosome), which is what one "
+                         "GPU of the 8-GPU node runs")
     ap.add_argument("--chrom", default=None,
                     help="diagnostic: restrict the grch38 workload to one chromosome (e.g. chr21)")
     ap.add_argument("--cells", type=int, default=None, help="cells per GPU (weak scaling)")
@@ -221,11 +225,23 @@ def main():
                 t.copy_(h)
 
     default_cells = 2048 if args.workload == "grch38" else 512
+    cfg_overrides = {}
+    plan_rank, plan_world = rank, world
+    if args.workload == "grch38-dense":
+        # BASELINE configs[4] is an 8-GPU job with a fixed number of cells: always strong scaling;
+        # a single GPU runs the shard of rank 0 of 8 (tests/test_gpu_baseline_configs.py checks
+        # exactly that launch against the oracle)
+        args.scaling = "strong"
+        args.total_cells = args.total_cells or 4096
+        cfg_overrides = dict(number_of_lefs_per_mbp=64.0, lef_bar_minor_collision_pblock=0.3,
+                             soft_stall_lef_stability_multiplier=2.0)
+        if world == 1:
+            plan_rank, plan_world = 0, 8
     if args.scaling == "strong":
         total_cells = args.total_cells or default_cells
         if total_cells < world:
             raise SystemExit("--total-cells must be at least the number of GPUs")
-        cells_per_gpu = -(-total_cells // world)  # largest shard
+        cells_per_gpu = -(-total_cells // plan_world)  # largest shard
         cells_txt = f"{total_cells} cells in total (strong scaling)"
     else:
         cells_per_gpu = args.cells or default_cells
@@ -241,14 +257,21 @@ def main():
                     f"count per chromosome), "
                     f"{cells_txt}, reference defaults (BASELINE configs[2]/[3])")
         unit = "genome-cells/s"
+    elif args.workload == "grch38-dense":
+        genome = synthetic.grch38_like(seed=42)
+        workload = (f"GRCh38-shaped genome, collision-heavy stress (BASELINE configs[4]): {cells_txt}, 64 LEFs/Mb, "
+                    f"lef_bar_minor_collision_pblock 0.3, soft_stall_lef_stability_multiplier 2"
+                    + (f"; this GPU runs the shard of rank 0 of 8 ({cells_per_gpu} cells of every chromosome)"
+                       if world == 1 else ""))
+        unit = "genome-cells/s"
     else:
         genome = synthetic.grch38_like(seed=42, chroms={"chr1"})
         workload = (f"chr1-shaped interval (248 956 422 bp, {len(genome[0]['bar_pos'])} synthetic barriers), "
                     f"{cells_txt}, reference defaults (BASELINE configs[1])")
         unit = "chr1-cells/s"
-    cfg = api.make_config(num_cells=total_cells, seed=0)
+    cfg = api.make_config(num_cells=total_cells, seed=0, **cfg_overrides)
 
-    plan = driver.plan_genome(cfg, genome, rank, world)
+    plan = driver.plan_genome(cfg, genome, plan_rank, plan_world)
     # outputs live in torch tensors so that RCCL can reduce them in place
     buffers, tensors = [], []
     for entry in plan:
@@ -394,6 +417,21 @@ def main():
         job_epochs, job_tasks = int(tot[0].item()), int(tot[1].item())
     else:
         job_epochs, job_tasks = epochs, n_tasks
+    # the kernel time of every rank (the longest shard bounds the job: a real multi-GPU run shows its
+    # imbalance here)
+    kernel_ms_per_rank = None
+    if use_dist:
+        import torch.distributed as dist
+
+        mine = torch.tensor([avg_kernel_s * 1e3 if avg_kernel_s else float("nan")], dtype=torch.float64,
+                            device=coll_dev)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        kernel_ms_per_rank = [float(g.item()) for g in gathered]
+        kernel_ms_per_rank = [x if math.isfinite(x) else None for x in kernel_ms_per_rank]
+    # cells the job simulated per step: all of them, except where one GPU stands for one rank of a
+    # larger job (grch38-dense on a single GPU: its shard only)
+    job_cells = total_cells if plan_world == world else cells_per_gpu
 
     if rank == 0 and args.checksum_out:
         sums = {}
@@ -412,12 +450,14 @@ def main():
 
     if rank == 0:
         traffic_bytes, traffic_source = measured_traffic(f"{args.workload}:{cells_per_gpu}")
+        if args.workload == "grch38-dense" and args.cpu_sample_cells is None:
+            args.cpu_sample_cells = max(2, usable_cores())  # (a dense cell costs several default ones)
         out = {
             "metric": "simulated cells/sec (whole node), GRCh38 default barriers"
                       + (" [PHILOX generator policy: statistically equivalent output, not the "
                          "reference's stream]" if args.rng == "philox" else ""),
             "rng": args.rng,
-            "value": total_cells * args.steps / dt,
+            "value": job_cells * args.steps / dt,
             "unit": unit,
             "n_gpus": world,
             "steps": args.steps,
@@ -446,6 +486,7 @@ def main():
                          "traffic": traffic_bytes, "traffic_source": traffic_source,
                          "kernel": "modle_simulate_cells",
                          "kernel_ms": avg_kernel_s * 1e3 if avg_kernel_s else None,
+                         "kernel_ms_per_rank": kernel_ms_per_rank,
                          "algorithmic_bytes_per_launch": step_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -202,6 +202,8 @@ def test_bench_runs_under_torch_distributed_run_with_one_rank(tmp_path):
     d = json.loads(line)
     assert d["checked"] is True and d["n_gpus"] == 1 and d["value"] > 0
     assert d["check"]["tasks"] == 24 * 16 and "side stream" in d["config"]["parallelism"]
+    # the kernel time of every rank goes with the line (a real multi-GPU run shows its imbalance there)
+    assert len(d["roofline"]["kernel_ms_per_rank"]) == 1 and d["roofline"]["kernel_ms_per_rank"][0] > 0
 
 
 def _bench(tmp_path, nproc, port, extra):
@@ -244,3 +246,5 @@ def test_bench_with_two_real_ranks_reduces_to_the_single_rank_matrices(tmp_path)
     # whole-job counters are sums over the ranks
     assert two["check"]["tasks"] == 24 * 12  # rank 0's shard
     assert round(two["tasks_per_s"] * two["ms_per_step"] / 1e3) == 24 * 24
+    assert len(two["roofline"]["kernel_ms_per_rank"]) == 2 and all(x > 0 for x in two["roofline"]["kernel_ms_per_rank"])
+    assert one["roofline"]["kernel_ms_per_rank"] is None

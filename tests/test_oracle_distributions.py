@@ -90,3 +90,44 @@ def test_ziggurat_tables_match_generator():
     assert "0x1.b8a8c1f45f8c2p+1" in regenerated or float.fromhex("0x1.b8a8c1f45f8c2p+1")
     x1 = 3.4426198558966521214
     assert math.isclose(math.exp(-x1 * x1 / 2), 0.0026696290839025035, rel_tol=1e-15)
+
+
+def test_boost_draw_vectors_when_present(oracle):
+    """Closes "parity unpinned" for the Boost.Random restatement WHERE BOOST BUILDS:
+    tools/boost_draw_vectors.cpp (plain C++ + Boost 1.88, the reference's pin) prints the first 10 000
+    draws of every distribution of the path at the reference's call-site parameters, for the two
+    seeds of its seed-dependent tests, with the number of engine outputs consumed; this test replays
+    them on the oracle.  The image has no Boost, so the file is absent here and the test skips
+    (INTEGRATION.md section 4 names the one command that produces it)."""
+    import json
+    import os
+    import struct
+
+    import pytest
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "boost_draws.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/boost_draws.json is not here: run tools/boost_draw_vectors.cpp where Boost builds")
+    with open(path) as f:
+        doc = json.load(f)
+    L = oracle.lib()
+    L.mo_normal.restype = C.c_double
+    L.mo_canonical.restype = C.c_double
+    bits = lambda x: struct.unpack("<Q", struct.pack("<d", x))[0]
+    draw = {
+        "normal": lambda g, p: bits(L.mo_normal(C.byref(g), C.c_double(p["mean"]), C.c_double(p["sigma"]))),
+        "poisson": lambda g, p: int(L.mo_poisson(C.byref(g), C.c_double(p["mean"]))),
+        "binomial": lambda g, p: int(L.mo_binomial(C.byref(g), C.c_int64(p["t"]), C.c_double(p["p"]))),
+        "uniform_int": lambda g, p: int(L.mo_uniform_int(C.byref(g), C.c_uint64(p["lo"]), C.c_uint64(p["hi"]))),
+        "canonical": lambda g, p: bits(L.mo_canonical(C.byref(g))),
+        "bernoulli": lambda g, p: int(L.mo_bernoulli(C.byref(g), C.c_double(p["p"]))),
+    }
+    assert len(doc["entries"]) == 20
+    for e in doc["entries"]:
+        g = oracle.prng_from_seed(e["seed"])
+        start = g.count
+        got = [draw[e["distribution"]](g, e["params"]) for _ in range(len(e["values"]))]
+        what = f"{e['distribution']} {e['params']} seed {e['seed']} (Boost {doc['boost_version']})"
+        first_bad = next((i for i, (a, b) in enumerate(zip(got, e["values"])) if a != b), None)
+        assert first_bad is None, f"{what}: draw {first_bad} differs"
+        assert g.count - start == e["engine_outputs_consumed"], f"{what}: engine outputs consumed"
