@@ -411,7 +411,8 @@ MODLE_DEV void rank_finish(Cell& c, bool ties, const u32* where, u32 t_lo, u32 t
 // of the previous epoch, which has the new positions in registers anyway, has marked them and
 // listed their keys (a separate sweep over positions and marks used to find them here).
 // Returns false -- nothing committed, the caller runs the general update -- when the keys do not
-// fit the LDS buffers.
+// fit the LDS buffers (RANK_KEY_CAP keys, the sort buffer less the sentinel; 256 when the chromosome
+// has 65536 LEFs or more and the per-key counts need 32 bits).
 template <bool FWD>
 MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
   Workspace& ws = c.ws;
@@ -422,7 +423,17 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
   const u32* ids = FWD ? ws.f_id : ws.r_id;
   const u32* marks = FWD ? ws.f_move : ws.r_move;
   u64* keys = c.lds.sort_lds;
-  u32* cnt_lds = c.lds.stage;
+  // per key: the number of carried-over units that go before it.  16-bit entries (twice as many keys
+  // in the 1 KB staging buffer: the collision-heavy configurations re-insert several hundred units
+  // per epoch) whenever the counts fit, i.e. on every real chromosome; 32-bit entries otherwise
+  u32* cnt32 = c.lds.stage;
+  u16* cnt16 = reinterpret_cast<u16*>(c.lds.stage);
+  const bool narrow_cnt = n < 65536u;
+  const u32 key_cap = narrow_cnt ? RANK_KEY_CAP : STAGE_CAP;
+  const auto cnt_store = [&](u32 q, u32 v) {
+    if (narrow_cnt) cnt16[q] = static_cast<u16>(v); else cnt32[q] = v;
+  };
+  const auto cnt_load = [&](u32 q) -> u32 { return narrow_cnt ? static_cast<u32>(cnt16[q]) : cnt32[q]; };
   const u64* src = reinterpret_cast<const u64*>(FWD ? ws.tmp[4] : ws.tmp[2]);
   u32* out_pos = ws.tmp[0];
   u32* out_id = ws.tmp[1];
@@ -445,19 +456,22 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
       const bool still = e < nd && wave::ld_sel(marks, static_cast<u32>(kv), e < nd, 0u) == DISP_MARK;
       const u64 dm = wave::ballot(still);
       const u32 j = n_new + static_cast<u32>(wave::popc64(dm & lanemask_lt(lane)));
-      if (still && j < STAGE_CAP) keys[j] = kv;
+      if (still && j < key_cap) keys[j] = kv;
       n_new += static_cast<u32>(wave::popc64(dm));
     }
   }
-  if (n_new > STAGE_CAP) return false;
+  if (n_new > key_cap) return false;
+#ifdef MODLE_EMU_TRACE_RANK  // (emulator only: which regime a test exercises)
+  if (lane == 0) fprintf(stderr, "rank_update_listed: n_new %u (listed %u) of %u, key_cap %u\n", n_new, n_listed, n, key_cap);
+#endif
   const u32 n_old = n - n_new;
   const u32 m2 = n_new != 0 ? pow2_ceil(n_new) : 0;
   for (u32 k = n_new + lane; k < m2; k += 64) keys[k] = ~u64(0);
   // (a key of all ones behind the last one, also when n_new is a power of two: a step of the
   // searches below that overshoots reads it, through one `v_min` on the index, instead of testing
-  // its range; n_new <= STAGE_CAP < SORT_LDS_CAP)
+  // its range; n_new <= RANK_KEY_CAP < SORT_LDS_CAP)
   if (lane == 0) keys[n_new] = ~u64(0);
-  for (u32 j = lane; j < n_new; j += 64) cnt_lds[j] = n_old;
+  for (u32 j = lane; j < n_new; j += 64) cnt_store(j, n_old);
   wave::sync_lds();
   if (m2 > 1) bitonic_sort_u64<true>(keys, m2);
 
@@ -589,7 +603,7 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
           // key at the position of either neighbour is flagged for the final ordering
           const u32 a = slot[j] - lo[j];
           for (u32 q = lo_prev[j]; q < lo[j]; ++q) {
-            cnt_lds[q] = a;
+            cnt_store(q, a);
             const u32 kp = static_cast<u32>(keys[q] >> 32);
             if (kp != UNBOUND && (kp == pp[j] || (a > 0 && kp == excl[j]))) {
               tie = true;
@@ -631,7 +645,7 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
     if (bq < n_new) {
       const u64 key = keys[bq];
       const u32 pp = static_cast<u32>(key >> 32);
-      const u32 lo = cnt_lds[bq];
+      const u32 lo = cnt_load(bq);
       const u32 nid = ids[static_cast<u32>(key)];  // the slot the unit was bound in
       wave::st_stream(&out_pos[bq + lo], pp);
       wave::st_stream(&out_id[bq + lo], nid);
@@ -642,7 +656,7 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
     }
     if (wave::any(tie)) {
       ties = true;
-      const u32 slot = bq < n_new ? bq + cnt_lds[bq < n_new ? bq : 0] : 0;
+      const u32 slot = bq < n_new ? bq + cnt_load(bq < n_new ? bq : 0) : 0;
       t_lo = umin(t_lo, ~wave::bcast(wave_prefix_max_u32(tie ? ~slot : 0u), 63));
       t_hi = umax(t_hi, wave::bcast(wave_prefix_max_u32(tie ? slot : 0u), 63));
     }
@@ -659,7 +673,7 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
   const u32 n = wave::uniform(c.n_active);
   if (n < 2) return;
   {
-    const bool listed = !all_new && c.keys_valid && c.disp_valid && c.n_keys <= STAGE_CAP;
+    const bool listed = !all_new && c.keys_valid && c.disp_valid && c.n_keys <= RANK_KEY_CAP;
     if (listed && rank_update_listed<FWD>(c)) {
       if (FWD) c.keys_valid = false;  // (the keys serve the rev update, then the fwd update)
       return;

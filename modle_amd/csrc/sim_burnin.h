@@ -50,6 +50,10 @@ MODLE_DEV LoopStats loop_size_stats(Cell& c) {
       if (k < n) {
         by_id_fwd[g.fI[u]] = g.fP[u];
         by_id_rev[g.rI[u]] = g.rP[u];
+#ifdef MODLE_EXP_DOUBLE_SCATTER  // (measurement: what the two scattered stores per LEF cost -- a second pair, same pattern, dead arrays)
+        ws.tmp[8][g.fI[u]] = g.fP[u];
+        ws.tmp[9][g.rI[u]] = g.rP[u];
+#endif
         part += static_cast<u64>(g.fP[u]) - static_cast<u64>(g.rP[u]);
       }
     }

@@ -84,6 +84,10 @@ struct Cell {
   } while (0)
 #endif
 constexpr u32 REL_CAP = 2 * SORT_LDS_CAP;  // u32 entries in the LDS sort buffer
+// units the one-sweep rank update (rank_update_listed) can re-insert per epoch and direction: the keys
+// of the LDS sort buffer less one sentinel.  (Round 4: was STAGE_CAP = 256, which BASELINE configs[4]
+// -- 64 LEFs/Mb: 250-430 LEFs released per epoch on the large chromosomes -- exceeded in every epoch.)
+constexpr u32 RANK_KEY_CAP = SORT_LDS_CAP - 1;
 constexpr u32 ERR_LIST_OVERFLOW = 1;
 constexpr u32 ERR_TRIAL_OVERFLOW = 2;
 constexpr u32 ERR_INTERNAL = 3;

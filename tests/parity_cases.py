@@ -65,6 +65,12 @@ CASES = {
     "mass_release": dict(size=120_000_000, barriers=True,
                          cfg=dict(num_cells=4, skip_burnin=1, avg_lef_processivity=8000,
                                   target_contact_density=0.0004)),
+    # 300-450 LEFs released and bound again per epoch (1 300 LEFs at a processivity of 25 kb): more keys
+    # than the one-sweep rank update held before round 4 (256), within what it holds now (511, 16-bit
+    # per-key counts): the regime of BASELINE configs[4] on the large chromosomes
+    "many_rebinds_per_epoch": dict(size=65_000_000, barriers=True,
+                                   cfg=dict(num_cells=4, skip_burnin=1, avg_lef_processivity=25000,
+                                            target_contact_density=0.004)),
     # more LEFs than the LDS id filters have bits (32768): ids that share a bit pass the filters
     # together -- the release candidates' and the partner lookups' sweeps then store a few ranks
     # nobody asked for, and nothing else may change
