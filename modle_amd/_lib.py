@@ -36,6 +36,36 @@ u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
 _lib = None
 
 
+def _share_the_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so (same soname as the
+    system's) and loads it by path; libmodle_hip.so names the runtime by soname.  Whichever of the two
+    initialises second in a process that holds both copies finds no device (seen on the MI355X
+    boxes: `import torch` after this library -> "No HIP GPUs are available", this library after
+    torch's own load-by-path -> "no HIP device available").  When torch is installed its copy is
+    therefore loaded FIRST, globally, so that this library's dependency resolves to it by soname and
+    a later `import torch` finds its runtime already in place.  No torch import happens here;
+    MODLE_HIP_OWN_RUNTIME=1 keeps the system's runtime (processes that never load torch)."""
+    if os.environ.get("MODLE_HIP_OWN_RUNTIME", "") not in ("", "0"):
+        return
+    try:
+        with open("/proc/self/maps") as f:
+            if "libamdhip64" in f.read():
+                return  # a runtime is already loaded: the dynamic linker will reuse it by soname
+    except OSError:
+        pass
+    import importlib.util
+
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    bundled = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        try:
+            C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass  # (the system's runtime then serves this library alone)
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -44,6 +74,7 @@ def lib():
         raise ImportError(
             f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc, gfx950). modle_amd has no CPU fallback.")
+    _share_the_hip_runtime_with_torch()
     L = C.CDLL(SO_PATH)
     P = C.POINTER
     err = [C.c_char_p, C.c_size_t]

@@ -9,7 +9,7 @@ namespace modle_dev {
 struct LoopStats {
   f64 avg, std;  // stats::mean / stats::standard_dev of the loop sizes (population std)
 };
-MODLE_DEV LoopStats loop_size_stats(Cell& c) {
+MODLE_DEV LoopStats loop_size_stats_scattered(Cell& c) {
   // reference: simulation.cpp:795-819 and stats/descriptive_impl.hpp:22-31, 63-101.  The mean is
   // a sum of integers below 2^53 (order independent); the squared deviations are accumulated
   // strictly left to right in LEF-id order like std::accumulate.
@@ -112,6 +112,175 @@ MODLE_DEV LoopStats loop_size_stats(Cell& c) {
     }
   }
   return LoopStats{avg, wave::f_sqrt(ssd / static_cast<f64>(n))};
+}
+
+// Folds 64 consecutive terms (lane l holds term l; lanes past the end hold +0.0, which leaves the
+// non-negative running sum unchanged) into `ssd`, strictly in lane order like std::accumulate.  The
+// terms go through LDS: every lane reads them back in order (one address for the whole wave: a
+// broadcast) and keeps its own copy of the running sum -- two lane broadcasts per term plus the wait
+// states between a broadcast and the addition that uses it had been two thirds of the chain.
+// `buf`: 64 doubles of the staging buffer (LDS operations of one wave execute in order: the reads of
+// one call are performed before the writes of the next).
+MODLE_DEV f64 fold_terms_in_lane_order(f64 ssd, f64 term, f64* buf) {
+  wave::lockstep();
+  buf[wave::lane()] = term;
+  wave::sync_lds();
+#pragma unroll
+  for (u32 l = 0; l < 64; ++l) ssd = ssd + buf[l];
+  return ssd;
+}
+
+// The same statistics without scattering 4-byte stores over device memory (round 4).  The two
+// id-ordered scatters of loop_size_stats_scattered -- one store per unit into a random line -- were
+// the most expensive memory traffic of the kernel: a second pair of them cost 8.3 % of the launch
+// (profiles/r04c).  Here the id order is restored in two steps:
+//   A. one sweep over the units in rank order (coalesced 128-bit loads of positions and ids)
+//      PARTITIONS them by windows of STATS_WINDOW consecutive LEF ids: a unit appends
+//      (position, id within the window) to its window's region of a pair array -- every id occurs
+//      once per direction, so window b's region is exactly entries [b W, b W + W); the next free
+//      entry of every region is a counter in LDS (one returning LDS add per unit).  A wave store
+//      then writes a few runs of consecutive 8-byte entries instead of 64 unrelated lines;
+//   B. per window the pairs are read back (coalesced) and dropped at their id's slot of two arrays
+//      in LDS (the sort buffer: W rev positions, W fwd positions), and the window is folded in id
+//      order.
+// The mean needs all positions first: step A sums them.  Step B needs the LDS sort buffer: the
+// epoch loop computes the statistics behind the bind phase, when the list of released LEFs has
+// been consumed (a LEF bound in between has both units at one position: loop size 0, exactly what
+// it counted for while it was unbound).  Pair arrays: ws.sort_keys (rev) and ws.tmp[8..9] (fwd: two
+// arrays that lie next to each other and hold the dead moves of the previous epoch).
+constexpr u32 STATS_WINDOW = SORT_LDS_CAP;  // ids per window: two 32-bit slots each in the sort buffer
+constexpr u32 STATS_MAX_WINDOWS = STAGE_CAP / 2;  // region counters (rev, fwd) in the staging buffer
+constexpr u32 STATS_WINDOW_LOG2 = STATS_WINDOW == 512 ? 9 : STATS_WINDOW == 256 ? 8 : 0;
+static_assert((u32(1) << STATS_WINDOW_LOG2) == STATS_WINDOW, "the window must be a power of two");
+MODLE_DEV LoopStats loop_size_stats_partitioned(Cell& c, u64* pairs_r, u64* pairs_f) {
+  Workspace& ws = c.ws;
+  const u32 n = wave::uniform(c.n_active);
+  const u32 lane = wave::lane();
+  const u32 nblk = (n + 255) / 256;
+  const u32 nwin = (n + STATS_WINDOW - 1) / STATS_WINDOW;
+  u32* cursor = c.lds.stage;  // [0, nwin): rev regions, [nwin, 2 nwin): fwd regions
+  wave::lockstep();
+  for (u32 k = lane; k < 2 * nwin; k += 64) cursor[k] = 0;
+  wave::sync_lds();
+  // A. partition
+  struct Blk {
+    wave::U32x4 rP, rI, fP, fI;
+  };
+  const auto load_blk = [&](u32 t, Blk& r) {
+    const u32 w = 256 * t + 4 * lane;
+    const u32 wq = w < n ? w : 0u;
+    r.rP = wave::ld4(ws.r_pos, wq);
+    r.rI = wave::ld4(ws.r_id, wq);
+    r.fP = wave::ld4(ws.f_pos, wq);
+    r.fI = wave::ld4(ws.f_id, wq);
+  };
+  u64 part = 0;
+#ifdef MODLE_SUBTIMER_STATS
+  const u64 t_part = wave::clock();
+#endif
+  Blk cur;
+  load_blk(0, cur);
+  for (u32 t = 0; t < nblk; ++t) {
+    const Blk g = cur;
+    if (t + 1 < nblk) load_blk(t + 1, cur);
+    const u32 w = 256 * t + 4 * lane;
+    u32 er[4], ef[4];  // entry of the unit in its window's region
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+      er[q] = 0;
+      ef[q] = 0;
+      if (w + q < n) {
+        er[q] = wave::lds_fetch_add_u32(&cursor[g.rI.v[q] >> STATS_WINDOW_LOG2], 1u);
+        ef[q] = wave::lds_fetch_add_u32(&cursor[nwin + (g.fI.v[q] >> STATS_WINDOW_LOG2)], 1u);
+      }
+    }
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+      if (w + q < n) {
+        const u32 ri = g.rI.v[q], fi = g.fI.v[q];
+        pairs_r[(ri & ~(STATS_WINDOW - 1)) + er[q]] = (static_cast<u64>(ri & (STATS_WINDOW - 1)) << 32) | g.rP.v[q];
+        pairs_f[(fi & ~(STATS_WINDOW - 1)) + ef[q]] = (static_cast<u64>(fi & (STATS_WINDOW - 1)) << 32) | g.fP.v[q];
+        part += static_cast<u64>(g.fP.v[q]) - static_cast<u64>(g.rP.v[q]);
+      }
+    }
+  }
+  wave::sync_mem();
+#pragma unroll
+  for (u32 s = 1; s < 64; s <<= 1) {
+    const u64 o = wave::shfl_down(part, s);
+    if (lane + s < 64) part += o;
+  }
+  const f64 avg = static_cast<f64>(wave::bcast(part, 0)) / static_cast<f64>(n);
+#ifdef MODLE_SUBTIMER_STATS
+  c.ph[14] += wave::clock() - t_part;  // (the partition sweep)
+#endif
+  // B. per window: pairs -> LDS slots by id, then the fold in id order
+  u32* slot_r = reinterpret_cast<u32*>(c.lds.sort_lds);
+  u32* slot_f = slot_r + STATS_WINDOW;
+  f64* terms = reinterpret_cast<f64*>(c.lds.stage);
+  f64 ssd = 0.0;
+  constexpr u32 UX = STATS_WINDOW / 64;  // loads of one window, all in flight
+  struct PairRegs {
+    u64 r[UX], f[UX];
+  };
+  const auto load_pairs = [&](u32 b, PairRegs& p) {
+    const u32 lo = b * STATS_WINDOW;
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 e = lo + 64 * u + lane;
+      p.r[u] = wave::LdRaw{}(pairs_r, e, e < n, u64(0), u64(0));
+      p.f[u] = wave::LdRaw{}(pairs_f, e, e < n, u64(0), u64(0));
+    }
+  };
+  PairRegs pcur;
+  load_pairs(0, pcur);
+  for (u32 b = 0; b < nwin; ++b) {
+    const PairRegs pg = pcur;
+    if (b + 1 < nwin) load_pairs(b + 1, pcur);  // (in flight during this window's fold)
+    const u32 lo = b * STATS_WINDOW;
+    const u32 cnt = umin(STATS_WINDOW, n - lo);
+    wave::lockstep();  // (the fold of the previous window has read its slots)
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      if (64 * u + lane < cnt) {
+        slot_r[static_cast<u32>(pg.r[u] >> 32)] = static_cast<u32>(pg.r[u]);
+        slot_f[static_cast<u32>(pg.f[u] >> 32)] = static_cast<u32>(pg.f[u]);
+      }
+    }
+    wave::sync_lds();
+#ifdef MODLE_SUBTIMER_STATS
+    const u64 t_fold = wave::clock();
+#endif
+    for (u32 base = 0; base < cnt; base += 64) {
+      const u32 i = base + lane;
+      f64 term = 0.0;
+      if (i < cnt) {
+        const u32 ls = slot_f[i] - slot_r[i];
+        const f64 d = static_cast<f64>(static_cast<u64>(ls)) - avg;
+        term = d * d;
+      }
+      ssd = fold_terms_in_lane_order(ssd, term, terms);
+    }
+#ifdef MODLE_SUBTIMER_STATS
+    c.ph[15] += wave::clock() - t_fold;  // (the fold alone)
+#endif
+  }
+  return LoopStats{avg, wave::f_sqrt(ssd / static_cast<f64>(n))};
+}
+
+MODLE_DEV LoopStats loop_size_stats(Cell& c) {
+  const u32 n = wave::uniform(c.n_active);
+  // the fwd pairs live in two scratch arrays that must lie next to each other (the workspace is
+  // carved that way: sim_types.h / modle_hip.hip device_carve; only tmp[0], tmp[1] and tmp[7] ever
+  // trade places with other arrays)
+  const i64 stride = (static_cast<i64>(c.ws.capacity_lefs) + 63) & ~i64(63);
+  const bool adjacent = wave::uniform(static_cast<i64>(c.ws.tmp[9] - c.ws.tmp[8])) == stride;
+#ifdef MODLE_EMU_TRACE_RANK  // (emulator only: which form a test exercises)
+  if (wave::lane() == 0) fprintf(stderr, "loop_size_stats: n %u, %s\n", n, (n <= STATS_MAX_WINDOWS * STATS_WINDOW && adjacent) ? "partitioned" : "scattered");
+#endif
+  if (n <= STATS_MAX_WINDOWS * STATS_WINDOW && adjacent)
+    return loop_size_stats_partitioned(c, c.ws.sort_keys, reinterpret_cast<u64*>(c.ws.tmp[8]));
+  return loop_size_stats_scattered(c);
 }
 
 MODLE_DEV_NOINLINE void compute_loop_size_stats(Cell& c) {

@@ -64,7 +64,10 @@ struct Cell {
 };
 // (slot 14: LEF activation; a sub-phase measurement may claim slots 14 and 15 and sends the
 // activation time to slot 1 with the bind phase)
-#ifdef MODLE_SUBTIMER_LEFBAR
+#if defined(MODLE_SUBTIMER_LEFBAR) || defined(MODLE_SUBTIMER_STATS)
+#define MODLE_SUBTIMER 1
+#endif
+#ifdef MODLE_SUBTIMER
 #define MODLE_PH_ACTIVATION 1
 #else
 #define MODLE_PH_ACTIVATION 14

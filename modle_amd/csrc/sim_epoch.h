@@ -245,8 +245,13 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
       status = ERR_CANCELLED;
       break;
     }
+    // run_burnin (reference: simulation.cpp:866-894).  The loop-size statistics and the stability
+    // test of an epoch run BEHIND the bind phase: they draw nothing, a LEF bound in between counts
+    // exactly as it did while it was unbound (both units at one position: loop size 0), and behind the
+    // bind phase the LDS sort buffer no longer holds the list of released LEFs, so the statistics can
+    // restore the LEF-id order there instead of scattering to device memory (sim_burnin.h).
+    bool stats_due = false;
     if (!burnin_completed) {
-      // run_burnin (reference: simulation.cpp:866-894)
       do {
         ++num_burnin_epochs;
         if (c.n_active != c.n_lefs) {
@@ -254,12 +259,7 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
                 const u64 na = static_cast<u64>(c.n_active) + k;
                 activate_lefs(c, c.n_active, na < c.n_lefs ? static_cast<u32>(na) : c.n_lefs));
         } else {
-          PHASE(c, 0, compute_loop_size_stats(c); burnin_completed = evaluate_burnin(c));
-          burnin_completed = burnin_completed && epoch > p.min_burnin_epochs;
-          if (!burnin_completed && epoch >= p.max_burnin_epochs) {
-            burnin_completed = true;
-            activate_lefs(c, c.n_active, c.n_lefs);
-          }
+          stats_due = true;  // (every LEF is active: the loop ends here)
         }
       } while (c.n_active == 0);
     }
@@ -268,6 +268,14 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
             phase_bind(c, static_cast<u32>(epoch));
             c.n_bound = c.n_active;
           });
+    if (stats_due) {
+      PHASE(c, 0, compute_loop_size_stats(c); burnin_completed = evaluate_burnin(c));
+      burnin_completed = burnin_completed && epoch > p.min_burnin_epochs;
+      if (!burnin_completed && epoch >= p.max_burnin_epochs) {
+        burnin_completed = true;
+        activate_lefs(c, c.n_active, c.n_lefs);
+      }
+    }
     trace_stage(c, epoch, 0);
     // helper-wave mode (sim_pair.h), burn-in epochs (nothing draws between the bind phase and the
     // moves): the helper draws the moves and the barrier states while this wave ranks the units
@@ -329,7 +337,7 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
 
   trace_stage(c, epoch, 6);
 #ifdef MODLE_PHASE_TIMERS
-#ifndef MODLE_SUBTIMER_LEFBAR
+#ifndef MODLE_SUBTIMER
   c.ph[15] = wave::clock() - t_cell;  // (the whole cell: what the phases do not add up to is the glue between them)
 #endif
   if (lds.phase_ticks != nullptr && wave::lane() == 0) {

@@ -207,14 +207,18 @@ MODLE_DEV u32 run_test_units(const Params& p, const Interval& iv, const Workspac
   init_cell(c, p, ivg, ws, lds, n, zero);
   c.n_active = n;
   if (what == UNIT_LOOP_STATS) {
-    // pairs (rev position, fwd position) of LEF i; identity ranking
+    // pairs (rev position, fwd position) of LEF i.  The units sit at scrambled ranks (rev: reversed;
+    // fwd: a stride permutation), as they do in a cell: the statistics must restore the id order
+    const u32 stride = n % 7919u != 0 ? 7919u : 1u;  // (7919 is prime: a bijection modulo n)
     for (u32 base = 0; base < n; base += 64) {
       const u32 k = base + lane;
       if (k < n) {
-        c.ws.r_pos[k] = static_cast<u32>(in[2 * k]);
-        c.ws.f_pos[k] = static_cast<u32>(in[2 * k + 1]);
-        c.ws.r_id[k] = k;
-        c.ws.f_id[k] = k;
+        const u32 ir = n - 1 - k;
+        const u32 jf = static_cast<u32>((static_cast<u64>(k) * stride + 13u) % n);
+        c.ws.r_pos[k] = static_cast<u32>(in[2 * ir]);
+        c.ws.r_id[k] = ir;
+        c.ws.f_pos[k] = static_cast<u32>(in[2 * jf + 1]);
+        c.ws.f_id[k] = jf;
       }
     }
     wave::sync_mem();

@@ -299,6 +299,11 @@ MODLE_DEV void atomic_add_u64(uint64_t* p, uint64_t v) {
   atomicAdd(reinterpret_cast<unsigned long long*>(p), static_cast<unsigned long long>(v));
 }
 MODLE_DEV uint32_t atomic_fetch_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+// returns *p and adds v to it, on a word in LDS that other lanes of the wave may be adding to as well
+// (ds_add_rtn_u32: the adds of one wave instruction to one word are performed one after the other)
+MODLE_DEV uint32_t lds_fetch_add_u32(uint32_t* p, uint32_t v) {
+  return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
 // *p |= v on a word in LDS that other lanes of the wave may be updating too (ds_or_b32)
 MODLE_DEV void lds_or_u32(uint32_t* p, uint32_t v) {
   __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);

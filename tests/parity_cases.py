@@ -65,6 +65,11 @@ CASES = {
     "mass_release": dict(size=120_000_000, barriers=True,
                          cfg=dict(num_cells=4, skip_burnin=1, avg_lef_processivity=8000,
                                   target_contact_density=0.0004)),
+    # 2 200 LEFs with a burn-in (ended by --max-burnin-epochs after ~75 evaluations of the loop-size
+    # statistics): the statistics restore the LEF-id order in LDS in windows of 1 024 ids (round 4) --
+    # here two full windows and a partial one, the fold running across their borders
+    "burnin_three_windows": dict(size=110_000_000, barriers=True,
+                                 cfg=dict(num_cells=2048, max_burnin_epochs=260)),
     # 300-450 LEFs released and bound again per epoch (1 300 LEFs at a processivity of 25 kb): more keys
     # than the one-sweep rank update held before round 4 (256), within what it holds now (511, 16-bit
     # per-key counts): the regime of BASELINE configs[4] on the large chromosomes

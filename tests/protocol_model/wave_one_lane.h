@@ -115,6 +115,11 @@ MODLE_DEV void model_delay() {
 MODLE_DEV void atomic_inc_u32(uint32_t* p) { __atomic_fetch_add(p, 1u, __ATOMIC_RELAXED); }
 MODLE_DEV void atomic_add_u64(uint64_t* p, uint64_t v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 MODLE_DEV uint32_t atomic_fetch_add_u32(uint32_t* p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+MODLE_DEV uint32_t lds_fetch_add_u32(uint32_t* p, uint32_t v) {  // (lanes run one at a time)
+  const uint32_t old = *p;
+  *p = old + v;
+  return old;
+}
 MODLE_DEV void lds_or_u32(uint32_t* p, uint32_t v) { *p |= v; }
 
 MODLE_DEV double f_log(double x) { return mm_log(x); }

@@ -13,7 +13,8 @@ from parity_cases import assert_same_outputs, assert_same_results, build_case
                                          ("window_near_position_limit", 1),
                                          ("dense_barriers_trials", 1),
                                          ("ultra_dense_barriers_trials", 1), ("mass_release", 1),
-                                         ("many_lefs_hashed_filters", 1), ("many_rebinds_per_epoch", 1)])
+                                         ("many_lefs_hashed_filters", 1), ("many_rebinds_per_epoch", 1),
+                                         ("burnin_three_windows", 1)])
 def test_emulated_device_code_matches_oracle(oracle, name, ncells):
     case = build_case(name)
     cfg, chrom = case["cfg"], case["chrom"]

@@ -13,7 +13,8 @@ NCELLS = {"config0_5mb_nobarriers": 64, "chr20mb_barriers": 96, "chr12mb_dense_s
           "chr8mb_loop_only": 64, "chr6mb_skip_burnin": 64, "tiny_single_lef": 8,
           "zero_target_cells": 128, "epochs_stop_tad_only": 16, "window_near_position_limit": 64,
           "dense_barriers_trials": 8, "ultra_dense_barriers_trials": 4, "mass_release": 4,
-          "many_lefs_hashed_filters": 2, "many_rebinds_per_epoch": 4}
+          "many_lefs_hashed_filters": 2, "many_rebinds_per_epoch": 4,
+          "burnin_three_windows": 12}
 
 
 @pytest.mark.parametrize("name", list(CASES))

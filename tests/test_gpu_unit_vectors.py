@@ -53,7 +53,7 @@ def test_reference_unit_vector_on_gpu(oracle, gpu_backend, group, v):
 def test_loop_stats_bit_identical_on_random_loops_gpu(oracle, gpu_backend):
     rng = np.random.default_rng(9)
     be_o = OracleUnits(oracle)
-    for n in (1, 2, 63, 64, 65, 300, 1000, 4979):
+    for n in (1, 2, 63, 64, 65, 300, 511, 512, 513, 1000, 4979, 15920, 70000):  # (> 65536: the scattering form)
         rev = rng.integers(1, 200_000_000, size=n).astype(np.uint64)
         fwd = rev + rng.integers(0, 3_000_000, size=n).astype(np.uint64)
         a, b = be_o.loop_stats(rev, fwd), gpu_backend.loop_stats(rev, fwd)

@@ -60,7 +60,7 @@ def test_loop_stats_bit_identical_on_random_loops(oracle):
     burn-in statistics of random loop-size sets (sequential fp64 accumulation)"""
     rng = np.random.default_rng(9)
     be_o, be_d = OracleUnits(oracle), _emu_backend(oracle)
-    for n in (1, 2, 63, 64, 65, 300, 1000):
+    for n in (1, 2, 63, 64, 65, 300, 511, 512, 513, 1000, 4979, 70000):  # (> 65536: the scattering form)
         rev = rng.integers(1, 200_000_000, size=n).astype(np.uint64)
         fwd = rev + rng.integers(0, 3_000_000, size=n).astype(np.uint64)
         a, b = be_o.loop_stats(rev, fwd), be_d.loop_stats(rev, fwd)
