@@ -27,26 +27,27 @@ MODLE_DEV_NOINLINE void barriers_init_states(Cell& c) {
   wave::sync_mem();
 }
 
-// LEF-BAR detection without Bernoulli trials (both blocking probabilities in {0, 1}) works on
-// the barriers that stall a unit, compacted in position order: list 0 as the rev units see
-// them, list 1 as the fwd units do.  A barrier is on a list iff it is active and the blocking
-// probability that applies to it there is 1.
-MODLE_DEV bool stalling_lists_wanted(const Params& p) {
-  return (p.pblock_major == 1.0 || p.pblock_major == 0.0) &&
-         (p.pblock_minor == 1.0 || p.pblock_minor == 0.0);
+// LEF-BAR detection works on the barriers that CAN stall a unit, compacted in position order: list 0
+// as the rev units see them, list 1 as the fwd units do.  A barrier is on a list iff it is active
+// and the blocking probability that applies to it there is not zero; an entry whose probability is
+// below one costs a Bernoulli trial when a unit reaches it (lef_bar_trials_needed: round 4 -- the
+// lists used to exist only when both probabilities were 0 or 1, and every other configuration,
+// BASELINE configs[4] among them, searched the complete barrier set per unit).
+MODLE_DEV bool lef_bar_trials_needed(const Params& p) {
+  return !((p.pblock_major == 1.0 || p.pblock_major == 0.0) && (p.pblock_minor == 1.0 || p.pblock_minor == 0.0));
 }
-constexpr u32 HITBAR_HARD = 0x80000000u;
+constexpr u32 HITBAR_HARD = 0x80000000u;  // the barrier blocks the direction of the list's units (the major probability applies)
 
 // appends the barriers of one batch (index i per lane, `on`: active) to the two lists; uniform
-// (major_hits / minor_hits: the blocking probability of that kind is 1 -- worked out once by the
+// (major_in / minor_in: the blocking probability of that kind is not zero -- worked out once by the
 // caller: a Params field read inside the loop comes back as a sixteen-register reload per batch)
 MODLE_DEV void stalling_lists_append(Cell& c, u32 i, bool in, bool on, u32 bpos, u32 bdir,
-                                     bool major_hits, bool minor_hits) {
+                                     bool major_in, bool minor_in) {
   const u32 lane = wave::lane();
 #pragma unroll
   for (u32 d = 0; d < 2; ++d) {
     const bool is_major = bdir == (d == 0 ? DIR_REV : DIR_FWD);
-    const bool hit = in && on && (is_major ? major_hits : minor_hits);
+    const bool hit = in && on && (is_major ? major_in : minor_in);
     const u64 hm = wave::ballot(hit);
     if (hit) {
       const u32 slot = c.n_hit[d] + static_cast<u32>(wave::popc64(hm & lanemask_lt(lane)));
@@ -65,12 +66,12 @@ MODLE_DEV_NOINLINE void compact_stalling_barriers(Cell& c) {
   const u32 lane = wave::lane();
   c.n_hit[0] = 0;
   c.n_hit[1] = 0;
-  const bool major_hits = wave::uniform(c.p->pblock_major == 1.0), minor_hits = wave::uniform(c.p->pblock_minor == 1.0);
+  const bool major_in = wave::uniform(c.p->pblock_major != 0.0), minor_in = wave::uniform(c.p->pblock_minor != 0.0);
   for (u32 base = 0; base < nb; base += 64) {
     const u32 i = base + lane;
     const bool in = i < nb;
     stalling_lists_append(c, i, in, in && c.ws.bar_active[i] != 0, in ? iv.bar_pos[i] : 0,
-                          in ? iv.bar_dir[i] : 0, major_hits, minor_hits);
+                          in ? iv.bar_dir[i] : 0, major_in, minor_in);
   }
   wave::sync_mem();
 }
@@ -79,8 +80,8 @@ MODLE_DEV_NOINLINE void barriers_next_state(Cell& c) {
   const Interval& iv = *c.iv;
   const u32 nb = wave::uniform(iv.n_barriers);
   const u32 lane = wave::lane();
-  const bool lists = stalling_lists_wanted(*c.p);
-  const bool major_hits = wave::uniform(c.p->pblock_major == 1.0), minor_hits = wave::uniform(c.p->pblock_minor == 1.0);
+  constexpr bool lists = true;
+  const bool major_in = wave::uniform(c.p->pblock_major != 0.0), minor_in = wave::uniform(c.p->pblock_minor != 0.0);
   c.n_hit[0] = 0;
   c.n_hit[1] = 0;
   constexpr u32 UX = 4;  // batches per group; the next group's loads go before this group's stores
@@ -128,7 +129,7 @@ MODLE_DEV_NOINLINE void barriers_next_state(Cell& c) {
         }
       }
       rng_advance(c.g, cnt);
-      if (lists) stalling_lists_append(c, i, i < nb, st != 0, g.P[u], g.D[u], major_hits, minor_hits);
+      stalling_lists_append(c, i, i < nb, st != 0, g.P[u], g.D[u], major_in, minor_in);
     }
   }
   wave::sync_mem();

@@ -78,15 +78,23 @@ MODLE_DEV_NOINLINE BoundaryCounts detect_boundaries(Cell& c) {
 // of rank j-1 and itself that lie within its move.  Bernoulli trials (pblock not in {0,1}) are
 // numbered in the reference's order: barriers ascending for rev units, descending for fwd units.
 //
-// The barriers a batch of 64 consecutive ranks can touch form one index range that continues
-// where the previous batch stopped.  A window of BAR_WIN barriers (position and a flag word:
-// state, blocking direction) is staged in LDS with one coalesced load and all per-unit searches
-// run there; a batch whose units need more than the window falls back to device memory.
-// The window lives in the LDS sort buffer (idle during the collision passes): BAR_WIN positions
-// followed by BAR_WIN flag words.  It is re-staged only when a batch starts closer than BAR_NEED
-// barriers to its far edge.
+// Only active barriers whose blocking probability is not zero can stall a unit: they are compacted
+// once per epoch, in position order, into one list per direction (sim_barriers.h: position,
+// index | HITBAR_HARD), and a window of BAR_WIN list entries is staged in LDS (the sort buffer, idle
+// during the collision passes) and moved along the list as the ranks advance.  Unit windows are
+// disjoint and ordered like the ranks, so every block of units continues the search where the
+// previous one stopped; a block whose windows do not fit the staged entries searches the list in
+// device memory.
+//   * Blocking probabilities in {0, 1} (the reference default: major 1, minor 0): no trial is drawn,
+//     every entry stalls, and of the entries in a unit's window the reference keeps the one it visits
+//     last -- the highest for a rev unit, the lowest for a fwd unit: one search and one test per unit.
+//   * Otherwise (BASELINE configs[4]: minor 0.3) the same sweep only LISTS the units whose window
+//     holds an entry -- a few per cent of them -- and a second pass takes 64 listed units at a time:
+//     window ends, trials numbered by a prefix sum in list order = draw order, outcomes, the entry
+//     visited last among the hits.  (Round 4.  Before, every configuration with a fractional
+//     probability searched the complete barrier set per unit, one rank per lane, and counted and
+//     drew in two per-lane loops over every barrier of the window: 30 % of a configs[4] launch.)
 constexpr u32 BAR_WIN = SORT_LDS_CAP;  // SORT_LDS_CAP u64 keys = 2 * BAR_WIN words
-constexpr u32 BAR_NEED = 128;
 
 // Position of the barrier that stalls the unit of rank k (valid where the collision word says
 // LEF-BAR), written by detect_lef_bar for the passes that correct moves.  Lives in ranking
@@ -96,6 +104,34 @@ MODLE_DEV u32* stalling_barrier_positions(const Workspace& ws) {
   return FWD ? ws.tmp[4] : ws.tmp[3];
 }
 
+constexpr u32 HITBAR_NEAR = 127;
+
+// Copies `cnt` (<= BAR_WIN) list entries into the LDS window: all loads in flight, then the LDS
+// writes.  A real call: it runs a few times per pass and its registers stay out of the pass's
+// allocation.
+MODLE_DEV_CALL void stage_stalling_window_call(MODLE_LDS u32* cp, MODLE_LDS u32* ci,
+                                               const u32* hpos, const u32* hidx, u32 cnt) {
+  const u32 lane = wave::lane();
+  const u32* gp = wave::as_global(hpos);
+  const u32* gi = wave::as_global(hidx);
+  u32 Hp[BAR_WIN / 64], Hi[BAR_WIN / 64];
+#pragma unroll
+  for (u32 t = 0; t < BAR_WIN / 64; ++t) {
+    const u32 e = lane + 64 * t;
+    Hp[t] = e < cnt ? gp[e] : 0;
+    Hi[t] = e < cnt ? gi[e] : 0;
+  }
+#pragma unroll
+  for (u32 t = 0; t < BAR_WIN / 64; ++t) {
+    const u32 e = lane + 64 * t;
+    if (e < cnt) {
+      cp[e] = Hp[t];
+      ci[e] = Hi[t];
+    }
+  }
+}  // entries next to the anchor that the fixed-step search covers
+
+constexpr u32 BAR_NEED = 128;
 // Barriers [s0, s1) are staged.  STAGED_ONLY accessors assume the index is inside the staged
 // range (the caller has checked that the whole batch stays inside); the general ones read
 // everything else from device memory.
@@ -180,19 +216,7 @@ MODLE_DEV void lef_bar_window(const BarView& v, u32 nb, u32 anchor, u64 lo_key, 
   }
 }
 
-// Bernoulli trials of one unit: how many it consumes (count_only) or which barrier stalls it
-template <bool FWD, bool STAGED_ONLY>
-MODLE_DEV u32 lef_bar_count_trials(const BarView& v, const Params& p, u32 b_lo, u32 b_hi) {
-  const u32 major_dir = FWD ? DIR_FWD : DIR_REV;
-  u32 ntr = 0;
-  for (u32 b = b_lo; b < b_hi; ++b) {
-    const u32 fl = v.flag<STAGED_ONLY>(b);
-    const f64 pb = (fl >> 1) == major_dir ? p.pblock_major : p.pblock_minor;
-    ntr += ((fl & 1u) && pb != 1.0 && pb != 0.0) ? 1u : 0u;
-  }
-  return ntr;
-}
-
+// the barrier that stalls one unit, among barriers [b_lo, b_hi) of a view (no trials on this path)
 template <bool FWD, bool STAGED_ONLY>
 MODLE_DEV u32 lef_bar_pick(const BarView& v, const Params& p, const Rng& g, u32 b_lo, u32 b_hi,
                            u32 trial_off, bool& hard, u32& bpos) {
@@ -222,46 +246,9 @@ MODLE_DEV u32 lef_bar_pick(const BarView& v, const Params& p, const Rng& g, u32 
   return winner;
 }
 
-// ---------------------------------------------------------------------------------------------
-// detect_lef_bar_collisions when both blocking probabilities are 0 or 1 (the reference default:
-// major 1, minor 0): no Bernoulli trial is drawn and a barrier stalls a unit iff it is active
-// and the probability that applies to its direction is 1.  Of the barriers in a unit's window the
-// reference keeps the one it visits last: the highest such barrier for a rev unit, the lowest
-// for a fwd unit.  The stalling barriers are therefore compacted (position, index | hard << 31)
-// into the LDS window, in ascending order, and a unit needs one search there and one test.
-//
-// The compacted window holds every stalling barrier with index in [s0, s1); it serves any unit
-// window [lo, hi) with lo >= lo_cover and hi <= hi_cover.  Unit windows are disjoint and ordered
-// like the ranks, so every batch continues the search where the previous one stopped; a batch
-// whose windows do not fit is looked up in device memory.
-// ---------------------------------------------------------------------------------------------
-constexpr u32 HITBAR_NEAR = 127;
-
-// Copies `cnt` (<= BAR_WIN) list entries into the LDS window: all loads in flight, then the LDS
-// writes.  A real call: it runs a few times per pass and its registers stay out of the pass's
-// allocation.
-MODLE_DEV_CALL void stage_stalling_window_call(MODLE_LDS u32* cp, MODLE_LDS u32* ci,
-                                               const u32* hpos, const u32* hidx, u32 cnt) {
-  const u32 lane = wave::lane();
-  const u32* gp = wave::as_global(hpos);
-  const u32* gi = wave::as_global(hidx);
-  u32 Hp[BAR_WIN / 64], Hi[BAR_WIN / 64];
-#pragma unroll
-  for (u32 t = 0; t < BAR_WIN / 64; ++t) {
-    const u32 e = lane + 64 * t;
-    Hp[t] = e < cnt ? gp[e] : 0;
-    Hi[t] = e < cnt ? gi[e] : 0;
-  }
-#pragma unroll
-  for (u32 t = 0; t < BAR_WIN / 64; ++t) {
-    const u32 e = lane + 64 * t;
-    if (e < cnt) {
-      cp[e] = Hp[t];
-      ci[e] = Hi[t];
-    }
-  }
-}  // entries next to the anchor that the fixed-step search covers
-
+// ---- blocking probabilities in {0, 1}: the sweep of rounds 2-3, unchanged (the headline path) ----
+// (its fall-back for a block that spans more list entries than the window holds searches the
+// complete barrier set through a BarView: a few units spread over a chromosome, early burn-in)
 template <bool FWD>
 MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
   Workspace& ws = c.ws;
@@ -592,215 +579,517 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
   wave::sync_mem();
 }
 
-template <bool FWD>
-MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
+
+// ---- fractional blocking probabilities ----
+// One sweep over the units of a direction (rank order), four consecutive ranks per lane: finds for
+// every unit the list entry its window ends at.  TRIALS = false: no probability needs a Bernoulli
+// trial, the entry at the end of a non-empty window is the one the reference keeps, the collision
+// word is written on the spot.  TRIALS = true: the units with a non-empty window are LISTED (rank,
+// list entry at the near end of the window, key of its far end) in sweep order = the reference's
+// draw order, for resolve_listed_units below; returns their number.
+template <bool FWD, bool TRIALS>
+MODLE_DEV_NOINLINE u32 detect_lef_bar_sweep(Cell& c, BoundaryCounts bc) {
   Workspace& ws = c.ws;
-  const Interval& iv = *c.iv;
-  const Params& p = *c.p;
   const u32 n = wave::uniform(c.n_active);
-  const u32 nb = wave::uniform(iv.n_barriers);
-  if (nb == 0) return;
   const u32 lane = wave::lane();
   const u32* pos = FWD ? ws.f_pos : ws.r_pos;
   const u32* moves = FWD ? ws.f_move : ws.r_move;
   u32* coll = FWD ? ws.f_coll : ws.r_coll;
-  const bool trials = !((p.pblock_major == 1.0 || p.pblock_major == 0.0) &&
-                        (p.pblock_minor == 1.0 || p.pblock_minor == 0.0));
-  if (!trials) {
-    detect_lef_bar_det<FWD>(c, bc);
-    return;
-  }
   u32* barpos = stalling_barrier_positions<FWD>(ws);
-  u32* st_pos = reinterpret_cast<u32*>(c.lds.sort_lds);
-  u32* st_flag = st_pos + BAR_WIN;
-  // first / last rank that takes part
+  // positions of the compacted barriers and their indices (| HITBAR_HARD): at most BAR_FILL entries,
+  // with a sentinel next to them so that the fixed-step searches need no range test -- rev: a word
+  // of all ones behind the last entry (cp[cnt]; a step that overshoots reads it through one
+  // `v_min` on the index); fwd: a zero in front of the first entry (the window starts one word into
+  // the buffer; a step that undershoots reads cp[-1] through one `v_max`)
+  constexpr u32 BAR_FILL = BAR_WIN - 1;
+  u32* cp = reinterpret_cast<u32*>(c.lds.sort_lds) + (FWD ? 1 : 0);
+  u32* ci = cp + BAR_WIN;
   const u32 j_rev0 = bc.n5 == 0 ? 0 : bc.n5 - 1;
   const u32 j_fwd0 = bc.n3 == 0 ? n - 1 : n - bc.n3;
-  u32 carry_pos = 0;  // position of the neighbouring unit processed by the previous batch
-  u32 anchor = 0;     // rev: first barrier index the next batch can need; fwd: one past the last
-  BarView v;
-  v.iv = &iv;
-  v.active = ws.bar_active;
-  v.st_pos = st_pos;
-  v.st_flag = st_flag;
-  v.s0 = 0;
-  v.s1 = 0;  // nothing staged yet
-  bool located = false;
-  const u32 nbatch = (n + 63) / 64;
-  constexpr u32 UX = 4;  // batches whose loads are in flight together
-  for (u32 bg = 0; bg < nbatch; bg += UX) {
-    u32 Pq[UX], Mq[UX];
+  u32 carry_pos = 0;
+  const u32 nh = wave::uniform(c.n_hit[FWD ? 1 : 0]);
+  if (nh == 0 || n == 0) return 0;  // no barrier can stall a unit of this direction in this epoch
+  // TRIALS: the listed units (ws.tmp[0]: rank, tmp[1]: list entry, tmp[2]: key; all three idle here)
+  u32* const unit_rank = ws.tmp[0];
+  u32* const unit_entry = ws.tmp[1];
+  u32* const unit_key = ws.tmp[2];
+  u32 n_listed = 0;
+  const u32* hpos = ws.hit_pos[FWD ? 1 : 0];
+  const u32* hidx = ws.hit_idx[FWD ? 1 : 0];
+  constexpr u32 c0 = 0;
+  u32 g0 = 0, g1 = 0, cnt = 0;      // the window holds list entries [g0, g1): cp[0 .. cnt)
+  bool staged = false;
+  u32 lo_cover = 1, hi_cover = 0;   // nothing staged yet (0xFFFFFFFF: no bound)
+  u32 anchor = 0;                   // rev: entries below it lie before the batch; fwd: entries at
+                                    // or above it lie beyond the batch (relative to c0)
+  // Four consecutive ranks per lane, blocks of 256 ranks on 256-rank boundaries (128-bit loads);
+  // rev: ranks ascending from j_rev0, fwd: ranks descending from j_fwd0 (lane 0 holds the highest
+  // ranks of a block and walks its four units downwards).  Ranks outside the sweep are masked.
+  const u32 b_first = (FWD ? j_fwd0 : j_rev0) / 256;
+  const u32 nblk = FWD ? b_first + 1 : (n + 255) / 256 - b_first;
+  const auto word0 = [&](u32 t) { return (FWD ? b_first - t : b_first + t) * 256 + 4 * (FWD ? 63 - lane : lane); };
+  struct Blk {
+    wave::U32x4 P, M;
+  };
+  const auto load_blk = [&](u32 t, Blk& r) {
+    const u32 w = word0(t);
+    const u32 wq = w < n ? w : 0u;
+    r.P = wave::ld4(pos, wq);
+    r.M = wave::ld4(moves, wq);
+  };
+  Blk cur;
+  load_blk(0, cur);
+  for (u32 t = 0; t < nblk; ++t) {
+    const Blk g = cur;
+    if (t + 1 < nblk) load_blk(t + 1, cur);
+    const u32 w = word0(t);
+    u32 k[4], P[4], lo_key[4], hi_key[4];
+    bool bnd[4];
 #pragma unroll
-    for (u32 u = 0; u < UX; ++u) {
-      // rev: ranks ascending; fwd: ranks descending, lane 0 = highest rank of the batch
-      const i64 kk = FWD ? static_cast<i64>(j_fwd0) - static_cast<i64>(bg + u) * 64 - lane
-                         : static_cast<i64>(j_rev0) + static_cast<i64>(bg + u) * 64 + lane;
-      const bool act = kk >= 0 && kk < static_cast<i64>(n);
-      Pq[u] = wave::ld_sel(pos, static_cast<u32>(kk), act, 0);
-      Mq[u] = wave::ld_sel(moves, static_cast<u32>(kk), act, 0);
+    for (u32 j = 0; j < 4; ++j) {  // j: position in sweep order inside the lane
+      const u32 q = FWD ? 3 - j : j;
+      k[j] = w + q;
+      const bool act = FWD ? k[j] <= j_fwd0 : (k[j] >= j_rev0 && k[j] < n);
+      P[j] = act ? g.P.v[q] : 0u;
+      bnd[j] = act && P[j] != UNBOUND;
     }
+    const u32 nbr_in = wave::shfl_up1(P[3]);
+    const u32 nbr0 = lane > 0 ? nbr_in : carry_pos;
+    carry_pos = wave::bcast(P[3], 63);
 #pragma unroll
-    for (u32 u = 0; u < UX; ++u) {
-      const u32 bi = bg + u;
-      const i64 kk = FWD ? static_cast<i64>(j_fwd0) - static_cast<i64>(bi) * 64 - lane
-                         : static_cast<i64>(j_rev0) + static_cast<i64>(bi) * 64 + lane;
-      const bool act = kk >= 0 && kk < static_cast<i64>(n);
-      if (!wave::any(act)) break;
-      const u32 k = act ? static_cast<u32>(kk) : 0;
-      const u32 P = Pq[u];
-      const u32 M = Mq[u];
-      const bool bnd = act && P != UNBOUND;
-      // neighbour towards which the barriers are shadowed (rank k-1 for rev, k+1 for fwd)
-      const u32 nbr_in = wave::shfl_up1(P);
-      const bool first = (bi == 0 && lane == 0);
-      const u32 nbr = lane > 0 ? nbr_in : carry_pos;
-      // the unit can be stalled by barriers with lo_key <= position < hi_key
-      u64 lo_key = 0, hi_key = 0;
-      if (bnd) {
+    for (u32 j = 0; j < 4; ++j) {
+      const u32 q = FWD ? 3 - j : j;
+      const u32 M = g.M.v[q];
+      const bool first = k[j] == (FWD ? j_fwd0 : j_rev0);
+      const u32 nbr = j == 0 ? nbr0 : P[j - 1];
+      // see detect_lef_bar; 32-bit keys: positions lie below 2^32 - 2 (the host rejects longer
+      // intervals), and a reach beyond that is as good as 2^32 - 2
+      // (units that take no part: keys no window entry compares with -- nothing lies below 0,
+      // nothing at or above 2^32 - 1)
+      lo_key[j] = FWD ? 0xFFFFFFFFu : 0u;
+      hi_key[j] = 0;
+      if (bnd[j]) {
         if (!FWD) {
-          // prev <= bpos < P and P - bpos <= M
-          const u32 reach = P - M;  // M <= P - start after clamping
-          lo_key = first ? reach : umax(reach, nbr);
-          hi_key = P;
+          const u32 reach = P[j] - M;
+          lo_key[j] = first ? reach : umax(reach, nbr);
+          hi_key[j] = P[j];
         } else {
-          // P < bpos <= next and bpos - P <= M
-          const u64 reach = static_cast<u64>(P) + M;
-          lo_key = static_cast<u64>(P) + 1;
-          hi_key = (first ? reach : umin64(reach, nbr)) + 1;
+          const u32 sum = P[j] + M;
+          const u32 reach = (sum < P[j] || sum > 0xFFFFFFFEu) ? 0xFFFFFFFEu : sum;
+          lo_key[j] = P[j] + 1;
+          hi_key[j] = (first ? reach : umin(reach, nbr)) + 1;
         }
       }
-      const u64 bm = wave::ballot(bnd);
-      carry_pos = wave::bcast(P, 63);
-      if (bm == 0) continue;
-      // the first batch with a bound unit locates the window through the bucket table; later
-      // batches continue where the previous one stopped
-      if (!located) {
-        const u32 l0 = static_cast<u32>(wave::ctz64(bm));
-        const u64 key = FWD ? wave::bcast(hi_key, l0) : wave::bcast(lo_key, l0);
-        anchor = wave::uniform(bar_lower_bound(iv, key));
-        located = true;
-      }
-      const bool restage = FWD ? (v.s1 == 0 || (anchor < v.s0 + BAR_NEED && v.s0 > 0) || anchor > v.s1)
-                               : (v.s1 == 0 || (anchor + BAR_NEED > v.s1 && v.s1 < nb) || anchor < v.s0);
-      if (restage) {
-        if (!FWD) {
-          v.s0 = anchor;
-          v.s1 = umin(anchor + BAR_WIN, nb);
-        } else {
-          v.s1 = anchor;
-          v.s0 = anchor > BAR_WIN ? anchor - BAR_WIN : 0;
-        }
-        wave::lockstep();
-        for (u32 t = lane; t < BAR_WIN; t += 64) {
-          const u32 b = v.s0 + t;
-          if (b < v.s1) {
-            st_pos[t] = iv.bar_pos[b];
-            st_flag[t] =
-                static_cast<u32>(ws.bar_active[b] != 0) | (static_cast<u32>(iv.bar_dir[b]) << 1);
+    }
+    const u64 bm = wave::ballot(bnd[0] || bnd[1] || bnd[2] || bnd[3]);
+    if (bm == 0) continue;
+    const u32 l_first = static_cast<u32>(wave::ctz64(bm));
+    const u32 l_last = static_cast<u32>(63 - wave::clz64(bm));
+    // keys of the lane's first / last bound unit in sweep order
+    const u32 jf = bnd[0] ? 0u : bnd[1] ? 1u : bnd[2] ? 2u : 3u;
+    const u32 jl = bnd[3] ? 3u : bnd[2] ? 2u : bnd[1] ? 1u : 0u;
+    const u32 lo_f = jf == 0 ? lo_key[0] : jf == 1 ? lo_key[1] : jf == 2 ? lo_key[2] : lo_key[3];
+    const u32 hi_f = jf == 0 ? hi_key[0] : jf == 1 ? hi_key[1] : jf == 2 ? hi_key[2] : hi_key[3];
+    const u32 lo_l = jl == 3 ? lo_key[3] : jl == 2 ? lo_key[2] : jl == 1 ? lo_key[1] : lo_key[0];
+    const u32 hi_l = jl == 3 ? hi_key[3] : jl == 2 ? hi_key[2] : jl == 1 ? hi_key[1] : hi_key[0];
+    // keys the block spans (sweep order holds ascending positions for rev, descending for fwd)
+    const u32 need_lo = FWD ? wave::bcast(lo_l, l_last) : wave::bcast(lo_f, l_first);
+    const u32 need_hi = FWD ? wave::bcast(hi_f, l_first) : wave::bcast(hi_l, l_last);
+#ifdef MODLE_SUBTIMER_LEFBAR
+    const u64 t_stage = wave::clock();
+#endif
+    if (need_lo < lo_cover || need_hi > hi_cover) {
+      // Move the window along the list to where this block starts (one coalesced load of
+      // positions and indices).  Entries the window has already passed are dropped by counting;
+      // when the block lies beyond the whole window, the window keeps moving.
+      u32 moved = 0;
+      for (;;) {
+        if (staged) {
+          // window entries before the block (rev: below need_lo; fwd: below need_hi)
+          const u32 key = FWD ? need_hi : need_lo;
+          u32 below = 0;
+#pragma unroll
+          for (u32 e0 = 0; e0 < BAR_WIN / 64; ++e0) {
+            const u32 e = lane + 64 * e0;
+            const u32 ce = cp[e];  // (e < BAR_WIN: inside the window whatever cnt is)
+            below += static_cast<u32>(wave::popc64(wave::ballot((e < cnt) & (ce < key))));
           }
+          if (!FWD) {
+            g0 += below;
+          } else {
+            g1 = g0 + below;
+          }
+        } else {
+          if (FWD) g1 = nh; else g0 = 0;
+        }
+        if (!FWD) {
+          g1 = umin(g0 + BAR_FILL, nh);
+        } else {
+          g0 = g1 > BAR_FILL ? g1 - BAR_FILL : 0;
+        }
+        cnt = g1 - g0;
+        wave::lockstep();
+        {
+          // what the window does not hold: everything before it lies below lo_cover,
+          // everything after it at or above hi_cover
+          const u32 edge_lo = g0 > 0 ? hpos[g0 - 1] : 0;
+          const u32 edge_hi = g1 < nh ? hpos[g1] : 0;
+          stage_stalling_window_call((MODLE_LDS u32*)cp, (MODLE_LDS u32*)ci, hpos + g0, hidx + g0, cnt);
+          if (lane == 0) {
+            if (FWD) cp[-1] = 0u; else cp[cnt] = 0xFFFFFFFFu;  // (the sentinel of the searches)
+          }
+          lo_cover = g0 > 0 ? wave::uniform(edge_lo) + 1 : 0;
+          hi_cover = g1 < nh ? wave::uniform(edge_hi) : 0xFFFFFFFFu;
         }
         wave::sync_lds();
+        staged = true;
+        anchor = FWD ? cnt : 0;
+        // done unless the block starts beyond this window and the list goes on
+        const bool beyond = FWD ? (need_hi <= lo_cover && g0 > 0) : (need_lo >= hi_cover && g1 < nh);
+        if (!beyond || ++moved > 64) break;  // (a block that is still not covered is looked up in device memory)
       }
-      // windows of barrier indices [b_lo, b_hi): in LDS when every unit of the batch stays inside
-      // the staged range, otherwise through the general accessors
-      u32 b_lo = 0, b_hi = 0;
-      bool edge = false;
-      if (bnd) lef_bar_window<FWD, true>(v, nb, anchor, lo_key, hi_key, b_lo, b_hi, edge);
-      const bool staged_only = !wave::any(edge);
-      if (!staged_only) {
-        b_lo = 0;
-        b_hi = 0;
-        if (bnd) lef_bar_window<FWD, false>(v, nb, anchor, lo_key, hi_key, b_lo, b_hi, edge);
-      }
-      // number of Bernoulli trials this unit consumes
-      u32 ntr = 0;
-      if (trials) {
-        ntr = staged_only ? lef_bar_count_trials<FWD, true>(v, p, b_lo, b_hi)
-                          : lef_bar_count_trials<FWD, false>(v, p, b_lo, b_hi);
-      }
-      u32 off = 0, total = 0;
-      if (trials) {
-        // exclusive prefix sum of ntr over lanes
-        off = wave_prefix_sum_u32(ntr);
-        total = wave::bcast(off, 63);
-        off -= ntr;
-      }
-      bool hard = false;
-      u32 bpos = 0;
-      u32 winner = 0xFFFFFFFFu;
-      if (total <= RNG_BLOCK) {
-        if (total != 0) rng_ensure(c.g, total);
-        winner = staged_only ? lef_bar_pick<FWD, true>(v, p, c.g, b_lo, b_hi, off, hard, bpos)
-                             : lef_bar_pick<FWD, false>(v, p, c.g, b_lo, b_hi, off, hard, bpos);
-        rng_advance(c.g, total);
+    }
+#ifdef MODLE_SUBTIMER_LEFBAR
+    c.ph[14] += wave::clock() - t_stage;
+    const u64 t_search = wave::clock();
+#endif
+    // per unit: the list entry at the near end of its window (rev: one past the last entry below the
+    // unit; fwd: the first entry above it), when the window holds an entry at all
+    u32 entry[4];
+    bool has[4];
+    u32 winner[4], bpos[4];  // (!TRIALS: the stalling barrier and its position)
+    bool hard[4];
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j) {
+      entry[j] = 0;
+      has[j] = false;
+      winner[j] = 0xFFFFFFFFu;
+      bpos[j] = 0;
+      hard[j] = false;
+    }
+    if (need_lo >= lo_cover && need_hi <= hi_cover) {
+      // four searches side by side, all from the anchor the previous block left
+      u32 q[4];
+#pragma unroll
+      for (u32 j = 0; j < 4; ++j) q[j] = anchor;
+      if (!FWD) {
+        // q = number of entries before the unit: the last of them is the candidate
+#pragma unroll
+        for (u32 sft = 64; sft >= 1; sft >>= 1) {
+          // (the four reads of a round are issued together: left alone the compiler waits for each)
+          u32 jx[4], kv[4];
+#pragma unroll
+          for (u32 j = 0; j < 4; ++j) {
+            jx[j] = q[j] + sft;
+            kv[j] = (cp - 1)[umin(jx[j], cnt + 1)];  // (beyond the window: the sentinel)
+          }
+          wave::sched_fence();
+#pragma unroll
+          for (u32 j = 0; j < 4; ++j) {
+            if (kv[j] < hi_key[j]) q[j] = jx[j];
+          }
+          wave::sched_fence();
+        }
+        bool far = false;  // the fixed steps ran out: finish with a binary search (rare)
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) far = far || (bnd[j] && q[j] == anchor + HITBAR_NEAR && q[j] < cnt);
+        if (wave::any(far)) {
+#pragma unroll
+          for (u32 j = 0; j < 4; ++j) {
+            if (bnd[j] && q[j] == anchor + HITBAR_NEAR && q[j] < cnt) {
+              u32 hi = cnt;
+              u32 l = q[j];
+              while (l < hi) {
+                const u32 mid = (l + hi) >> 1;
+                if (cp[c0 + mid] < hi_key[j]) l = mid + 1; else hi = mid;
+              }
+              q[j] = l;
+            }
+          }
+        }
+        // the candidates of the four units: position and index read together, then tested
+        u32 bp[4], wd[4];
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          const u32 e = c0 + (q[j] > 0 ? q[j] - 1 : 0);
+          bp[j] = cp[e];
+          wd[j] = ci[e];
+        }
+        wave::sched_fence();
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          if (bnd[j] & (q[j] > 0) & (bp[j] >= lo_key[j])) {
+            has[j] = true;
+            entry[j] = g0 + q[j];
+            winner[j] = wd[j] & ~HITBAR_HARD;
+            hard[j] = (wd[j] & HITBAR_HARD) != 0;
+            bpos[j] = bp[j];
+          }
+        }
       } else {
-        // More Bernoulli trials in this batch than one block of the PRNG ring serves (dense
-        // barrier annotations with a fractional blocking probability): the lanes are resolved in
-        // rounds, each taking the longest run of lanes (in lane = stream order) whose trials fit
-        // one block; a single unit with more trials than that is replayed sequentially.
-        u64 pend = wave::ballot(bnd);
-        u32 base_tr = 0;  // trials consumed by the lanes resolved so far
-        while (pend != 0) {
-          const bool mine_pending = ((pend >> lane) & 1u) != 0;
-          const bool fits = mine_pending && (off + ntr - base_tr <= RNG_BLOCK);
-          const u64 fm = wave::ballot(fits);
-          if (fm == 0) {
-            const u32 l = static_cast<u32>(wave::ctz64(pend));
-            const u32 lo = wave::bcast(b_lo, l), hi = wave::bcast(b_hi, l);
-            const u32 major_dir = FWD ? DIR_FWD : DIR_REV;
-            u32 w = 0xFFFFFFFFu;
-            bool h = false;
-            for (u32 q = lo; q < hi; ++q) {
-              const u32 b = FWD ? (hi - 1 - (q - lo)) : q;  // reference visiting order
-              const u32 fl = wave::uniform(v.flag<false>(b));
-              if (!(fl & 1u)) continue;
-              const f64 pb = (fl >> 1) == major_dir ? p.pblock_major : p.pblock_minor;
-              bool hit;
-              if (pb == 1.0) {
-                hit = true;
-              } else if (pb == 0.0) {
-                hit = false;
-              } else {
-                hit = bernoulli_raw(rng_next(c.g), pb);
+        // q = number of entries at or before the unit: entry q is the candidate
+#pragma unroll
+        for (u32 sft = 64; sft >= 1; sft >>= 1) {
+          u32 kv[4];
+          i32 tq[4];
+#pragma unroll
+          for (u32 j = 0; j < 4; ++j) {
+            tq[j] = static_cast<i32>(q[j]) - static_cast<i32>(sft);
+            kv[j] = cp[tq[j] > -1 ? tq[j] : -1];  // (before the window: the sentinel)
+          }
+          wave::sched_fence();
+#pragma unroll
+          for (u32 j = 0; j < 4; ++j) {
+            if (kv[j] >= lo_key[j]) q[j] = static_cast<u32>(tq[j]);
+          }
+          wave::sched_fence();
+        }
+        bool far = false;  // the fixed steps ran out: finish with a binary search (rare)
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) far = far || (bnd[j] && q[j] + HITBAR_NEAR == anchor && q[j] > 0);
+        if (wave::any(far)) {
+#pragma unroll
+          for (u32 j = 0; j < 4; ++j) {
+            if (bnd[j] && q[j] + HITBAR_NEAR == anchor && q[j] > 0) {
+              u32 lo = 0;
+              u32 h = q[j];
+              while (lo < h) {
+                const u32 mid = (lo + h) >> 1;
+                if (cp[c0 + mid] < lo_key[j]) lo = mid + 1; else h = mid;
               }
-              if (hit) {
-                w = b;
-                h = (fl >> 1) == major_dir;
-              }
+              q[j] = h;
             }
-            if (lane == l) {
-              winner = w;
-              hard = h;
-              if (w != 0xFFFFFFFFu) bpos = v.pos<false>(w);
-            }
-            base_tr += wave::bcast(ntr, l);
-            pend &= ~(u64(1) << l);
-          } else {
-            // fitting lanes are a run of pending lanes starting at the first one
-            const u32 l_last_fit = static_cast<u32>(63 - wave::clz64(fm));
-            const u32 cnt = wave::bcast(off + ntr, l_last_fit) - base_tr;
-            if (cnt != 0) rng_ensure(c.g, cnt);
-            if (fits) {
-              winner = staged_only
-                           ? lef_bar_pick<FWD, true>(v, p, c.g, b_lo, b_hi, off - base_tr, hard, bpos)
-                           : lef_bar_pick<FWD, false>(v, p, c.g, b_lo, b_hi, off - base_tr, hard, bpos);
-            }
-            rng_advance(c.g, cnt);
-            base_tr += cnt;
-            pend &= ~fm;
+          }
+        }
+        // the candidates of the four units: position and index read together, then tested
+        u32 bp[4], wd[4];
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          const u32 e = c0 + (q[j] < cnt ? q[j] : 0);
+          bp[j] = cp[e];
+          wd[j] = ci[e];
+        }
+        wave::sched_fence();
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          if (bnd[j] & (q[j] < cnt) & (bp[j] < hi_key[j])) {
+            has[j] = true;
+            entry[j] = g0 + q[j];
+            winner[j] = wd[j] & ~HITBAR_HARD;
+            hard[j] = (wd[j] & HITBAR_HARD) != 0;
+            bpos[j] = bp[j];
           }
         }
       }
-      if (winner != 0xFFFFFFFFu) {
-        coll[k] = cw_make(winner, EV_COLLISION | EV_LEF_BAR) | (hard ? CW_HARD : 0u);
-        barpos[k] = bpos;
+      const u32 q_last = jl == 3 ? q[3] : jl == 2 ? q[2] : jl == 1 ? q[1] : q[0];
+      anchor = wave::bcast(q_last, l_last);
+    } else {
+      // the block spans more list entries than the window holds (few, far apart units): per-unit
+      // binary searches in the list in device memory
+#pragma unroll
+      for (u32 j = 0; j < 4; ++j) {
+        if (bnd[j]) {
+          if (!FWD) {
+            const u32 qa = lower_bound_u32(hpos, nh, hi_key[j]);  // entries below the unit
+            if (qa > 0) {
+              const u32 bp_ = hpos[qa - 1];
+              if (bp_ >= lo_key[j]) {
+                const u32 wd_ = hidx[qa - 1];
+                has[j] = true;
+                entry[j] = qa;
+                winner[j] = wd_ & ~HITBAR_HARD;
+                hard[j] = (wd_ & HITBAR_HARD) != 0;
+                bpos[j] = bp_;
+              }
+            }
+          } else {
+            const u32 qa = lower_bound_u32(hpos, nh, lo_key[j]);  // first entry above the unit
+            if (qa < nh) {
+              const u32 bp_ = hpos[qa];
+              if (bp_ < hi_key[j]) {
+                const u32 wd_ = hidx[qa];
+                has[j] = true;
+                entry[j] = qa;
+                winner[j] = wd_ & ~HITBAR_HARD;
+                hard[j] = (wd_ & HITBAR_HARD) != 0;
+                bpos[j] = bp_;
+              }
+            }
+          }
+        }
+        // (the loads of this rare path end here: see detect_primary)
+        wave::pin(entry[j]);
+        wave::pin(winner[j]);
+        wave::pin(bpos[j]);
+        u32 hd = (hard[j] ? 1u : 0u) | (has[j] ? 2u : 0u);
+        wave::pin(hd);
+        hard[j] = (hd & 1u) != 0;
+        has[j] = (hd & 2u) != 0;
       }
-      // where the next batch continues: past the last bound unit's window (rev) / below it (fwd)
-      const u32 l_last = static_cast<u32>(63 - wave::clz64(bm));
-      anchor = FWD ? wave::bcast(b_lo, l_last) : wave::bcast(b_hi, l_last);
+      // the staged entries stay valid, but the next block must not trust the anchor
+      lo_cover = 1;
+      hi_cover = 0;
+    }
+#ifdef MODLE_SUBTIMER_LEFBAR
+    c.ph[15] += wave::clock() - t_search;
+#endif
+    if (wave::any(has[0] || has[1] || has[2] || has[3])) {
+      if (!TRIALS) {
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          if (has[j]) {
+            coll[k[j]] = cw_make(winner[j], EV_COLLISION | EV_LEF_BAR) | (hard[j] ? CW_HARD : 0u);
+            barpos[k[j]] = bpos[j];
+          }
+        }
+      } else {
+        // listed in sweep order: lane by lane, the four units of a lane in turn
+        u32 before[4];
+        u32 lane_cnt = 0;
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          before[j] = lane_cnt;
+          lane_cnt += has[j] ? 1u : 0u;
+        }
+        const u32 ps = wave_prefix_sum_u32(lane_cnt);
+        const u32 first = n_listed + ps - lane_cnt;
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+          if (has[j]) {
+            unit_rank[first + before[j]] = k[j];
+            unit_entry[first + before[j]] = entry[j];
+            unit_key[first + before[j]] = FWD ? hi_key[j] : lo_key[j];
+          }
+        }
+        n_listed += wave::bcast(ps, 63);
+      }
     }
   }
   wave::sync_mem();
+  return n_listed;
+}
+
+// Second pass with Bernoulli trials: 64 listed units at a time, in list order (rev: ascending
+// ranks, fwd: descending ranks -- the order in which the reference reaches their barriers).  A
+// unit's window is the run of list entries [e_lo, e_hi) between the entry the sweep found and its
+// far key; the reference visits them in ascending order for a rev unit and in descending order for
+// a fwd unit, draws for every entry whose probability is below one, and keeps the last hit.
+template <bool FWD>
+MODLE_DEV_NOINLINE void resolve_listed_units(Cell& c, u32 n_listed) {
+  Workspace& ws = c.ws;
+  const Params& p = *c.p;
+  const u32 lane = wave::lane();
+  const u32 nh = wave::uniform(c.n_hit[FWD ? 1 : 0]);
+  const u32* hpos = ws.hit_pos[FWD ? 1 : 0];
+  const u32* hidx = ws.hit_idx[FWD ? 1 : 0];
+  const u32* unit_rank = ws.tmp[0];
+  const u32* unit_entry = ws.tmp[1];
+  const u32* unit_key = ws.tmp[2];
+  u32* coll = FWD ? ws.f_coll : ws.r_coll;
+  u32* barpos = stalling_barrier_positions<FWD>(ws);
+  const f64 pb_major = wave::own_regs(p.pblock_major), pb_minor = wave::own_regs(p.pblock_minor);
+  const bool major_trial = pb_major != 1.0, minor_trial = pb_minor != 1.0;  // (neither is zero on a list)
+  // entries of a window in the reference's visiting order: q = 0 .. e_hi - e_lo - 1
+  const auto visit = [&](u32 e_lo, u32 e_hi, u32 q) { return FWD ? e_hi - 1 - q : e_lo + q; };
+  for (u32 base = 0; base < n_listed; base += 64) {
+    const u32 u = base + lane;
+    const bool act = u < n_listed;
+    const u32 k = wave::ld_sel(unit_rank, u, act, 0u);
+    const u32 e0 = wave::ld_sel(unit_entry, u, act, 0u);
+    const u32 key = wave::ld_sel(unit_key, u, act, 0u);
+    // the far end of the window (a run of one entry nearly always)
+    u32 e_lo = e0, e_hi = e0;
+    if (act) {
+      if (!FWD) {
+        while (e_lo > 0 && hpos[e_lo - 1] >= key) --e_lo;  // (key: the window's lower bound)
+      } else {
+        while (e_hi < nh && hpos[e_hi] < key) ++e_hi;      // (key: one past its upper bound)
+      }
+    }
+    // trials this unit consumes
+    u32 ntr = 0;
+    for (u32 q = 0; q < e_hi - e_lo; ++q) {
+      const bool is_major = (hidx[visit(e_lo, e_hi, q)] & HITBAR_HARD) != 0;
+      ntr += (is_major ? major_trial : minor_trial) ? 1u : 0u;
+    }
+    u32 off = wave_prefix_sum_u32(ntr);
+    const u32 total = wave::bcast(off, 63);
+    off -= ntr;
+    // winner of a unit whose trials start `first` outputs into the stream from g.pos
+    const auto pick = [&](u32 first, u32& w_entry) {
+      u32 t = 0;
+      w_entry = 0xFFFFFFFFu;
+      for (u32 q = 0; q < e_hi - e_lo; ++q) {
+        const u32 e = visit(e_lo, e_hi, q);
+        const bool is_major = (hidx[e] & HITBAR_HARD) != 0;
+        bool hit = true;
+        if (is_major ? major_trial : minor_trial) {
+          hit = bernoulli_raw(rng_peek(c.g, c.g.pos + first + t), is_major ? pb_major : pb_minor);
+          ++t;
+        }
+        if (hit) w_entry = e;  // later visits overwrite earlier ones
+      }
+    };
+    u32 w_entry = 0xFFFFFFFFu;
+    if (total <= RNG_BLOCK) {
+      if (total != 0) rng_ensure(c.g, total);
+      if (act) pick(off, w_entry);
+      rng_advance(c.g, total);
+    } else {
+      // More trials in this batch than one block of the PRNG ring serves (dense barrier
+      // annotations): the lanes are resolved in rounds, each taking the longest run of lanes (in
+      // lane = stream order) whose trials fit one block; a single unit with more trials than that is
+      // replayed sequentially.
+      u64 pend = wave::ballot(act);
+      u32 base_tr = 0;  // trials consumed by the lanes resolved so far
+      while (pend != 0) {
+        const bool mine_pending = ((pend >> lane) & 1u) != 0;
+        const bool fits = mine_pending && (off + ntr - base_tr <= RNG_BLOCK);
+        const u64 fm = wave::ballot(fits);
+        if (fm == 0) {
+          const u32 l = static_cast<u32>(wave::ctz64(pend));
+          const u32 lo = wave::bcast(e_lo, l), hi = wave::bcast(e_hi, l);
+          u32 w = 0xFFFFFFFFu;
+          for (u32 q = 0; q < hi - lo; ++q) {
+            const u32 e = FWD ? hi - 1 - q : lo + q;
+            const bool is_major = (wave::uniform(hidx[e]) & HITBAR_HARD) != 0;
+            bool hit = true;
+            if (is_major ? major_trial : minor_trial) hit = bernoulli_raw(rng_next(c.g), is_major ? pb_major : pb_minor);
+            if (hit) w = e;
+          }
+          if (lane == l) w_entry = w;
+          base_tr += wave::bcast(ntr, l);
+          pend &= ~(u64(1) << l);
+        } else {
+          // fitting lanes are a run of pending lanes starting at the first one
+          const u32 l_last_fit = static_cast<u32>(63 - wave::clz64(fm));
+          const u32 cnt = wave::bcast(off + ntr, l_last_fit) - base_tr;
+          if (cnt != 0) rng_ensure(c.g, cnt);
+          if (fits) pick(off - base_tr, w_entry);
+          rng_advance(c.g, cnt);
+          base_tr += cnt;
+          pend &= ~fm;
+        }
+      }
+    }
+    if (w_entry != 0xFFFFFFFFu) {
+      const u32 wd = hidx[w_entry];
+      coll[k] = cw_make(wd & ~HITBAR_HARD, EV_COLLISION | EV_LEF_BAR) | ((wd & HITBAR_HARD) ? CW_HARD : 0u);
+      barpos[k] = hpos[w_entry];
+    }
+  }
+  wave::sync_mem();
+}
+
+template <bool FWD>
+MODLE_DEV_NOINLINE void detect_lef_bar(Cell& c, BoundaryCounts bc) {
+  if (wave::uniform(c.iv->n_barriers) == 0) return;
+  if (!lef_bar_trials_needed(*c.p)) {
+    detect_lef_bar_det<FWD>(c, bc);
+    return;
+  }
+  const u32 n_listed = detect_lef_bar_sweep<FWD, true>(c, bc);
+  if (n_listed != 0) resolve_listed_units<FWD>(c, n_listed);
 }
 
 // compute_lef_lef_collision_pos (reference: simulation.cpp:523-551)
@@ -1797,7 +2086,7 @@ MODLE_DEV bool phase_process_collisions(Cell& c) {
   PHASE(c, 8, bc = detect_boundaries(c));
   // helper-wave mode (sim_pair.h): without Bernoulli trials the two instances draw nothing and touch
   // disjoint arrays; the helper takes the fwd one
-  const bool split = c.pair_on && stalling_lists_wanted(*c.p) && wave::uniform(c.iv->n_barriers) != 0;
+  const bool split = c.pair_on && !lef_bar_trials_needed(*c.p) && wave::uniform(c.iv->n_barriers) != 0;
   if (split) {
     bool handed = false;
     PHASE(c, 9, pair_request_lef_bar(c, bc.n5, bc.n3); detect_lef_bar<false>(c, bc); handed = pair_wait(c, PAIR_ALL));

@@ -120,7 +120,7 @@ MODLE_DEV u32 run_test_phases(const Params& p, const Interval& iv, const Workspa
     if (mask & PH_USE_BOUNDARY_COUNTS) bc = got;
   }
   if (mask & PH_LEF_BAR) {
-    if (stalling_lists_wanted(p)) compact_stalling_barriers(c);
+    compact_stalling_barriers(c);
     detect_lef_bar<false>(c, bc);
     detect_lef_bar<true>(c, bc);
   }
