@@ -460,6 +460,9 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
       n_new += static_cast<u32>(wave::popc64(dm));
     }
   }
+#ifdef MODLE_EMU_TRACE_RANK
+  if (n_new > key_cap && lane == 0) fprintf(stderr, "rank_update_listed: n_new %u > key_cap %u: general update\n", n_new, key_cap);
+#endif
   if (n_new > key_cap) return false;
 #ifdef MODLE_EMU_TRACE_RANK  // (emulator only: which regime a test exercises)
   if (lane == 0) fprintf(stderr, "rank_update_listed: n_new %u (listed %u) of %u, key_cap %u\n", n_new, n_listed, n, key_cap);
@@ -473,7 +476,13 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
   if (lane == 0) keys[n_new] = ~u64(0);
   for (u32 j = lane; j < n_new; j += 64) cnt_store(j, n_old);
   wave::sync_lds();
+#ifdef MODLE_SUBTIMER_RANK
+  const u64 t_sort = wave::clock();
+#endif
   if (m2 > 1) bitonic_sort_u64<true>(keys, m2);
+#ifdef MODLE_SUBTIMER_RANK
+  c.ph[14] += wave::clock() - t_sort;  // (the sort of the keys)
+#endif
 
   bool ties = false;
   u32 t_lo = 0xFFFFFFFFu, t_hi = 0;  // output slots of the units flagged for equal positions
@@ -635,6 +644,8 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
       t_lo = umin(t_lo, ~wave::bcast(wave_prefix_max_u32(~tie_lo), 63));
       t_hi = umax(t_hi, wave::bcast(wave_prefix_max_u32(tie_hi), 63));
     }
+    // (two blocks of loads in flight were tried in round 4: no gain -- the sweep is bound by its ~500
+    // instructions and four dependent search rounds per block, not by the latency of its loads)
     if (t + 1 < nblk) g = cur;
   }
   if (seen_new != n_new) return false;  // (the marks and the list disagree: cannot happen)
@@ -662,7 +673,13 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
     }
   }
   wave::sync_mem();
+#ifdef MODLE_SUBTIMER_RANK
+  const u64 t_fin = wave::clock();
+#endif
   rank_finish<FWD>(c, ties, nullptr, t_lo, t_hi);
+#ifdef MODLE_SUBTIMER_RANK
+  c.ph[15] += wave::clock() - t_fin;  // (ordering equal positions)
+#endif
   return true;
 }
 
@@ -674,6 +691,9 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
   if (n < 2) return;
   {
     const bool listed = !all_new && c.keys_valid && c.disp_valid && c.n_keys <= RANK_KEY_CAP;
+#ifdef MODLE_EMU_TRACE_RANK
+    if (!listed && wave::lane() == 0) fprintf(stderr, "rank_update: general (all_new %d keys_valid %d disp_valid %d n_keys %u n_disp %u %u)\n", int(all_new), int(c.keys_valid), int(c.disp_valid), c.n_keys, c.n_disp[0], c.n_disp[1]);
+#endif
     if (listed && rank_update_listed<FWD>(c)) {
       if (FWD) c.keys_valid = false;  // (the keys serve the rev update, then the fwd update)
       return;

@@ -64,7 +64,7 @@ struct Cell {
 };
 // (slot 14: LEF activation; a sub-phase measurement may claim slots 14 and 15 and sends the
 // activation time to slot 1 with the bind phase)
-#if defined(MODLE_SUBTIMER_LEFBAR) || defined(MODLE_SUBTIMER_STATS)
+#if defined(MODLE_SUBTIMER_LEFBAR) || defined(MODLE_SUBTIMER_STATS) || defined(MODLE_SUBTIMER_RANK)
 #define MODLE_SUBTIMER 1
 #endif
 #ifdef MODLE_SUBTIMER
