@@ -121,6 +121,7 @@ inline modle_dev::Workspace carve_workspace(void* base, uint32_t max_lefs, uint3
                           &ws.f_move, &ws.f_coll, &ws.epoch, &ws.r_rank, &ws.f_rank, &ws.stall};
   for (int k = 0; k < 12; ++k) *slots[k] = q + static_cast<size_t>(k) * Lp;
   for (uint32_t k = 0; k < modle_dev::NUM_TMP; ++k) ws.tmp[k] = q + (12 + static_cast<size_t>(k)) * Lp;
+  for (uint32_t d = 0; d < 2; ++d) ws.by_id_pos[d] = q + (12 + modle_dev::NUM_TMP + static_cast<size_t>(d)) * Lp;
   p += w.u32_words * 4;
   ws.bar_active = reinterpret_cast<uint8_t*>(p);
   p += w.u8_bytes;

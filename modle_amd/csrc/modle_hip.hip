@@ -111,6 +111,7 @@ __device__ __forceinline__ Workspace device_carve(char* base, u32 max_lefs, u32 
   ws.f_rank = q + 10 * Lp;
   ws.stall = q + 11 * Lp;
   for (u32 k = 0; k < NUM_TMP; ++k) ws.tmp[k] = q + (12 + static_cast<u64>(k)) * Lp;
+  for (u32 d = 0; d < 2; ++d) ws.by_id_pos[d] = q + (12 + NUM_TMP + static_cast<u64>(d)) * Lp;
   p += static_cast<u64>(NUM_STATE_ARRAYS) * Lp * 4;
   ws.bar_active = reinterpret_cast<u8*>(p);
   const u64 Bp = (static_cast<u64>(max_barriers) + 63) & ~u64(63);

@@ -125,8 +125,14 @@ MODLE_DEV f64 fold_terms_in_lane_order(f64 ssd, f64 term, f64* buf) {
   wave::lockstep();
   buf[wave::lane()] = term;
   wave::sync_lds();
+  // (two terms per LDS read: the chain is 64 dependent additions either way, the reads are half the
+  // instructions between them)
 #pragma unroll
-  for (u32 l = 0; l < 64; ++l) ssd = ssd + buf[l];
+  for (u32 l = 0; l < 64; l += 2) {
+    const wave::F64x2 t = wave::lds_ld2_f64(buf + l);
+    ssd = ssd + t.v[0];
+    ssd = ssd + t.v[1];
+  }
   return ssd;
 }
 
@@ -248,6 +254,16 @@ MODLE_DEV LoopStats loop_size_stats_partitioned(Cell& c, u64* pairs_r, u64* pair
       }
     }
     wave::sync_lds();
+    // the positions by LEF id, for the passes of this epoch that need a LEF's other unit
+    // (fix_secondary): two coalesced stores per LEF
+#pragma unroll
+    for (u32 u = 0; u < UX; ++u) {
+      const u32 i = 64 * u + lane;
+      if (i < cnt) {
+        ws.by_id_pos[0][lo + i] = slot_r[i];
+        ws.by_id_pos[1][lo + i] = slot_f[i];
+      }
+    }
 #ifdef MODLE_SUBTIMER_STATS
     const u64 t_fold = wave::clock();
 #endif
@@ -265,6 +281,8 @@ MODLE_DEV LoopStats loop_size_stats_partitioned(Cell& c, u64* pairs_r, u64* pair
     c.ph[15] += wave::clock() - t_fold;  // (the fold alone)
 #endif
   }
+  wave::sync_mem();
+  c.by_id_valid = true;
   return LoopStats{avg, wave::f_sqrt(ssd / static_cast<f64>(n))};
 }
 

@@ -54,6 +54,10 @@ struct Cell {
   // the secondary pass collects the LEFs of its avoided collisions in the LDS id filter (for the
   // rank lookups of fix_secondary)
   bool filter_on;
+  // ws.by_id_pos holds the current position of every LEF's two units (written by the burn-in
+  // statistics of this epoch, behind the bind phase; positions only change again in the extrusion):
+  // fix_secondary reads the partner units' positions there instead of looking their ranks up
+  bool by_id_valid;
   // helper-wave mode (sim_pair.h): sequence number of the last request posted to the helper
   u32 pair_seq;
   u32 pair_interval;  // index of the task's interval (goes with every request)

@@ -1896,8 +1896,8 @@ MODLE_DEV_NOINLINE void fix_secondary_rev_seq(Cell& c, const u32* list, u32 n_li
     const u32 pos1 = p1 - m1;
     const u32 m2 = p2 > pos1 + 1 ? p2 - (pos1 + 1) : 0;
     const u32 c2 = cw_make(id1, EV_COLLISION | sec);
-    const u32 np1 = umin(ws.f_pos[ws.f_rank[id1]], p2);
-    const u32 np2 = umin(ws.f_pos[ws.f_rank[id2]], p1);
+    const u32 np1 = umin(c.by_id_valid ? ws.by_id_pos[1][id1] : ws.f_pos[ws.f_rank[id1]], p2);
+    const u32 np2 = umin(c.by_id_valid ? ws.by_id_pos[1][id2] : ws.f_pos[ws.f_rank[id2]], p1);
     wave::lockstep();
     // unit 2 moves to slot i-1 with unit 1's old collision / move, unit 1 to slot i
     ws.r_id[i - 1] = id2;
@@ -1910,6 +1910,10 @@ MODLE_DEV_NOINLINE void fix_secondary_rev_seq(Cell& c, const u32* list, u32 n_li
     ws.r_move[i] = umin(np1 - start, m2);
     ws.r_rank[id2] = i - 1;
     ws.r_rank[id1] = i;
+    if (c.by_id_valid) {
+      ws.by_id_pos[0][id2] = np2;
+      ws.by_id_pos[0][id1] = np1;
+    }
     wave::sync_mem();
   }
 }
@@ -1928,8 +1932,8 @@ MODLE_DEV_NOINLINE void fix_secondary_fwd_seq(Cell& c, const u32* list, u32 n_li
     const u32 pos2 = p2 + m2;
     const u32 m1 = pos2 > p1 + 1 ? pos2 - (p1 + 1) : 0;
     const u32 c1 = cw_make(id2, EV_COLLISION | sec);
-    const u32 np1 = umax(ws.r_pos[ws.r_rank[id1]], p2);
-    const u32 np2 = umax(ws.r_pos[ws.r_rank[id2]], p1);
+    const u32 np1 = umax(c.by_id_valid ? ws.by_id_pos[0][id1] : ws.r_pos[ws.r_rank[id1]], p2);
+    const u32 np2 = umax(c.by_id_valid ? ws.by_id_pos[0][id2] : ws.r_pos[ws.r_rank[id2]], p1);
     wave::lockstep();
     ws.f_id[i] = id2;
     ws.f_pos[i] = np2;
@@ -1941,6 +1945,10 @@ MODLE_DEV_NOINLINE void fix_secondary_fwd_seq(Cell& c, const u32* list, u32 n_li
     ws.f_move[i + 1] = umin(last - np1, m2);
     ws.f_rank[id2] = i;
     ws.f_rank[id1] = i + 1;
+    if (c.by_id_valid) {
+      ws.by_id_pos[1][id2] = np2;
+      ws.by_id_pos[1][id1] = np1;
+    }
     wave::sync_mem();
   }
 }
@@ -1984,8 +1992,8 @@ MODLE_DEV_NOINLINE void fix_secondary_rev(Cell& c, const u32* list, u32 n_list) 
         const u32 pos1 = p1 - m1;
         const u32 m2 = p2 > pos1 + 1 ? p2 - (pos1 + 1) : 0;
         const u32 c2 = cw_make(id1, EV_COLLISION | sec);
-        const u32 np1 = umin(ws.f_pos[ws.f_rank[id1]], p2);
-        const u32 np2 = umin(ws.f_pos[ws.f_rank[id2]], p1);
+        const u32 np1 = umin(c.by_id_valid ? ws.by_id_pos[1][id1] : ws.f_pos[ws.f_rank[id1]], p2);
+        const u32 np2 = umin(c.by_id_valid ? ws.by_id_pos[1][id2] : ws.f_pos[ws.f_rank[id2]], p1);
         ws.r_id[i - 1] = id2;
         ws.r_pos[i - 1] = np2;
         ws.r_coll[i - 1] = c1;
@@ -1996,6 +2004,10 @@ MODLE_DEV_NOINLINE void fix_secondary_rev(Cell& c, const u32* list, u32 n_list) 
         ws.r_move[i] = umin(np1 - start, m2);
         ws.r_rank[id2] = i - 1;
         ws.r_rank[id1] = i;
+        if (c.by_id_valid) {
+          ws.by_id_pos[0][id2] = np2;
+          ws.by_id_pos[0][id1] = np1;
+        }
       }
     }
   }
@@ -2023,8 +2035,8 @@ MODLE_DEV_NOINLINE void fix_secondary_fwd(Cell& c, const u32* list, u32 n_list) 
         const u32 pos2 = p2 + m2;
         const u32 m1 = pos2 > p1 + 1 ? pos2 - (p1 + 1) : 0;
         const u32 c1 = cw_make(id2, EV_COLLISION | sec);
-        const u32 np1 = umax(ws.r_pos[ws.r_rank[id1]], p2);
-        const u32 np2 = umax(ws.r_pos[ws.r_rank[id2]], p1);
+        const u32 np1 = umax(c.by_id_valid ? ws.by_id_pos[0][id1] : ws.r_pos[ws.r_rank[id1]], p2);
+        const u32 np2 = umax(c.by_id_valid ? ws.by_id_pos[0][id2] : ws.r_pos[ws.r_rank[id2]], p1);
         ws.f_id[i] = id2;
         ws.f_pos[i] = np2;
         ws.f_coll[i] = c1;
@@ -2035,6 +2047,10 @@ MODLE_DEV_NOINLINE void fix_secondary_fwd(Cell& c, const u32* list, u32 n_list) 
         ws.f_move[i + 1] = umin(last - np1, m2);
         ws.f_rank[id2] = i;
         ws.f_rank[id1] = i + 1;
+        if (c.by_id_valid) {
+          ws.by_id_pos[1][id2] = np2;
+          ws.by_id_pos[1][id1] = np1;
+        }
       }
     }
   }
@@ -2049,8 +2065,9 @@ MODLE_DEV_NOINLINE void fix_secondary_fwd(Cell& c, const u32* list, u32 n_list) 
 // before the fwd fix looks at them, but it updates ws.r_rank for every unit it moves; the ids on
 // the slots a cascade of fixes touches are the ids of its entries, whatever their order.)
 MODLE_DEV_NOINLINE void lookup_partner_ranks(Cell& c, bool want_r, bool want_f) {
-  want_r = want_r && !c.inv_valid[0];
-  want_f = want_f && !c.inv_valid[1];
+  // (the positions by LEF id are at hand: nothing to look up)
+  want_r = want_r && !c.inv_valid[0] && !c.by_id_valid;
+  want_f = want_f && !c.inv_valid[1] && !c.by_id_valid;
   if (!want_f && !want_r) return;
   Workspace& ws = c.ws;
   const u32 n = wave::uniform(c.n_active);

@@ -74,6 +74,7 @@ MODLE_DEV void init_cell(Cell& c, const Params& p, const Interval& iv, const Wor
   c.inv_valid[0] = true;  // (reset_cell_buffers / run_test_phases write complete permutations)
   c.inv_valid[1] = true;
   c.filter_on = false;
+  c.by_id_valid = false;
   // (the helper keeps counting the requests across the tasks of its main wave)
   c.pair_seq = lds.mbox != nullptr ? wave::uniform(lds.mbox[PAIR_REQ]) : 0u;
   c.pair_on = false;
@@ -251,6 +252,7 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
     // bind phase the LDS sort buffer no longer holds the list of released LEFs, so the statistics can
     // restore the LEF-id order there instead of scattering to device memory (sim_burnin.h).
     bool stats_due = false;
+    c.by_id_valid = false;  // (last epoch's extrusion moved every unit)
     if (!burnin_completed) {
       do {
         ++num_burnin_epochs;

@@ -121,6 +121,9 @@ struct Workspace {
   u32 *f_pos, *f_id, *f_move, *f_coll;  // fwd units, by fwd rank
   u32 *epoch, *r_rank, *f_rank, *stall; // by LEF id
   u32* tmp[NUM_TMP];                    // L words each
+  // rev / fwd position of every LEF in LEF-id order, as of the last evaluation of the burn-in
+  // statistics (which restores the id order anyway: sim_burnin.h); valid while Cell::by_id_valid
+  u32* by_id_pos[2];
   u64* sort_keys;                       // pow2ceil(L) words
   f64* hist;                            // 2 * hist_len doubles (burn-in history)
   u8* bar_active;                       // n_barriers bytes
@@ -130,7 +133,7 @@ struct Workspace {
   u32* hit_idx[2];                      // barrier index | hard << 31
   u32 capacity_lefs, capacity_barriers;
 };
-constexpr u32 NUM_STATE_ARRAYS = 12 + NUM_TMP;
+constexpr u32 NUM_STATE_ARRAYS = 12 + NUM_TMP + 2;
 // marker left in r_move / f_move by bind: "this unit was (re)bound this epoch"
 constexpr u32 NEW_MARK = 0xFFFFFFFFu;
 // ... and by the extrusion sweep: "this unit ended up below a unit of lower rank" (moves are

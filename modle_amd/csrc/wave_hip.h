@@ -190,6 +190,12 @@ MODLE_DEV LdsRow lds_load_row(const MODLE_LDS uint64_t* table, uint32_t v) {
   return LdsRow{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
 }
 
+// two consecutive doubles of an LDS buffer as one 128-bit read (p 16-byte aligned)
+struct alignas(16) F64x2 {
+  double v[2];
+};
+MODLE_DEV F64x2 lds_ld2_f64(const double* p) { return *reinterpret_cast<const F64x2*>(p); }
+
 // the instruction scheduler may not move anything across this point
 MODLE_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 

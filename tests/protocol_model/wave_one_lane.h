@@ -57,6 +57,10 @@ MODLE_DEV uint64_t clock() { return 0; }
 MODLE_DEV void pin(uint32_t&) {}
 MODLE_DEV void launder(uint32_t&) {}
 MODLE_DEV void sched_fence() {}
+struct F64x2 {
+  double v[2];
+};
+MODLE_DEV F64x2 lds_ld2_f64(const double* p) { return F64x2{{p[0], p[1]}}; }
 MODLE_DEV double own_regs(double v) { return v; }
 MODLE_DEV uint32_t own_regs(uint32_t v) { return v; }
 MODLE_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }

@@ -194,6 +194,10 @@ MODLE_DEV LdsRow lds_load_row(const uint64_t* table, uint32_t v) {
   return r;
 }
 MODLE_DEV void sched_fence() {}
+struct F64x2 {
+  double v[2];
+};
+MODLE_DEV F64x2 lds_ld2_f64(const double* p) { return F64x2{{p[0], p[1]}}; }
 
 template <class T>
 MODLE_DEV T ld_stream(const T* p) { return *p; }
