@@ -119,6 +119,60 @@ def test_chr1_scale_properties():
         assert r.sim_epochs <= r.epochs
 
 
+def test_chr1_full_launch_properties():
+    """BASELINE configs[1] as bench.py launches it: ALL 512 cells of the chr1-shaped interval in one
+    launch, which leaves most wave slots empty, so every cell runs on a main wave with a helper and
+    a PRNG producer (helper-wave mode: the library's own choice, read back from
+    modle_hip_last_launch_info).  The oracle would need minutes for it: checked through the
+    size-independent properties of driver.verify_outputs, and against a second launch of the same
+    cells with one wave per cell, word for word."""
+    import os
+
+    from modle_amd import api, driver, synthetic
+
+    genome = synthetic.grch38_like(seed=42, chroms={"chr1"})
+    cfg = api.make_config(num_cells=512, seed=0)
+    plan = driver.plan_genome(cfg, genome)
+    assert len(plan[0]["tasks"]) == 512 and plan[0]["tasks"][0].num_lefs == 4979
+    old = os.environ.get("MODLE_HIP_PAIRED")
+    outs = {}
+    try:
+        for mode in (None, "0"):
+            if mode is None:
+                os.environ.pop("MODLE_HIP_PAIRED", None)
+            else:
+                os.environ["MODLE_HIP_PAIRED"] = mode
+            sim = api.Simulator(cfg, 0)
+            try:
+                ids = driver.enqueue_plan(sim, cfg, plan)
+                sim.launch()
+                sim.wait()
+                info = sim.launch_info()
+                c, missed, occ = sim.copy_outputs(ids[0])
+                res = sim.results(ids[0])
+                summary = driver.verify_outputs(sim, cfg, plan, ids, [int(c.astype(np.int64).sum())], [missed],
+                                                [int(occ.astype(np.int64).sum())])
+                outs[mode] = (c, missed, occ, [(r.epochs, r.burnin_epochs, r.num_contacts, r.raws_consumed,
+                                               list(r.prng_final)) for r in res], info, sim.kernel_ms())
+            finally:
+                sim.close()
+            assert summary["tasks"] == 512 and summary["contacts"] > 0
+    finally:
+        if old is None:
+            os.environ.pop("MODLE_HIP_PAIRED", None)
+        else:
+            os.environ["MODLE_HIP_PAIRED"] = old
+    helper, single = outs[None], outs["0"]
+    assert helper[4]["helper_waves"] == 1 and helper[4]["prng_producer_waves"] == 1 and helper[4]["main_waves_per_workgroup"] == 2
+    assert single[4]["helper_waves"] == 0
+    assert np.array_equal(helper[0], single[0]) and helper[1] == single[1] and np.array_equal(helper[2], single[2])
+    assert helper[3] == single[3]
+    # the launch lasts as long as its longest cell: the burn-in of some cell takes three times the mean
+    epochs = [r[0] for r in helper[3]]
+    assert max(epochs) > 2 * (sum(epochs) / len(epochs))
+    print(f"chr1 x 512: helper-wave mode {helper[5]:.0f} ms, one wave per cell {single[5]:.0f} ms")
+
+
 @pytest.mark.parametrize("skip_burnin,ncells,extra", [
     (0, 8, {}), (1, 6, {}),
     # BASELINE config 4 shape: 64 LEFs/Mb (15 933 LEFs on chr1), minor-collision trials, soft stalls
