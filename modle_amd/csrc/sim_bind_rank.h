@@ -422,6 +422,9 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
   const u32* pos = FWD ? ws.f_pos : ws.r_pos;
   const u32* ids = FWD ? ws.f_id : ws.r_id;
   const u32* marks = FWD ? ws.f_move : ws.r_move;
+#ifdef MODLE_SUBTIMER_RANK
+  const u64 t_enter = wave::clock();
+#endif
   u64* keys = c.lds.sort_lds;
   // per key: the number of carried-over units that go before it.  16-bit entries (twice as many keys
   // in the 1 KB staging buffer: the collision-heavy configurations re-insert several hundred units
@@ -465,7 +468,7 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
 #endif
   if (n_new > key_cap) return false;
 #ifdef MODLE_EMU_TRACE_RANK  // (emulator only: which regime a test exercises)
-  if (lane == 0) fprintf(stderr, "rank_update_listed: n_new %u (listed %u) of %u, key_cap %u\n", n_new, n_listed, n, key_cap);
+  if (lane == 0) fprintf(stderr, "rank_update_listed: %s n_new %u (listed %u, displaced %u) of %u, key_cap %u\n", FWD ? "fwd" : "rev", n_new, n_listed, n_new - n_listed, n, key_cap);
 #endif
   const u32 n_old = n - n_new;
   const u32 m2 = n_new != 0 ? pow2_ceil(n_new) : 0;
@@ -476,12 +479,10 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
   if (lane == 0) keys[n_new] = ~u64(0);
   for (u32 j = lane; j < n_new; j += 64) cnt_store(j, n_old);
   wave::sync_lds();
-#ifdef MODLE_SUBTIMER_RANK
-  const u64 t_sort = wave::clock();
-#endif
   if (m2 > 1) bitonic_sort_u64<true>(keys, m2);
 #ifdef MODLE_SUBTIMER_RANK
-  c.ph[14] += wave::clock() - t_sort;  // (the sort of the keys)
+  c.ph[14] += wave::clock() - t_enter;  // (keys: load, displaced units, sort)
+  const u64 t_sweep = wave::clock();
 #endif
 
   bool ties = false;
@@ -652,6 +653,9 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
   }
   if (seen_new != n_new) return false;  // (the marks and the list disagree: cannot happen)
   wave::sync_lds();
+#ifdef MODLE_SUBTIMER_RANK
+  c.ph[15] += wave::clock() - t_sweep;  // (the sweep)
+#endif
   for (u32 base = 0; base < n_new; base += 64) {
     const u32 bq = base + lane;
     bool tie = false;
@@ -675,13 +679,7 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
     }
   }
   wave::sync_mem();
-#ifdef MODLE_SUBTIMER_RANK
-  const u64 t_fin = wave::clock();
-#endif
   rank_finish<FWD>(c, ties, nullptr, t_lo, t_hi);
-#ifdef MODLE_SUBTIMER_RANK
-  c.ph[15] += wave::clock() - t_fin;  // (ordering equal positions)
-#endif
   return true;
 }
 
