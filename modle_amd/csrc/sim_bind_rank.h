@@ -411,8 +411,9 @@ MODLE_DEV void rank_finish(Cell& c, bool ties, const u32* where, u32 t_lo, u32 t
 // of the previous epoch, which has the new positions in registers anyway, has marked them and
 // listed their keys (a separate sweep over positions and marks used to find them here).
 // Returns false -- nothing committed, the caller runs the general update -- when the keys do not
-// fit the LDS buffers (RANK_KEY_CAP keys, the sort buffer less the sentinel; 256 when the chromosome
-// has 65536 LEFs or more and the per-key counts need 32 bits).
+// fit the LDS buffers (RANK_KEY_CAP keys, the sort buffer less the sentinel; RANK_KEY_CAP_BIG in the
+// generator's ring when that is free; 256 when the chromosome has 65536 LEFs or more and the per-key
+// counts need 32 bits).
 template <bool FWD>
 MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
   Workspace& ws = c.ws;
@@ -425,18 +426,40 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
 #ifdef MODLE_SUBTIMER_RANK
   const u64 t_enter = wave::clock();
 #endif
-  u64* keys = c.lds.sort_lds;
-  // per key: the number of carried-over units that go before it.  16-bit entries (twice as many keys
-  // in the 1 KB staging buffer: the collision-heavy configurations re-insert several hundred units
-  // per epoch) whenever the counts fit, i.e. on every real chromosome; 32-bit entries otherwise
+  // per key: the number of carried-over units that go before it.  With fewer than 65536 LEFs -- every
+  // real chromosome -- the count rides in the key itself, (position, previous rank, count) =
+  // 32 + 16 + 16 bits: one LDS word per key, nothing beside it, and the comparisons of the sweep are
+  // unchanged because no two keys share (position, previous rank).  Otherwise: 32-bit counts in the
+  // staging buffer, and STAGE_CAP keys.
+  const bool narrow = n < 65536u;
+  const u32 kshift = narrow ? 16u : 0u;
   u32* cnt32 = c.lds.stage;
-  u16* cnt16 = reinterpret_cast<u16*>(c.lds.stage);
-  const bool narrow_cnt = n < 65536u;
-  const u32 key_cap = narrow_cnt ? RANK_KEY_CAP : STAGE_CAP;
-  const auto cnt_store = [&](u32 q, u32 v) {
-    if (narrow_cnt) cnt16[q] = static_cast<u16>(v); else cnt32[q] = v;
+  // the keys: the sort buffer (RANK_KEY_CAP).  An epoch that re-inserts more (the collision-heavy
+  // configurations: 600-800 units per epoch and direction on the large chromosomes) borrows the 8 KB
+  // of the generator's ring, whose contents wait in device memory meanwhile -- when the ring is this
+  // wave's to borrow (helper-wave mode lends it to the helper for the burn-in epochs)
+  const u32 nd_listed = wave::uniform(c.n_disp[FWD ? 1 : 0]);
+  const bool big = n_listed + nd_listed > RANK_KEY_CAP;
+  if (big && (!narrow || c.ring_lent || n_listed + nd_listed > RANK_KEY_CAP_BIG ||
+              ws.capacity_lefs < RING_SPILL_AT + RNG_RING))
+    return false;
+  const u32 key_cap = big ? RANK_KEY_CAP_BIG : (narrow ? RANK_KEY_CAP : STAGE_CAP);
+  u64* const keys = big ? c.g.ring : c.lds.sort_lds;
+  u64* const ring_spill = ws.sort_keys + RING_SPILL_AT;
+  if (big) {
+    for (u32 k = lane; k < RNG_RING; k += 64) ring_spill[k] = c.g.ring[k];
+  }
+  const auto give_ring_back = [&]() {
+    if (big) {
+      wave::sync_mem();
+      for (u32 k = lane; k < RNG_RING; k += 64) c.g.ring[k] = ring_spill[k];
+      wave::sync_lds();
+    }
   };
-  const auto cnt_load = [&](u32 q) -> u32 { return narrow_cnt ? static_cast<u32>(cnt16[q]) : cnt32[q]; };
+  const auto in_lds_format = [&](u64 kv) -> u64 {
+    return (kv & 0xFFFFFFFF00000000ull) | (static_cast<u64>(static_cast<u32>(kv)) << kshift);
+  };
+  const auto cnt_load = [&](u32 q, u64 key) -> u32 { return narrow ? static_cast<u32>(key) & 0xFFFFu : cnt32[q]; };
   const u64* src = reinterpret_cast<const u64*>(FWD ? ws.tmp[4] : ws.tmp[2]);
   u32* out_pos = ws.tmp[0];
   u32* out_id = ws.tmp[1];
@@ -445,28 +468,31 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
   for (u32 base = 0; base < n_listed; base += 64) {
     const u32 k = base + lane;
     const u64 kv = wave::ld_sel(src, k, k < n_listed, ~u64(0));
-    if (k < n_listed) keys[k] = kv;
+    if (k < n_listed) keys[k] = in_lds_format(kv);
   }
   // the out-of-order units the extrusion sweep listed, unless they have been released and bound
   // again since (their slot then carries the mark of a new unit, and the bind phase's key)
   u32 n_new = n_listed;
   {
     const u64* dsrc = reinterpret_cast<const u64*>(FWD ? ws.tmp[7] : ws.tmp[6]);
-    const u32 nd = wave::uniform(c.n_disp[FWD ? 1 : 0]);
+    const u32 nd = nd_listed;
     for (u32 base = 0; base < nd; base += 64) {
       const u32 e = base + lane;
       const u64 kv = wave::ld_sel(dsrc, e, e < nd, ~u64(0));
       const bool still = e < nd && wave::ld_sel(marks, static_cast<u32>(kv), e < nd, 0u) == DISP_MARK;
       const u64 dm = wave::ballot(still);
       const u32 j = n_new + static_cast<u32>(wave::popc64(dm & lanemask_lt(lane)));
-      if (still && j < key_cap) keys[j] = kv;
+      if (still && j < key_cap) keys[j] = in_lds_format(kv);
       n_new += static_cast<u32>(wave::popc64(dm));
     }
   }
 #ifdef MODLE_EMU_TRACE_RANK
   if (n_new > key_cap && lane == 0) fprintf(stderr, "rank_update_listed: n_new %u > key_cap %u: general update\n", n_new, key_cap);
 #endif
-  if (n_new > key_cap) return false;
+  if (n_new > key_cap) {
+    give_ring_back();
+    return false;
+  }
 #ifdef MODLE_EMU_TRACE_RANK  // (emulator only: which regime a test exercises)
   if (lane == 0) fprintf(stderr, "rank_update_listed: %s n_new %u (listed %u, displaced %u) of %u, key_cap %u\n", FWD ? "fwd" : "rev", n_new, n_listed, n_new - n_listed, n, key_cap);
 #endif
@@ -475,9 +501,14 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
   for (u32 k = n_new + lane; k < m2; k += 64) keys[k] = ~u64(0);
   // (a key of all ones behind the last one, also when n_new is a power of two: a step of the
   // searches below that overshoots reads it, through one `v_min` on the index, instead of testing
-  // its range; n_new <= RANK_KEY_CAP < SORT_LDS_CAP)
+  // its range; n_new <= key_cap, one less than the buffer holds)
   if (lane == 0) keys[n_new] = ~u64(0);
-  for (u32 j = lane; j < n_new; j += 64) cnt_store(j, n_old);
+  // (the count every key starts from: no carried-over unit follows it)
+  if (narrow) {
+    for (u32 j = lane; j < n_new; j += 64) keys[j] |= n_old;
+  } else {
+    for (u32 j = lane; j < n_new; j += 64) cnt32[j] = n_old;
+  }
   wave::sync_lds();
   if (m2 > 1) bitonic_sort_u64<true>(keys, m2);
 #ifdef MODLE_SUBTIMER_RANK
@@ -549,7 +580,7 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
       // (position, previous rank): units and keys with equal positions merge in the order of their
       // previous ranks, which is what lets rank_finish order them by binding epoch alone; a unit
       // that takes no part has the key nothing lies below
-      thr[j] = carried[j] ? (static_cast<u64>(pp[j]) << 32) | (w + j) : u64(0);
+      thr[j] = carried[j] ? (static_cast<u64>(pp[j]) << 32) | ((w + j) << kshift) : u64(0);
     }
 #pragma unroll
     for (u32 sft = 8; sft >= 1; sft >>= 1) {
@@ -613,8 +644,9 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
           // key at the position of either neighbour is flagged for the final ordering
           const u32 a = slot[j] - lo[j];
           for (u32 q = lo_prev[j]; q < lo[j]; ++q) {
-            cnt_store(q, a);
-            const u32 kp = static_cast<u32>(keys[q] >> 32);
+            const u64 kq = keys[q];
+            if (narrow) keys[q] = (kq & ~u64(0xFFFF)) | a; else cnt32[q] = a;
+            const u32 kp = static_cast<u32>(kq >> 32);
             if (kp != UNBOUND && (kp == pp[j] || (a > 0 && kp == excl[j]))) {
               tie = true;
               tie_lo = umin(tie_lo, q + a);
@@ -651,7 +683,10 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
     // instructions and four dependent search rounds per block, not by the latency of its loads)
     if (t + 1 < nblk) g = cur;
   }
-  if (seen_new != n_new) return false;  // (the marks and the list disagree: cannot happen)
+  if (seen_new != n_new) {  // (the marks and the list disagree: cannot happen)
+    give_ring_back();
+    return false;
+  }
   wave::sync_lds();
 #ifdef MODLE_SUBTIMER_RANK
   c.ph[15] += wave::clock() - t_sweep;  // (the sweep)
@@ -662,8 +697,8 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
     if (bq < n_new) {
       const u64 key = keys[bq];
       const u32 pp = static_cast<u32>(key >> 32);
-      const u32 lo = cnt_load(bq);
-      const u32 nid = ids[static_cast<u32>(key)];  // the slot the unit was bound in
+      const u32 lo = cnt_load(bq, key);
+      const u32 nid = ids[static_cast<u32>(key) >> kshift];  // the slot the unit was bound in
       wave::st_stream(&out_pos[bq + lo], pp);
       wave::st_stream(&out_id[bq + lo], nid);
       tie = bq + 1 < n_new && static_cast<u32>(keys[bq + 1] >> 32) == pp;
@@ -673,11 +708,12 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
     }
     if (wave::any(tie)) {
       ties = true;
-      const u32 slot = bq < n_new ? bq + cnt_load(bq < n_new ? bq : 0) : 0;
+      const u32 slot = bq < n_new ? bq + cnt_load(bq, keys[bq]) : 0;
       t_lo = umin(t_lo, ~wave::bcast(wave_prefix_max_u32(tie ? ~slot : 0u), 63));
       t_hi = umax(t_hi, wave::bcast(wave_prefix_max_u32(tie ? slot : 0u), 63));
     }
   }
+  give_ring_back();
   wave::sync_mem();
   rank_finish<FWD>(c, ties, nullptr, t_lo, t_hi);
   return true;
@@ -690,7 +726,7 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
   const u32 n = wave::uniform(c.n_active);
   if (n < 2) return;
   {
-    const bool listed = !all_new && c.keys_valid && c.disp_valid && c.n_keys <= RANK_KEY_CAP;
+    const bool listed = !all_new && c.keys_valid && c.disp_valid && c.n_keys <= RANK_KEY_CAP_BIG;
 #ifdef MODLE_EMU_TRACE_RANK
     if (!listed && wave::lane() == 0) fprintf(stderr, "rank_update: general (all_new %d keys_valid %d disp_valid %d n_keys %u n_disp %u %u)\n", int(all_new), int(c.keys_valid), int(c.disp_valid), c.n_keys, c.n_disp[0], c.n_disp[1]);
 #endif

@@ -62,6 +62,7 @@ struct Cell {
   u32 pair_seq;
   u32 pair_interval;  // index of the task's interval (goes with every request)
   bool pair_on;       // a helper serves this epoch's requests (sampled once per epoch)
+  bool ring_lent;     // the generator (and its ring in LDS) is with the helper: pair_request .. pair_take_back
 #ifdef MODLE_PHASE_TIMERS
   u64 ph[16];     // profiling build: time spent per phase (wave::clock ticks)
 #endif
@@ -95,6 +96,10 @@ constexpr u32 REL_CAP = 2 * SORT_LDS_CAP;  // u32 entries in the LDS sort buffer
 // of the LDS sort buffer less one sentinel.  (Round 4: was STAGE_CAP = 256, which BASELINE configs[4]
 // -- 64 LEFs/Mb: 250-430 LEFs released per epoch on the large chromosomes -- exceeded in every epoch.)
 constexpr u32 RANK_KEY_CAP = SORT_LDS_CAP - 1;
+// ... and when the update borrows the generator's ring for its keys (sim_bind_rank.h); the ring's
+// contents wait at this offset (64-bit words) of ws.sort_keys, behind the scratch words of the sweeps
+constexpr u32 RANK_KEY_CAP_BIG = RNG_RING - 1;
+constexpr u32 RING_SPILL_AT = 64;
 constexpr u32 ERR_LIST_OVERFLOW = 1;
 constexpr u32 ERR_TRIAL_OVERFLOW = 2;
 constexpr u32 ERR_INTERNAL = 3;

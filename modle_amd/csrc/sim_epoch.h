@@ -78,6 +78,7 @@ MODLE_DEV void init_cell(Cell& c, const Params& p, const Interval& iv, const Wor
   // (the helper keeps counting the requests across the tasks of its main wave)
   c.pair_seq = lds.mbox != nullptr ? wave::uniform(lds.mbox[PAIR_REQ]) : 0u;
   c.pair_on = false;
+  c.ring_lent = false;
 #ifdef MODLE_PHASE_TIMERS
   for (int i = 0; i < 16; ++i) c.ph[i] = 0;
 #endif

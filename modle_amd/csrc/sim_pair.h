@@ -91,6 +91,7 @@ MODLE_DEV void pair_request(Cell& c, bool burnin_completed, u32 interval) {
     pair_put_u64(m, PAIR_GEN_END, c.g.gen_end);
   }
   ++c.pair_seq;
+  c.ring_lent = true;
   wave::st_release_wg(&m[PAIR_REQ], c.pair_seq);
 }
 // main wave: the fwd instance of LEF-BAR detection goes to the helper (n5, n3: BoundaryCounts)
@@ -163,6 +164,7 @@ MODLE_DEV bool pair_take_back(Cell& c) {
   c.g.gen_end = pair_get_u64(m, PAIR_GEN_END);
   c.n_hit[0] = wave::uniform(m[PAIR_N_HIT]);
   c.n_hit[1] = wave::uniform(m[PAIR_N_HIT + 1]);
+  c.ring_lent = false;
   return true;
 }
 // main wave, once per epoch: is there a helper to hand work to?

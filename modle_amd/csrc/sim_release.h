@@ -83,7 +83,7 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
   u32 n_disp_r = 0, n_disp_f = 0;
   u64* const disp_keys_r = reinterpret_cast<u64*>(ws.tmp[6]);
   u64* const disp_keys_f = reinterpret_cast<u64*>(ws.tmp[7]);
-  const u32 disp_cap = umin(RANK_KEY_CAP, ws.capacity_lefs / 2);
+  const u32 disp_cap = umin(RANK_KEY_CAP_BIG, ws.capacity_lefs / 2);
   const auto process_block = [&](const UnitRegs& g, u32 t) {
       const u32 w = 256 * t + 4 * lane;
       {

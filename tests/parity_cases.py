@@ -76,6 +76,20 @@ CASES = {
     "many_rebinds_per_epoch": dict(size=65_000_000, barriers=True,
                                    cfg=dict(num_cells=4, skip_burnin=1, avg_lef_processivity=25000,
                                             target_contact_density=0.004)),
+    # 600-900 re-inserted units per epoch and direction (2 400 LEFs at a processivity of 25 kb): more
+    # keys than the LDS sort buffer holds -- the one-sweep rank update keeps them in the generator's
+    # ring, whose contents wait in device memory and must come back bit for bit (the draws that follow
+    # read them): what BASELINE configs[4] does on chr1-chr12
+    "rebinds_beyond_sort_buffer": dict(size=120_000_000, barriers=True,
+                                       cfg=dict(num_cells=4, skip_burnin=1, avg_lef_processivity=25000,
+                                                target_contact_density=0.012)),
+    # the same with BASELINE configs[4]'s parameters on 190 Mb (12 160 LEFs): ~300 released LEFs AND
+    # several hundred units that went past a stalled neighbour per epoch and direction
+    "dense_stress_rebinds_and_displaced": dict(size=190_000_000, barriers=True,
+                                               cfg=dict(num_cells=4, skip_burnin=1, number_of_lefs_per_mbp=64.0,
+                                                        lef_bar_minor_collision_pblock=0.3,
+                                                        soft_stall_lef_stability_multiplier=2.0,
+                                                        target_contact_density=0.025)),
     # more LEFs than the LDS id filters have bits (32768): ids that share a bit pass the filters
     # together -- the release candidates' and the partner lookups' sweeps then store a few ranks
     # nobody asked for, and nothing else may change
