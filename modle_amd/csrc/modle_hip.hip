@@ -180,6 +180,9 @@ __device__ __forceinline__ void simulate_tasks(const SimArgs& a, const WaveLds& 
                                     a.max_lefs, a.max_barriers, a.params.hist_len);
   if (lds.pair_dynamic) pair_open(lds.mbox);  // this main wave is running: an idle wave may become its helper
   u32 finished_interval = 0xFFFFFFFFu;  // interval of the task this wave has just completed
+#ifdef MODLE_PHASE_TIMERS
+  const u64 t_enter = wave::clock();
+#endif
   for (;;) {
     // Pop one task.  Only lane 0 touches the counter, so this block branches on the lane id; the
     // wave barrier (a convergent operation the optimizer may not duplicate) and the laundered
@@ -200,6 +203,16 @@ __device__ __forceinline__ void simulate_tasks(const SimArgs& a, const WaveLds& 
     finished_interval = 0xFFFFFFFFu;
     t = wave::bcast(t, 0);  // scalar from here on: the queue loop is a scalar loop
     if (t >= a.n_tasks) {  // every wave leaves once the queue is empty
+#ifdef MODLE_PHASE_TIMERS
+      if (a.phase_ticks != nullptr && wave::lane() == 0) {
+        // how long this wave had work for: sum, longest, shortest (the launch lasts as long as the longest)
+        const unsigned long long busy = wave::clock() - t_enter;
+        unsigned long long* const pt = reinterpret_cast<unsigned long long*>(wave::as_global(a.phase_ticks));
+        atomicAdd(pt + 16, busy);
+        atomicMax(pt + 17, busy);
+        atomicMin(pt + 18, busy);
+      }
+#endif
       if (lds.mbox == nullptr) break;
       if (!lds.pair_dynamic) {
         pair_dismiss(lds.mbox);
@@ -231,7 +244,18 @@ __device__ __forceinline__ void simulate_tasks(const SimArgs& a, const WaveLds& 
       lds_t.trace = a.trace;
       lds_t.trace_cap = a.trace_cap;
     }
+#ifdef MODLE_PHASE_TIMERS
+    const u64 t_task = wave::clock();
+#endif
     const u32 st = simulate_cell(a.params, wave::as_global(a.intervals)[task.interval], task, ws, lds_t, res);
+#ifdef MODLE_PHASE_TIMERS
+    if (a.phase_ticks != nullptr) {  // (per task: start, end, wave slot -- MODLE_PROF_TASK_TIMES writes them out)
+      u64* const tt = wave::as_global(a.phase_ticks) + 20 + 3 * static_cast<u64>(t);
+      tt[0] = t_task;
+      tt[1] = wave::clock();
+      tt[2] = slot;
+    }
+#endif
     // all lanes store the same words (no lane-dependent branch at the end of the loop body)
     wave::as_global(a.results)[t] = res;
     wave::as_global(a.status)[t] = st;
@@ -839,8 +863,9 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
   }
   a.phase_ticks = nullptr;
 #ifdef MODLE_PHASE_TIMERS
-  HIP_TRY(h->d_phase_ticks.ensure(16));
-  HIP_TRY(hipMemsetAsync(h->d_phase_ticks.p, 0, 16 * 8, h->stream));
+  HIP_TRY(h->d_phase_ticks.ensure(20 + 3 * sorted.size()));
+  HIP_TRY(hipMemsetAsync(h->d_phase_ticks.p, 0, (20 + 3 * sorted.size()) * 8, h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_phase_ticks.p + 18, 0xFF, 8, h->stream));
   a.phase_ticks = h->d_phase_ticks.p;
 #endif
   a.workspace = h->d_workspace.p;
@@ -1000,7 +1025,7 @@ int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen) {
     static const char* names[16] = {"burnin_stats", "bind", "rank_rev", "rank_fwd", "sample", "gen_moves",
                                     "adjust_moves", "barriers+clear", "boundaries", "lef_bar", "primary",
                                     "secondary", "fix_secondary", "extrude_release", "lef_activation", "cell_total"};
-    u64 ticks[16];
+    u64 ticks[20];
     HIP_TRY(hipMemcpy(ticks, h->d_phase_ticks.p, sizeof(ticks), hipMemcpyDeviceToHost));
     u64 total = 0;
     for (int i = 0; i < 14; ++i) total += ticks[i];
@@ -1009,6 +1034,9 @@ int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen) {
       if (i < 14 || ticks[i] != 0)  // (14, 15: free for a measurement inside a phase)
       std::fprintf(stderr, "  %-16s %12.3f s  %5.1f %%\n", names[i], static_cast<double>(ticks[i]) * 1e-8,
                    total ? 100.0 * static_cast<double>(ticks[i]) / static_cast<double>(total) : 0.0);
+    std::fprintf(stderr, "  main waves with work: sum %.3f s, longest %.3f s, shortest %.3f s\n",
+                 static_cast<double>(ticks[16]) * 1e-8, static_cast<double>(ticks[17]) * 1e-8,
+                 static_cast<double>(ticks[18]) * 1e-8);
   }
 #endif
   std::vector<CellResult> res(h->n_launched);
@@ -1016,6 +1044,20 @@ int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen) {
   HIP_TRY(hipMemcpy(res.data(), h->d_results.p, res.size() * sizeof(CellResult),
                     hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(status.data(), h->d_status.p, status.size() * 4, hipMemcpyDeviceToHost));
+#ifdef MODLE_PHASE_TIMERS
+  if (const char* path = std::getenv("MODLE_PROF_TASK_TIMES")) {
+    std::vector<u64> tt(3 * h->n_launched);
+    HIP_TRY(hipMemcpy(tt.data(), h->d_phase_ticks.p + 20, tt.size() * 8, hipMemcpyDeviceToHost));
+    if (FILE* f = std::fopen(path, "w")) {
+      // (queue order: interval, start, end in ticks, wave slot, epochs, burn-in epochs)
+      for (size_t i = 0; i < h->n_launched; ++i)
+        std::fprintf(f, "%d %llu %llu %llu %llu %llu\n", h->launch_map[i].first, (unsigned long long)tt[3 * i],
+                     (unsigned long long)tt[3 * i + 1], (unsigned long long)tt[3 * i + 2],
+                     (unsigned long long)res[i].epochs, (unsigned long long)res[i].burnin_epochs);
+      std::fclose(f);
+    }
+  }
+#endif
   int rc = MODLE_HIP_OK;
   for (size_t i = 0; i < res.size(); ++i) {
     const auto [iv, idx] = h->launch_map[i];
