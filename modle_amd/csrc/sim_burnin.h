@@ -136,6 +136,60 @@ MODLE_DEV f64 fold_terms_in_lane_order(f64 ssd, f64 term, f64* buf) {
   return ssd;
 }
 
+// 64-lane inclusive prefix sum of doubles on the lane moves of the integer scans.  Exact -- and so
+// independent of the order of the additions -- wherever fold_terms_exact uses it: multiples of one
+// unit in the last place whose sum stays below 2^53 units.
+MODLE_DEV f64 wave_prefix_sum_f64(f64 v) {
+#define MODLE_STEP(S)                                                                            \
+  {                                                                                              \
+    const u64 b = __builtin_bit_cast(u64, v);                                                    \
+    const u32 lo = wave::scan_move<S>(static_cast<u32>(b), 0u);                                  \
+    const u32 hi = wave::scan_move<S>(static_cast<u32>(b >> 32), 0u);                            \
+    v = v + __builtin_bit_cast(f64, (static_cast<u64>(hi) << 32) | lo);                          \
+  }
+  MODLE_SCAN_STEPS(MODLE_STEP)
+#undef MODLE_STEP
+  return v;
+}
+
+// The same fold -- 64 terms in lane order, every addition rounded like std::accumulate rounds it --
+// without the chain of 64 dependent additions (14 cycles each: 3.4 % of the default launch).  While the
+// running sum s stays inside one binade [B, 2B), u = ulp(s):
+//     fl(s + t) = s + q(t),   q(t) = t rounded to the nearest multiple of u = (B + t) - B in fp64,
+// unless the rounding is a tie (the parity of s / u decides) or the sum reaches 2B; and multiples of u
+// whose sum stays below 2B add up exactly in any order.  So one prefix sum folds the lanes up to the
+// first one that ties or crosses; that lane takes a true addition, and the lanes behind it start
+// again in what may be the next binade.  A batch needs 0.24 such additions on average (ties: 64 x
+// 2^-(bits of t below u), about one batch in twenty; ~12 binades per fold); a batch that needs more than
+// three, and a running sum of zero, go through the chain.  The scalar rendition of exactly this is
+// checked against the sequential sum in tests/fold_model (ties, crossings, zero / huge terms).
+MODLE_DEV f64 fold_terms_exact(f64 ssd, f64 term, f64* buf) {
+  const u32 lane = wave::lane();
+  f64 s = ssd;  // (every lane holds the same value)
+  u32 start = 0;
+  for (u32 it = 0; it < 3; ++it) {
+    const u32 ef = static_cast<u32>(wave::uniform(__builtin_bit_cast(u64, s)) >> 52) & 0x7FFu;
+    if (ef <= 53u || ef == 0x7FFu) break;  // zero, tiny, not finite: the chain
+    const f64 B = __builtin_bit_cast(f64, static_cast<u64>(ef) << 52);
+    const f64 top = B + B;
+    const f64 u_half = __builtin_bit_cast(f64, static_cast<u64>(ef - 53u) << 52);
+    const bool in = lane >= start;
+    const f64 t = in ? term : 0.0;
+    const f64 q = (B + t) - B;
+    const f64 P = wave_prefix_sum_f64(q);
+    const bool bad = in && (wave::f_abs(t - q) == u_half || !(s + P < top));
+    const u64 bm = wave::ballot(bad);
+    if (bm == 0) return s + wave::bcast(P, 63);
+    const u32 fb = static_cast<u32>(wave::ctz64(bm));
+    if (fb > start) s = s + wave::bcast(P, fb - 1);
+    s = s + wave::bcast(term, fb);
+    start = fb + 1;
+    if (start == 64) return s;
+  }
+  // (adding +0.0 leaves the non-negative running sum as it is)
+  return fold_terms_in_lane_order(s, lane >= start ? term : 0.0, buf);
+}
+
 // The same statistics without scattering 4-byte stores over device memory (round 4).  The two
 // id-ordered scatters of loop_size_stats_scattered -- one store per unit into a random line -- were
 // the most expensive memory traffic of the kernel: a second pair of them cost 8.3 % of the launch
@@ -275,7 +329,7 @@ MODLE_DEV LoopStats loop_size_stats_partitioned(Cell& c, u64* pairs_r, u64* pair
         const f64 d = static_cast<f64>(static_cast<u64>(ls)) - avg;
         term = d * d;
       }
-      ssd = fold_terms_in_lane_order(ssd, term, terms);
+      ssd = fold_terms_exact(ssd, term, terms);
     }
 #ifdef MODLE_SUBTIMER_STATS
     c.ph[15] += wave::clock() - t_fold;  // (the fold alone)

@@ -83,6 +83,13 @@ CASES = {
     "rebinds_beyond_sort_buffer": dict(size=120_000_000, barriers=True,
                                        cfg=dict(num_cells=4, skip_burnin=1, avg_lef_processivity=25000,
                                                 target_contact_density=0.012)),
+    # the same through a burn-in (ended by --max-burnin-epochs): in helper-wave mode the generator and
+    # its ring are with the helper while the main wave ranks the units of a burn-in epoch -- the ring is
+    # not the main wave's to borrow, the update takes the general form -- and with one wave per cell the
+    # statistics' windows and the borrowed ring alternate in the same LDS
+    "rebinds_beyond_sort_buffer_burnin": dict(size=120_000_000, barriers=True,
+                                              cfg=dict(num_cells=4, avg_lef_processivity=25000,
+                                                       max_burnin_epochs=60, target_contact_density=0.002)),
     # the same with BASELINE configs[4]'s parameters on 190 Mb (12 160 LEFs): ~300 released LEFs AND
     # several hundred units that went past a stalled neighbour per epoch and direction
     "dense_stress_rebinds_and_displaced": dict(size=190_000_000, barriers=True,

@@ -14,7 +14,7 @@ from parity_cases import assert_same_outputs, assert_same_results, build_case
                                          ("dense_barriers_trials", 1),
                                          ("ultra_dense_barriers_trials", 1), ("mass_release", 1),
                                          ("many_lefs_hashed_filters", 1), ("many_rebinds_per_epoch", 1),
-                                         ("rebinds_beyond_sort_buffer", 1),
+                                         ("rebinds_beyond_sort_buffer", 1), ("rebinds_beyond_sort_buffer_burnin", 1),
                                          ("dense_stress_rebinds_and_displaced", 1),
                                          ("burnin_three_windows", 1)])
 def test_emulated_device_code_matches_oracle(oracle, name, ncells):

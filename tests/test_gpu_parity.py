@@ -14,7 +14,7 @@ NCELLS = {"config0_5mb_nobarriers": 64, "chr20mb_barriers": 96, "chr12mb_dense_s
           "zero_target_cells": 128, "epochs_stop_tad_only": 16, "window_near_position_limit": 64,
           "dense_barriers_trials": 8, "ultra_dense_barriers_trials": 4, "mass_release": 4,
           "many_lefs_hashed_filters": 2, "many_rebinds_per_epoch": 4,
-          "rebinds_beyond_sort_buffer": 4, "dense_stress_rebinds_and_displaced": 4,
+          "rebinds_beyond_sort_buffer": 4, "rebinds_beyond_sort_buffer_burnin": 4, "dense_stress_rebinds_and_displaced": 4,
           "burnin_three_windows": 12}
 
 

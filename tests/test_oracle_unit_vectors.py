@@ -65,3 +65,16 @@ def test_loop_stats_bit_identical_on_random_loops(oracle):
         fwd = rev + rng.integers(0, 3_000_000, size=n).astype(np.uint64)
         a, b = be_o.loop_stats(rev, fwd), be_d.loop_stats(rev, fwd)
         assert a["mean"] == b["mean"] and a["std"] == b["std"], n
+    # shapes that are hard for the device's fold (it replaces the chain of dependent additions by exact
+    # prefix sums between the additions that tie or cross a binade, sim_burnin.h: fold_terms_exact):
+    # tiny integers with a dyadic mean (every rounding a tie or exact), all equal (running sum zero),
+    # two values, rare huge terms, powers of two
+    for shape, n in [(s, n) for s in range(6) for n in (64, 1000, 4096, 5000)]:
+        rev = rng.integers(1, 200_000_000, size=n).astype(np.uint64)
+        size = [rng.integers(0, 4, size=n), np.full(n, 12345), rng.integers(0, 2, size=n) * 1_000_000,
+                np.where(rng.integers(0, 64, size=n) == 0, 4_000_000_000, rng.integers(0, 100, size=n)),
+                1 << rng.integers(0, 31, size=n), np.where(rng.integers(0, 2, size=n) == 0, 0,
+                                                            rng.integers(0, 200_000_000, size=n))][shape]
+        fwd = rev + size.astype(np.uint64)
+        a, b = be_o.loop_stats(rev, fwd), be_d.loop_stats(rev, fwd)
+        assert a["mean"] == b["mean"] and a["std"] == b["std"], (shape, n)
