@@ -785,6 +785,15 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
   HIP_TRY(h->d_tasks.ensure(sorted.size()));
   HIP_TRY(h->d_results.ensure(sorted.size()));
   HIP_TRY(h->d_status.ensure(sorted.size()));
+#ifdef MODLE_EXP_REALLOC  // (measurement: does the placement of the workspace decide which of a box's two speeds a process runs at?)
+  {
+    static DevBuf<char> hole;  // a hole of a different size in front of every new workspace
+    static int launches = 0;
+    h->d_workspace.reset();
+    hole.reset();
+    (void)hole.ensure(static_cast<size_t>(1 + (launches++ * 37) % 200) << 20);
+  }
+#endif
   HIP_TRY(h->d_workspace.ensure(layout.total_bytes * n_slots));
   if (h->remaining_cap < ivs.size()) {
     if (h->h_remaining != nullptr) (void)hipHostFree(h->h_remaining);
