@@ -111,7 +111,7 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
         if (w + 3 < n) {
           wave::st4(ws.r_pos, w, nr);
           wave::st4(ws.f_pos, w, nf);
-          const wave::U32x4 zero = {{0, 0, 0, 0}};
+          const wave::U32x4 zero = wave::zero4();
           if (rc_any) wave::st4(ws.r_coll, w, zero);
           if (fc_any) wave::st4(ws.f_coll, w, zero);
         } else {
@@ -267,7 +267,7 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
     }
     if (hard_any) {
       if (w + 3 < n) {
-        const wave::U32x4 zero = {{0, 0, 0, 0}};
+        const wave::U32x4 zero = wave::zero4();
         wave::st4(ws.stall, w, zero);
       } else {
 #pragma unroll

@@ -88,6 +88,7 @@ struct U32x4 {
   uint32_t v[4];
 };
 MODLE_DEV U32x4 ld4(const uint32_t* p, uint32_t k) { return U32x4{{p[k], p[k + 1], p[k + 2], p[k + 3]}}; }
+MODLE_DEV U32x4 zero4() { return U32x4{{0, 0, 0, 0}}; }
 MODLE_DEV void st4(uint32_t* p, uint32_t k, const U32x4& x) {
   for (int q = 0; q < 4; ++q) p[k + q] = x.v[q];
 }

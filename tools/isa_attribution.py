@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--hot-depth", type=int, default=3,
                     help="loop depth from which an instruction counts as `hot` (task loop 1, epoch loop 2, sweeps 3)")
     ap.add_argument("--sort", default="all")
+    ap.add_argument("--check-hot-scratch", action="store_true",
+                    help="exit 1 when a vector register is reloaded from scratch inside a sweep")
     args = ap.parse_args()
 
     files = {}
@@ -120,6 +122,7 @@ def main():
         d += depth_delta[i]
         depth.append(d)
     body_index = -1
+    scratch_hot = []
     with open(args.asm) as f:
         for line in f:
             m = filedir.match(line)
@@ -145,6 +148,10 @@ def main():
                 continue
             op = s.split()[0]
             kind = classify(op, s.split(";")[0])
+            if op.startswith("scratch_load") and depth[body_index] >= args.hot_depth:
+                # a VECTOR register reloaded from scratch inside a sweep: a memory round trip per block in
+                # front of whatever uses it (round 4: two builds 2 % slower for four of these)
+                scratch_hot.append(f"{cur[0]}:{cur[1]}  {s.split(';')[0].strip()}")
             if kind == "spill_rd" and depth[body_index] >= args.hot_depth:
                 per_func_hot_key = True
             else:
@@ -173,6 +180,11 @@ def main():
     for c in per_func.values():
         tot.update(c)
     print("kernel", args.kernel, " ".join(f"{k}={tot[k]}" for k in kinds))
+    print(f"vector-register reloads from scratch inside sweeps (loop depth >= {args.hot_depth}): {len(scratch_hot)}")
+    for x in scratch_hot:
+        print("   ", x)
+    if args.check_hot_scratch:
+        return 1 if scratch_hot else 0
     if args.lines:
         rows = [(c["all"], ln, c) for (fn, ln), c in per_line.items() if fn == args.lines]
         rows.sort(reverse=True)
