@@ -1579,7 +1579,7 @@ struct SecondaryFilter {
       const u32 q = FWD ? 3 - j : j;
       k[j] = w + q;
       act[j] = k[j] < n;
-      P[j] = g.P.v[q];
+      P[j] = act[j] ? g.P.v[q] : 0u;  // (ranks past the end: what follows the array; never used, and not passed around either)
       C[j] = act[j] ? g.C.v[q] : 0u;
       const u32 M0 = g.M.v[q];
       M[j] = M0;

@@ -22,6 +22,16 @@ int main(int argc, char** argv) {
   cfg.num_cells = 8;
   cfg.simulate_chromosomes_wo_barriers = 1;
   if (!with_barriers) cfg.number_of_lefs_per_mbp = 16.0;
+  // optional: LEFs per Mb, processivity, skip the burn-in, target contact density (the regimes of the
+  // rank update that borrows the generator's ring, of BASELINE configs[4], ...)
+  if (argc > 4 && atof(argv[4]) > 0) cfg.number_of_lefs_per_mbp = atof(argv[4]);
+  if (argc > 5 && atof(argv[5]) > 0) cfg.avg_lef_processivity = static_cast<uint64_t>(atof(argv[5]));
+  if (argc > 6) cfg.skip_burnin = atoi(argv[6]) != 0;
+  if (argc > 7 && atof(argv[7]) > 0) cfg.target_contact_density = atof(argv[7]);
+  if (argc > 8 && atof(argv[8]) > 0) {
+    cfg.lef_bar_minor_collision_pblock = atof(argv[8]);
+    cfg.soft_stall_lef_stability_multiplier = 2.0;
+  }
   char err[256];
   if (modle_hip_config_transform(&cfg, err, sizeof(err)) < 0) return 2;
   std::vector<uint64_t> bp;
