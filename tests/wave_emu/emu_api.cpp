@@ -151,7 +151,48 @@ void phase_body(void* arg) {
 
 }  // namespace
 
+#ifdef MODLE_EMU_WRITE_TRACE
+namespace emu_wtrace {
+// the running cell's workspace, its last snapshot, and where the cell's readings stand: 0 = the cell's own
+// first reading (sim_epoch.h: t_cell), then begin / end of a phase in turn
+static const unsigned char* g_base = nullptr;
+static size_t g_size = 0;
+static std::vector<unsigned char> g_snap;
+static int g_state = 0;
+void start_cell(const void* base, size_t size) {
+  g_base = static_cast<const unsigned char*>(base);
+  g_size = size;
+  g_snap.assign(size, 0);
+  g_state = 0;
+}
+uint64_t tick() {
+  if (g_state == 0) {
+    g_state = 1;
+    return 0;
+  }
+  if (g_state == 1) {  // a phase begins
+    memcpy(g_snap.data(), g_base, g_size);
+    g_state = 2;
+    return 0;
+  }
+  uint64_t changed = 0;  // a phase ends: 32-bit words that differ, in bytes
+  for (size_t i = 0; i + 4 <= g_size; i += 4) changed += memcmp(g_base + i, g_snap.data() + i, 4) != 0 ? 4 : 0;
+  g_state = 1;
+  return changed;
+}
+}  // namespace emu_wtrace
+static uint64_t g_phase_bytes[16];
+#endif
+
 extern "C" {
+
+#ifdef MODLE_EMU_WRITE_TRACE
+// bytes of device memory changed per phase (slot numbering of the PHASE macro), summed over the cells run so far
+void emu_write_trace_read(uint64_t out[16], int reset) {
+  memcpy(out, g_phase_bytes, sizeof(g_phase_bytes));
+  if (reset) memset(g_phase_bytes, 0, sizeof(g_phase_bytes));
+}
+#endif
 
 void emu_set_lane_schedule(unsigned schedule) { wave_emu::set_lane_schedule(schedule); }
 
@@ -217,6 +258,10 @@ int emu_simulate_interval(const modle_hip_config* cfg, uint64_t start, uint64_t 
       view.trace = trace.data();
       view.trace_cap = 4096;
     }
+#ifdef MODLE_EMU_WRITE_TRACE
+    view.phase_ticks = g_phase_bytes;
+    emu_wtrace::start_cell(wsmem.data(), layout.total_bytes);
+#endif
     CellJob job{&p, &img.iv, &task,
                 modle_host::carve_workspace(wsmem.data(), static_cast<u32>(max_lefs),
                                             static_cast<u32>(n_barriers), p.hist_len),

@@ -177,7 +177,28 @@ MODLE_DEV void sync_mem(int line = __builtin_LINE()) { (void)wave_emu::collectiv
 MODLE_DEV void sync_lds(int line = __builtin_LINE()) { (void)wave_emu::collective(0, 0, line); }
 MODLE_DEV void lockstep(int line = __builtin_LINE()) { (void)wave_emu::collective(0, 0, line); }
 
+#ifndef MODLE_EMU_WRITE_TRACE
 MODLE_DEV uint64_t clock() { return 0; }
+#else
+// Write-trace build (tools/emu_write_trace.py): compiled with MODLE_PHASE_TIMERS, whose PHASE macro reads
+// the clock before and after every phase and adds the difference to the phase's slot.  Here the "clock"
+// counts bytes: the first reading of a pair snapshots the cell's workspace and returns 0, the second
+// returns the number of bytes that differ from the snapshot -- so the slots end up holding the bytes of
+// device memory each phase CHANGED (a lower bound of what it wrote: a value written again does not
+// count).  All lanes arrive (two barriers), lane 0 does the work.
+}  // namespace wave
+namespace emu_wtrace {
+uint64_t tick();
+}
+namespace wave {
+MODLE_DEV uint64_t clock(int line = __builtin_LINE()) {
+  (void)wave_emu::collective(0, 0, line);
+  uint64_t w[2] = {0, 0};
+  if (lane() == 0) w[0] = emu_wtrace::tick();
+  const wave_emu::Slot* s = wave_emu::collective(w[0], w[1], line);
+  return s[0].v[0];
+}
+#endif
 MODLE_DEV void pin(uint32_t&) {}
 MODLE_DEV void launder(uint32_t&) {}
 MODLE_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }
