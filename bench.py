@@ -299,7 +299,15 @@ def main():
 
     timing = os.environ.get("MODLE_BENCH_TIMING", "") not in ("", "0")  # (diagnostic: host time per part of a step)
 
+    alternate = os.environ.get("MODLE_BENCH_ALTERNATE_TAIL", "") not in ("", "0")  # (diagnostic, see below)
+    n_step = [0]
+
     def step(first, last=False):
+        if alternate:
+            # diagnostic: tail helpers on / off in turn INSIDE one process -- two processes on one box differ
+            # by 2 % whatever they run (profiles/r04z), which is more than what is being asked about
+            os.environ["MODLE_HIP_TAIL_HELPERS"] = "1" if n_step[0] % 2 == 0 else "0"
+            n_step[0] += 1
         t_a = time.perf_counter()
         if not first:
             for entry, iid in zip(plan, ids):
@@ -356,7 +364,8 @@ def main():
         if timing:
             t_d = time.perf_counter()
             print(f"[bench timing] submit + zero {1e3 * (t_b - t_a):.1f} ms, launch {1e3 * (t_c - t_b):.1f} ms, "
-                  f"wait + collect {1e3 * (t_d - t_c):.1f} ms (kernel {kernel_ms[-1]:.1f} ms)", file=sys.stderr)
+                  f"wait + collect {1e3 * (t_d - t_c):.1f} ms (kernel {kernel_ms[-1]:.1f} ms)"
+                  + (f" tail helpers {os.environ['MODLE_HIP_TAIL_HELPERS']}" if alternate else ""), file=sys.stderr)
 
     def sync():
         torch.cuda.synchronize(dev)
