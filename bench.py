@@ -299,14 +299,18 @@ def main():
 
     timing = os.environ.get("MODLE_BENCH_TIMING", "") not in ("", "0")  # (diagnostic: host time per part of a step)
 
-    alternate = os.environ.get("MODLE_BENCH_ALTERNATE_TAIL", "") not in ("", "0")  # (diagnostic, see below)
+    # diagnostic: a switch the library reads at every launch, changed from step to step INSIDE one process --
+    # two processes on one box differ by 2 % whatever they run (profiles/r04z), the steps of one by 0.1 %.
+    #   MODLE_BENCH_ALTERNATE="MODLE_HIP_EXP=0,1"     (MODLE_BENCH_ALTERNATE_TAIL=1: "MODLE_HIP_TAIL_HELPERS=1,0")
+    alternate = os.environ.get("MODLE_BENCH_ALTERNATE", "")
+    if os.environ.get("MODLE_BENCH_ALTERNATE_TAIL", "") not in ("", "0"):
+        alternate = "MODLE_HIP_TAIL_HELPERS=1,0"
+    alt_var, alt_values = (alternate.split("=")[0], alternate.split("=")[1].split(",")) if alternate else (None, [])
     n_step = [0]
 
     def step(first, last=False):
         if alternate:
-            # diagnostic: tail helpers on / off in turn INSIDE one process -- two processes on one box differ
-            # by 2 % whatever they run (profiles/r04z), which is more than what is being asked about
-            os.environ["MODLE_HIP_TAIL_HELPERS"] = "1" if n_step[0] % 2 == 0 else "0"
+            os.environ[alt_var] = alt_values[n_step[0] % len(alt_values)]
             n_step[0] += 1
         t_a = time.perf_counter()
         if not first:
@@ -365,7 +369,7 @@ def main():
             t_d = time.perf_counter()
             print(f"[bench timing] submit + zero {1e3 * (t_b - t_a):.1f} ms, launch {1e3 * (t_c - t_b):.1f} ms, "
                   f"wait + collect {1e3 * (t_d - t_c):.1f} ms (kernel {kernel_ms[-1]:.1f} ms)"
-                  + (f" tail helpers {os.environ['MODLE_HIP_TAIL_HELPERS']}" if alternate else ""), file=sys.stderr)
+                  + (f" {alt_var}={os.environ[alt_var]}" if alternate else ""), file=sys.stderr)
 
     def sync():
         torch.cuda.synchronize(dev)

@@ -820,6 +820,10 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
 
   SimArgs a;
   a.params = h->params;
+#ifdef MODLE_EXP_SWITCH
+  a.params.exp_flags = std::getenv("MODLE_HIP_EXP") != nullptr ? static_cast<u32>(std::atoi(std::getenv("MODLE_HIP_EXP"))) : 0u;
+  a.params.exp_pad_ = 0;
+#endif
   a.tables.jump = h->d_jump.p;
   a.tables.zig = h->d_zig.p;
   a.intervals = h->d_intervals.p;

@@ -69,6 +69,13 @@ struct Params {
   u32 hist_len;   // burnin_history_length
   u32 window;     // burnin_smoothing_window_size
   u32 track_1d;
+#ifdef MODLE_EXP_SWITCH
+  // measurement builds (make exp FLAGS=-DMODLE_EXP_SWITCH): switches read from MODLE_HIP_EXP at every launch,
+  // so that ONE process compares two forms of a piece of code (bench.py: MODLE_BENCH_ALTERNATE) -- the
+  // steps of a process agree to 0.1 %, two processes differ by 2 % (profiles/r04z)
+  u32 exp_flags;
+  u32 exp_pad_;
+#endif
 };
 
 struct Interval {
