@@ -1,43 +1,47 @@
-"""The device code under the lane emulator AND the sanitizers (the GPU has none on this pool): MemorySanitizer (tests/wave_emu: `make msan_emu`, clang):
-whole cells in the regimes that use the most scratch -- a burn-in whose rank updates borrow the generator's
-ring (2 400 LEFs at a processivity of 25 kb), and BASELINE configs[4]'s parameters with Bernoulli trials --
-must not read a word of LDS or workspace that nothing has written (the harness poisons both)."""
+"""The device code under the lane emulator AND the sanitizers (the GPU has none on this pool).  Whole cells in
+the regimes that use the most scratch -- a burn-in whose rank updates borrow the generator's ring (2 400 LEFs
+at a processivity of 25 kb), BASELINE configs[4]'s parameters with Bernoulli trials, a small default cell --
+under MemorySanitizer (tests/wave_emu: `make msan_emu`, clang: no word of LDS or workspace is read that nothing
+has written; the harness poisons both) and under gcc's Address + UndefinedBehavior sanitizers (`make asan_emu`)."""
 import os
-import shutil
 import subprocess
 
 import pytest
 
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU = os.path.join(HERE, "wave_emu")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 # size, barriers, cells, LEFs per Mb, processivity, skip burn-in, target contact density, minor pblock
 REGIMES = (["120000000", "1", "1", "20", "25000", "0", "0.002"],
            ["60000000", "1", "1", "64", "0", "1", "0.01", "0.3"],
-           ["5000000", "0", "1"])
+           ["8000000", "1", "1", "0", "0", "0", "0.1"])  # (defaults: burn-in + contact sampling, barriers)
 
-HERE = os.path.dirname(os.path.abspath(__file__))
-CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+@pytest.fixture(scope="module")
+def builds():
+    """both sanitizer builds, side by side (a minute each)"""
+    procs = {t: subprocess.Popen(["make", "-C", EMU, t], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for t in ("msan_emu", "asan_emu")}
+    return {t: (p.communicate()[0], p.returncode) for t, p in procs.items()}
+
+
+def run_regimes(exe, marks):
+    for args in REGIMES:
+        run = subprocess.run([exe] + args, capture_output=True, text=True, timeout=900)
+        assert not any(m in run.stderr for m in marks), run.stderr[:3000]
+        assert run.returncode == 0 and "rc=0" in run.stdout, (run.stdout, run.stderr[:1000])
 
 
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="needs clang++ with MemorySanitizer")
-def test_whole_cells_read_no_uninitialised_memory():
-    emu = os.path.join(HERE, "wave_emu")
-    build = subprocess.run(["make", "-C", emu, "msan_emu"], capture_output=True, text=True)
-    if build.returncode != 0 and "msan" in (build.stderr + build.stdout).lower():
+def test_whole_cells_read_no_uninitialised_memory(builds):
+    out, rc = builds["msan_emu"]
+    if rc != 0 and "msan" in out.lower():
         pytest.skip("MemorySanitizer runtime not available")
-    assert build.returncode == 0, build.stderr[-2000:]
-    exe = os.path.join(emu, "msan_emu")
-    for args in REGIMES:
-        run = subprocess.run([exe] + args, capture_output=True, text=True, timeout=900)
-        assert "MemorySanitizer" not in run.stderr, run.stderr[:3000]
-        assert run.returncode == 0 and "rc=0" in run.stdout, (run.stdout, run.stderr[:1000])
+    assert rc == 0, out[-2000:]
+    run_regimes(os.path.join(EMU, "msan_emu"), ("MemorySanitizer",))
 
 
-def test_whole_cells_under_address_and_undefined_behaviour_sanitizers():
-    """the same cells under gcc's AddressSanitizer + UndefinedBehaviorSanitizer (`make asan_emu`)"""
-    emu = os.path.join(HERE, "wave_emu")
-    build = subprocess.run(["make", "-C", emu, "asan_emu"], capture_output=True, text=True)
-    assert build.returncode == 0, build.stderr[-2000:]
-    exe = os.path.join(emu, "asan_emu")
-    for args in REGIMES:
-        run = subprocess.run([exe] + args, capture_output=True, text=True, timeout=900)
-        assert "Sanitizer" not in run.stderr and "runtime error" not in run.stderr, run.stderr[:3000]
-        assert run.returncode == 0 and "rc=0" in run.stdout, (run.stdout, run.stderr[:1000])
+def test_whole_cells_under_address_and_undefined_behaviour_sanitizers(builds):
+    out, rc = builds["asan_emu"]
+    assert rc == 0, out[-2000:]
+    run_regimes(os.path.join(EMU, "asan_emu"), ("Sanitizer", "runtime error"))
