@@ -503,7 +503,9 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
   // searches below that overshoots reads it, through one `v_min` on the index, instead of testing
   // its range; n_new <= key_cap, one less than the buffer holds)
   if (lane == 0) keys[n_new] = ~u64(0);
-  // (the count every key starts from: no carried-over unit follows it)
+  // (the count every key starts from: no carried-over unit follows it.  Key j was written by whichever
+  // lane listed it: the read-modify-write below is another lane's, so the writes have to be complete)
+  wave::sync_lds();
   if (narrow) {
     for (u32 j = lane; j < n_new; j += 64) keys[j] |= n_old;
   } else {

@@ -8,7 +8,11 @@ from modle_amd import api
 from parity_cases import assert_same_outputs, assert_same_results
 
 
-@pytest.mark.parametrize("seed", [100, 101, 105, 108, 1148])
+# (790172: round 4 -- 70 re-inserted units of 395 with displaced units listed by other lanes than the ones that
+# initialise their counts: a read-modify-write of LDS across lanes without a barrier in between.  The GPU
+# executes a wave's LDS operations in order and never saw it; the emulator runs the lanes one after the
+# other and crashed in the release that followed the broken rank order)
+@pytest.mark.parametrize("seed", [100, 101, 105, 108, 1148, 790172])
 def test_emulated_device_code_matches_oracle_on_random_setups(oracle, seed):
     _compare(oracle, random_case(seed), f"seed {seed}")
 
