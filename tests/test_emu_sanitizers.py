@@ -2,7 +2,11 @@
 the regimes that use the most scratch -- a burn-in whose rank updates borrow the generator's ring (2 400 LEFs
 at a processivity of 25 kb), BASELINE configs[4]'s parameters with Bernoulli trials, a small default cell --
 under MemorySanitizer (tests/wave_emu: `make msan_emu`, clang: no word of LDS or workspace is read that nothing
-has written; the harness poisons both) and under gcc's Address + UndefinedBehavior sanitizers (`make asan_emu`)."""
+has written; the harness poisons both), under gcc's Address + UndefinedBehavior sanitizers (`make asan_emu`), and
+-- every lane a thread, every collective a barrier -- under ThreadSanitizer (`make tsan_emu`): a word that one
+lane writes and another touches without a collective in between is a reported race (round 4: the rank update
+seeded the counts inside its keys by a read-modify-write across lanes with no barrier behind the writes; the
+GPU executes a wave's LDS operations in order and 16 000 fuzz seeds never differed, the lane emulator broke)."""
 import os
 import subprocess
 
@@ -19,9 +23,9 @@ REGIMES = (["120000000", "1", "1", "20", "25000", "0", "0.002"],
 
 @pytest.fixture(scope="module")
 def builds():
-    """both sanitizer builds, side by side (a minute each)"""
+    """the three sanitizer builds, side by side (a minute each)"""
     procs = {t: subprocess.Popen(["make", "-C", EMU, t], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-             for t in ("msan_emu", "asan_emu")}
+             for t in ("msan_emu", "asan_emu", "tsan_emu")}
     return {t: (p.communicate()[0], p.returncode) for t, p in procs.items()}
 
 
@@ -45,3 +49,20 @@ def test_whole_cells_under_address_and_undefined_behaviour_sanitizers(builds):
     out, rc = builds["asan_emu"]
     assert rc == 0, out[-2000:]
     run_regimes(os.path.join(EMU, "asan_emu"), ("Sanitizer", "runtime error"))
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="needs clang++ with ThreadSanitizer")
+def test_no_lane_touches_what_another_wrote_without_a_collective(builds):
+    out, rc = builds["tsan_emu"]
+    if rc != 0 and "tsan" in out.lower():
+        pytest.skip("ThreadSanitizer runtime not available")
+    assert rc == 0, out[-2000:]
+    exe = os.path.join(EMU, "tsan_emu")
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0")
+    # 400 LEFs at a processivity of 300 kb (more than 64 re-inserted units per rank update); trials; a burn-in
+    for args in (["5000000", "1", "1", "80", "300000", "1", "0.05"],
+                 ["30000000", "1", "1", "40", "0", "1", "0.01", "0.3"],
+                 ["2000000", "1", "1", "0", "0", "0", "0.02", "0", "140"]):  # (burn-in cut at 140 epochs)
+        run = subprocess.run([exe] + args, capture_output=True, text=True, timeout=1200, env=env)
+        assert "ThreadSanitizer" not in run.stderr, run.stderr[:4000]
+        assert run.returncode == 0 and "rc=0" in run.stdout, (run.stdout, run.stderr[:1000])

@@ -32,6 +32,7 @@ int main(int argc, char** argv) {
     cfg.lef_bar_minor_collision_pblock = atof(argv[8]);
     cfg.soft_stall_lef_stability_multiplier = 2.0;
   }
+  if (argc > 9 && atoi(argv[9]) > 0) cfg.max_burnin_epochs = static_cast<uint64_t>(atoi(argv[9]));
   char err[256];
   if (modle_hip_config_transform(&cfg, err, sizeof(err)) < 0) return 2;
   std::vector<uint64_t> bp;

@@ -1,9 +1,40 @@
 // wave_emu.cpp -- fiber scheduler of the lane emulator (see wave_emu.h).  TEST INFRASTRUCTURE.
 #include "wave_emu.h"
 
+#ifdef MODLE_EMU_THREADS
+#include <pthread.h>
+
+#include <thread>
+#include <vector>
+#endif
+
 namespace wave_emu {
 
 thread_local WaveRuntime* g_rt = nullptr;
+#ifdef MODLE_EMU_THREADS
+// every lane a thread, every collective a barrier (wave_emu.h)
+thread_local int t_lane = 0;
+static pthread_barrier_t g_barrier;
+void threads_barrier() { pthread_barrier_wait(&g_barrier); }
+void set_lane_schedule(unsigned) {}
+void run_wave(void (*body)(void*), void* arg) {
+  WaveRuntime rt;
+  memset(&rt, 0, sizeof(rt));
+  for (int l = 0; l < kLanes; ++l)
+    for (int b = 0; b < 2; ++b) rt.slots[b][l].line = -1;
+  pthread_barrier_init(&g_barrier, nullptr, kLanes);
+  std::vector<std::thread> lanes;
+  for (int l = 0; l < kLanes; ++l)
+    lanes.emplace_back([&rt, body, arg, l]() {
+      g_rt = &rt;
+      t_lane = l;
+      body(arg);
+    });
+  for (auto& t : lanes) t.join();
+  pthread_barrier_destroy(&g_barrier);
+}
+}  // namespace wave_emu
+#else
 static unsigned g_schedule = 0;
 void set_lane_schedule(unsigned schedule) { g_schedule = schedule; }
 
@@ -94,3 +125,4 @@ void run_wave(void (*body)(void*), void* arg) {
 }
 
 }  // namespace wave_emu
+#endif

@@ -49,6 +49,14 @@ struct WaveRuntime {
 };
 
 extern thread_local WaveRuntime* g_rt;
+#ifdef MODLE_EMU_THREADS
+// Race-detector build (make tsan_emu): every lane is a THREAD, the collectives are the only thing that
+// orders them (a barrier each) -- so ThreadSanitizer reports every word of LDS or device memory that one
+// lane writes and another touches without a collective in between: the barrier the GPU may not need
+// (a wave's LDS operations execute in order) and the language does.
+extern thread_local int t_lane;
+void threads_barrier();
+#endif
 
 extern "C" void modle_emu_switch(void** save_sp, void* load_sp);
 
@@ -71,6 +79,24 @@ inline void yield_next() {
 // deposit + rendezvous; returns the slot bank to read from
 inline const Slot* collective(uint64_t lo, uint64_t hi, int line) {
   WaveRuntime* rt = g_rt;
+#ifdef MODLE_EMU_THREADS
+  {
+    const int me = t_lane;
+    const unsigned bank = rt->coll_count[me]++ & 1u;
+    rt->slots[bank][me].v[0] = lo;
+    rt->slots[bank][me].v[1] = hi;
+    rt->slots[bank][me].line = line;
+    threads_barrier();
+    const Slot* s = rt->slots[bank];
+    for (int l = 0; l < kLanes; ++l) {
+      if (s[l].line != line) {
+        fprintf(stderr, "wave_emu: divergent collective: lane %d at line %d, lane %d at line %d\n", me, line, l, s[l].line);
+        abort();
+      }
+    }
+    return s;
+  }
+#endif
   const int me = rt->cur;
   const unsigned bank = rt->coll_count[me]++ & 1u;
   rt->slots[bank][me].v[0] = lo;
@@ -96,7 +122,11 @@ void set_lane_schedule(unsigned schedule);
 
 namespace wave {
 
+#ifdef MODLE_EMU_THREADS
+MODLE_DEV unsigned lane() { return static_cast<unsigned>(wave_emu::t_lane); }
+#else
 MODLE_DEV unsigned lane() { return static_cast<unsigned>(wave_emu::g_rt->cur); }
+#endif
 
 MODLE_DEV uint64_t ballot(bool p, int line = __builtin_LINE()) {
   const wave_emu::Slot* s = wave_emu::collective(p ? 1 : 0, 0, line);
@@ -240,7 +270,27 @@ MODLE_DEV U32x2 ld2(const uint32_t* p, uint32_t k) {
 struct U32x4 {
   uint32_t v[4];
 };
+#ifdef MODLE_EMU_THREADS
+// The device code's idiom for a lane that has nothing to load is "load element 0 and do not look at it"
+// (no branch around the load).  Lane 0 may be storing element 0 meanwhile: a race by the letter, the one
+// the detector is not after.  Loads of element 0 by any other lane are kept from it.
+extern "C" void AnnotateIgnoreReadsBegin(const char* file, int line);
+extern "C" void AnnotateIgnoreReadsEnd(const char* file, int line);
+struct DummyLoadGuard {
+  bool on;
+  explicit DummyLoadGuard(uint32_t k) : on(k == 0 && wave_emu::t_lane != 0) {
+    if (on) AnnotateIgnoreReadsBegin(__FILE__, __LINE__);
+  }
+  ~DummyLoadGuard() {
+    if (on) AnnotateIgnoreReadsEnd(__FILE__, __LINE__);
+  }
+};
+#define MODLE_EMU_DUMMY_LOAD(k) DummyLoadGuard dummy_load_guard_(k)
+#else
+#define MODLE_EMU_DUMMY_LOAD(k)
+#endif
 MODLE_DEV U32x4 ld4(const uint32_t* p, uint32_t k) {
+  MODLE_EMU_DUMMY_LOAD(k);
   U32x4 x;
   for (int q = 0; q < 4; ++q) x.v[q] = p[k + q];
   return x;
@@ -256,6 +306,7 @@ struct LdRaw {
   template <class T, class D>
   T operator()(const T* p, uint32_t k, bool ok, D dflt, T) const {
     (void)dflt;
+    MODLE_EMU_DUMMY_LOAD(k);
     return ok ? p[k] : static_cast<T>(dflt);
   }
 };
@@ -287,12 +338,20 @@ MODLE_DEV void atomic_add_u64(uint64_t* p, uint64_t v) {
 MODLE_DEV uint32_t atomic_fetch_add_u32(uint32_t* p, uint32_t v) {
   return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
 }
+#ifdef MODLE_EMU_THREADS
+MODLE_DEV uint32_t lds_fetch_add_u32(uint32_t* p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+#else
 MODLE_DEV uint32_t lds_fetch_add_u32(uint32_t* p, uint32_t v) {  // (lanes run one at a time)
   const uint32_t old = *p;
   *p = old + v;
   return old;
 }
+#endif
+#ifdef MODLE_EMU_THREADS
+MODLE_DEV void lds_or_u32(uint32_t* p, uint32_t v) { __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+#else
 MODLE_DEV void lds_or_u32(uint32_t* p, uint32_t v) { *p |= v; }  // (lanes run one at a time)
+#endif
 
 MODLE_DEV double f_log(double x) { return mm_log(x); }
 MODLE_DEV double f_exp(double x) { return mm_exp(x); }
