@@ -60,9 +60,9 @@ def test_no_lane_touches_what_another_wrote_without_a_collective(builds):
     exe = os.path.join(EMU, "tsan_emu")
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0")
     # 400 LEFs at a processivity of 300 kb (more than 64 re-inserted units per rank update); trials; a burn-in
-    for args in (["5000000", "1", "1", "80", "300000", "1", "0.05"],
-                 ["30000000", "1", "1", "40", "0", "1", "0.01", "0.3"],
-                 ["2000000", "1", "1", "0", "0", "0", "0.02", "0", "140"]):  # (burn-in cut at 140 epochs)
+    for args in (["5000000", "1", "1", "80", "300000", "1", "0.02"],
+                 ["30000000", "1", "1", "40", "0", "1", "0.004", "0.3"],
+                 ["2000000", "1", "1", "0", "0", "0", "0.01", "0", "110"]):  # (burn-in cut at 110 epochs)
         run = subprocess.run([exe] + args, capture_output=True, text=True, timeout=1200, env=env)
         assert "ThreadSanitizer" not in run.stderr, run.stderr[:4000]
         assert run.returncode == 0 and "rc=0" in run.stdout, (run.stdout, run.stderr[:1000])
