@@ -87,7 +87,7 @@ def parse_args():
                          "with one GPU the shard of rank 0 of 8 (512 cells of every chromosome), which is what one "
                          "GPU of the 8-GPU node runs")
     ap.add_argument("--chrom", default=None,
-                    help="diagnostic: restrict the grch38 workload to one chromosome (e.g. chr21)")
+                    help="diagnostic: restrict the grch38 workload to one chromosome (e.g. chr21), or synth:<bp>")
     ap.add_argument("--cells", type=int, default=None, help="cells per GPU (weak scaling)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--total-cells", type=int, default=None,
@@ -247,7 +247,12 @@ def main():
         cells_per_gpu = args.cells or default_cells
         total_cells = cells_per_gpu * world
         cells_txt = f"{cells_per_gpu} cells per GPU"
-    if args.workload == "grch38" and args.chrom:
+    if args.workload == "grch38" and args.chrom and args.chrom.startswith("synth:"):
+        # diagnostic: one synthetic chromosome of the given length, barriers at the bundled file's mean spacing
+        genome = [synthetic.synthetic_chromosome("chrS", int(args.chrom.split(":")[1]))]
+        workload = f"synthetic {genome[0]['size']} bp interval (diagnostic), {cells_txt}, reference defaults"
+        unit = "cells/s"
+    elif args.workload == "grch38" and args.chrom:
         genome = synthetic.grch38_like(seed=42, chroms={args.chrom})
         workload = f"{args.chrom}-shaped interval only (diagnostic), {cells_txt}, reference defaults"
         unit = f"{args.chrom}-cells/s"

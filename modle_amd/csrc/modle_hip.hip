@@ -43,6 +43,21 @@ namespace {
 
 constexpr int kWavesPerBlock = MODLE_WAVES_PER_CU;
 constexpr int kThreadsPerBlock = kWavesPerBlock * 64;
+// Measurement build (round 5, profiles/r05a/lds_residency_ceiling.txt): MODLE_EXP_LDS_WS=<bytes> gives
+// MODLE_EXP_LDS_WAVES (1 or 2) waves of every workgroup -- waves 0 and MODLE_EXP_LDS_STRIDE (4: the same
+// SIMD, 1: two SIMDs) -- a slice of LDS that holds the unit arrays, the barrier states and the lists of
+// stalling barriers of their cell; with MODLE_EXP_LDS_WS_OFF the same waves keep them in device memory.
+#ifdef MODLE_EXP_LDS_WS
+#ifndef MODLE_EXP_LDS_WAVES
+#define MODLE_EXP_LDS_WAVES 2
+#endif
+#ifndef MODLE_EXP_LDS_STRIDE
+#define MODLE_EXP_LDS_STRIDE 4
+#endif
+constexpr int kLdsSlots = MODLE_EXP_LDS_WAVES;
+#else
+constexpr int kLdsSlots = kWavesPerBlock;
+#endif
 
 struct DeviceTables {
   const u64* jump;   // JUMP_TABLE_WORDS
@@ -85,7 +100,8 @@ struct SimArgs {
   u32 test_fault;
 };
 
-__device__ __forceinline__ Workspace device_carve(char* base, u32 max_lefs, u32 max_barriers, u32 hist_len) {
+__device__ __forceinline__ Workspace device_carve(char* base, u32 max_lefs, u32 max_barriers, u32 hist_len,
+                                                  char* lds_base = nullptr) {
   // mirrors modle_host::carve_workspace
   const u64 Lp = (static_cast<u64>(max_lefs) + 63) & ~u64(63);
   u64 pw = 1;
@@ -97,6 +113,12 @@ __device__ __forceinline__ Workspace device_carve(char* base, u32 max_lefs, u32 
   p += pw * 8;
   ws.hist = reinterpret_cast<f64*>(p);
   p += 2 * static_cast<u64>(hist_len) * 8;
+#if defined(MODLE_EXP_LDS_WS) && !defined(MODLE_EXP_LDS_WS_OFF)
+  // (the unit arrays, the barrier states and the lists of stalling barriers: in this wave's slice of LDS)
+  if (lds_base != nullptr) p = lds_base;
+#else
+  (void)lds_base;
+#endif
   u32* q = reinterpret_cast<u32*>(p);
   ws.r_pos = q + 0 * Lp;
   ws.r_id = q + 1 * Lp;
@@ -129,12 +151,15 @@ __device__ __forceinline__ Workspace device_carve(char* base, u32 max_lefs, u32 
 struct BlockLds {
   alignas(16) u64 jump[JUMP_TABLE_WORDS];  // rows are read 128 bits at a time
   f64 zig[kZigWords];
-  u64 ring[kWavesPerBlock][RNG_RING];
-  u64 rng_state[kWavesPerBlock][4 * 64];
-  u64 rng_snap[kWavesPerBlock][8];
-  u64 sort_keys[kWavesPerBlock][SORT_LDS_CAP];
-  u32 stage[kWavesPerBlock][STAGE_CAP];
-  u32 pairbox[kWavesPerBlock][PAIR_WORDS];  // helper-wave mode: hand-over words of main wave w (sim_pair.h)
+  u64 ring[kLdsSlots][RNG_RING];
+  u64 rng_state[kLdsSlots][4 * 64];
+  u64 rng_snap[kLdsSlots][8];
+  u64 sort_keys[kLdsSlots][SORT_LDS_CAP];
+  u32 stage[kLdsSlots][STAGE_CAP];
+  u32 pairbox[kLdsSlots][PAIR_WORDS];  // helper-wave mode: hand-over words of main wave w (sim_pair.h)
+#ifdef MODLE_EXP_LDS_WS
+  alignas(16) char ws[kLdsSlots][MODLE_EXP_LDS_WS];
+#endif
 };
 
 __device__ __forceinline__ WaveLds make_wave_lds(BlockLds& s, int wave_in_block) {
@@ -163,7 +188,7 @@ __device__ __forceinline__ WaveLds make_wave_lds(BlockLds& s, int wave_in_block)
 __device__ __forceinline__ void load_block_tables(BlockLds& s, const DeviceTables& t, int nthreads) {
   // (hand-over words of the helper-wave mode -- the first lane-state words of a producer wave double
   // as its own: sequence numbers start from zero on both sides, no main wave is running yet)
-  for (u32 i = threadIdx.x; i < static_cast<u32>(kWavesPerBlock) * PAIR_WORDS; i += nthreads) {
+  for (u32 i = threadIdx.x; i < static_cast<u32>(kLdsSlots) * PAIR_WORDS; i += nthreads) {
     s.pairbox[i / PAIR_WORDS][i % PAIR_WORDS] = 0;
     reinterpret_cast<u32*>(s.rng_state[i / PAIR_WORDS])[i % PAIR_WORDS] = 0;
   }
@@ -175,9 +200,15 @@ __device__ __forceinline__ void load_block_tables(BlockLds& s, const DeviceTable
 }
 
 // The task loop of a main wave.
-__device__ __forceinline__ void simulate_tasks(const SimArgs& a, const WaveLds& lds, u32 slot, int wave_in_block) {
+__device__ __forceinline__ void simulate_tasks(const SimArgs& a, const WaveLds& lds, u32 slot, int wave_in_block,
+                                               char* lds_ws = nullptr) {
+#ifdef MODLE_EXP_LDS_WS
+  const Workspace ws = device_carve(a.workspace + static_cast<u64>(slot) * a.workspace_stride,
+                                    a.max_lefs, a.max_barriers, a.params.hist_len, lds_ws);
+#else
   const Workspace ws = device_carve(a.workspace + static_cast<u64>(slot) * a.workspace_stride,
                                     a.max_lefs, a.max_barriers, a.params.hist_len);
+#endif
   if (lds.pair_dynamic) pair_open(lds.mbox);  // this main wave is running: an idle wave may become its helper
   u32 finished_interval = 0xFFFFFFFFu;  // interval of the task this wave has just completed
 #ifdef MODLE_PHASE_TIMERS
@@ -271,6 +302,15 @@ __global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs
   load_block_tables(s, a.tables, kThreadsPerBlock);
   const int wave_in_block = wave::uniform(static_cast<int>(threadIdx.x / 64));
   const u32 slot = blockIdx.x * kWavesPerBlock + wave_in_block;
+#ifdef MODLE_EXP_LDS_WS
+  // (measurement build: waves 0 and MODLE_EXP_LDS_STRIDE only, no helpers)
+  if (wave_in_block % MODLE_EXP_LDS_STRIDE != 0 || wave_in_block / MODLE_EXP_LDS_STRIDE >= kLdsSlots) return;
+  {
+    const int ls = wave_in_block / MODLE_EXP_LDS_STRIDE;
+    WaveLds lds = make_wave_lds(s, ls);
+    simulate_tasks(a, lds, slot, wave_in_block, s.ws[ls]);
+  }
+#else
   WaveLds lds = make_wave_lds(s, wave_in_block);
   // Roles (sim_pair.h).  Launches that leave wave slots empty (pair_mains != 0): fixed trios of
   // main wave / helper / PRNG producer.  Launches that fill the slots: every wave is a main wave
@@ -342,6 +382,7 @@ __global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs
     }
     if (!dynamic) return;
   }
+#endif
 }
 
 struct PhaseArgs {
@@ -781,6 +822,13 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
   const int grid = std::max(1, static_cast<int>(std::min<size_t>(h->num_cus, sorted.size())));
   const auto layout = modle_host::workspace_layout(max_lefs, max_barriers, h->params.hist_len);
   const size_t n_slots = static_cast<size_t>(grid) * kWavesPerBlock;
+#if defined(MODLE_EXP_LDS_WS) && !defined(MODLE_EXP_LDS_WS_OFF)
+  if (layout.u32_words * 4 + layout.u8_bytes + layout.hit_words * 4 > static_cast<size_t>(MODLE_EXP_LDS_WS)) {
+    set_err(err, errlen, "measurement build: the cell's state does not fit the LDS slice (" +
+                             std::to_string(layout.u32_words * 4 + layout.u8_bytes + layout.hit_words * 4) + " bytes)");
+    return MODLE_HIP_ERR_ARG;
+  }
+#endif
   HIP_TRY(h->d_intervals.ensure(ivs.size()));
   HIP_TRY(h->d_tasks.ensure(sorted.size()));
   HIP_TRY(h->d_results.ensure(sorted.size()));
