@@ -213,6 +213,21 @@ def main():
             dist.init_process_group("gloo")
 
     coll_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # small collectives
+    if use_dist:
+        # the job really is N ranks (and, over RCCL, N different GPUs): a launcher that lost LOCAL_RANK would
+        # still finish and report N x the cells
+        import socket
+
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group of {dist.get_world_size()} ranks for --gpus {args.gpus}")
+        props = torch.cuda.get_device_properties(dev)
+        mine = (socket.gethostname(), str(getattr(props, "uuid", "")) or str(torch.cuda.current_device()),
+                torch.cuda.current_device())
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        if args.dist_backend == "nccl":
+            driver.check_distinct_devices([(h, u) for h, u, _ in everyone], world)
+            driver.check_distinct_devices([(h, i) for h, _, i in everyone], world)
 
     def reduce_to_rank0(t):
         """sum of the ranks' tensors into rank 0's (issued on the current stream)"""
@@ -294,6 +309,8 @@ def main():
     stream = torch.cuda.current_stream(dev)
 
     kernel_ms = []
+    reduce_ms = []      # per step: time the side stream spent in this rank's reduces (events around each pair)
+    reduce_events = []  # of the step under way
     check = {}
     reduce_stream = torch.cuda.Stream(device=dev) if use_dist else None
     # largest (LEFs + barriers) first: the order in which modle_hip_launch starts the tasks
@@ -355,16 +372,36 @@ def main():
                     if time.monotonic() > deadline:
                         # a faulted kernel never counts its intervals down: fail instead of spinning
                         # (the peers then fail in their collective instead of waiting for ever)
-                        raise SystemExit(f"rank {rank}: interval {plan[k]['interval']['name']} not "
-                                         f"finished after {args.poll_timeout:.0f} s")
+                        # ... and leave without the unbounded waits of an orderly shutdown: the abort word is
+                        # raised (a kernel that still listens drains), the process exits non-zero at once
+                        sim.cancel()
+                        print(f"rank {rank}: interval {plan[k]['interval']['name']} not finished after "
+                              f"{args.poll_timeout:.0f} s", file=sys.stderr, flush=True)
+                        os._exit(1)
                     time.sleep(0.0005)
                 with torch.cuda.stream(reduce_stream):
                     if last:
                         own_sums(k)
-                    reduce_to_rank0(tensors[k][0])
-                    reduce_to_rank0(tensors[k][1])
+                    if args.dist_backend == "nccl":
+                        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                        ev[0].record(reduce_stream)
+                        reduce_to_rank0(tensors[k][0])
+                        reduce_to_rank0(tensors[k][1])
+                        ev[1].record(reduce_stream)
+                        reduce_events.append(ev)
+                    else:
+                        t_r = time.perf_counter()  # (gloo rehearsal: host copies + host reduce)
+                        reduce_to_rank0(tensors[k][0])
+                        reduce_to_rank0(tensors[k][1])
+                        reduce_events.append(1e3 * (time.perf_counter() - t_r))
             sim.wait()
             stream.wait_stream(reduce_stream)
+            if args.dist_backend == "nccl":
+                reduce_stream.synchronize()
+                reduce_ms.append(sum(a.elapsed_time(b) for a, b in reduce_events))
+            else:
+                reduce_ms.append(sum(reduce_events))
+            reduce_events.clear()
         else:
             sim.wait()
             # (single GPU: nothing folds into the outputs after the launch, so the sums of the self-check
@@ -389,6 +426,7 @@ def main():
         step(first)
         first = False
     kernel_ms.clear()
+    reduce_ms.clear()
     sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -459,6 +497,11 @@ def main():
         dist.all_gather(gathered, mine)
         kernel_ms_per_rank = [float(g.item()) for g in gathered]
         kernel_ms_per_rank = [x if math.isfinite(x) else None for x in kernel_ms_per_rank]
+        mine_r = torch.tensor([sum(reduce_ms) / len(reduce_ms) if reduce_ms else float("nan")],
+                              dtype=torch.float64, device=coll_dev)
+        gathered_r = [torch.zeros_like(mine_r) for _ in range(world)]
+        dist.all_gather(gathered_r, mine_r)
+        reduce_ms_per_rank = [float(g.item()) if math.isfinite(float(g.item())) else None for g in gathered_r]
     # cells the job simulated per step: all of them, except where one GPU stands for one rank of a
     # larger job (grch38-dense on a single GPU: its shard only)
     job_cells = total_cells if plan_world == world else cells_per_gpu
@@ -519,6 +562,19 @@ def main():
                          "kernel_ms_per_rank": kernel_ms_per_rank,
                          "algorithmic_bytes_per_launch": step_bytes},
         }
+        if use_dist:
+            prediction = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r04b", "scale_prediction.json")) as f:
+                    prediction = json.load(f)
+            except (OSError, ValueError):
+                pass
+            out["multi_gpu"] = driver.scaling_report(
+                world, args.scaling, total_cells, cells_per_gpu,
+                sum(reduce_ms) / len(reduce_ms) if reduce_ms else None, prediction)
+            out["multi_gpu"]["reduce_ms_per_rank"] = reduce_ms_per_rank
+            out["multi_gpu"]["ranks"] = [{"host": h, "device": i, "uuid": u} for h, u, i in everyone]
+            out["multi_gpu"]["backend"] = "RCCL" if args.dist_backend == "nccl" else "gloo (rehearsal)"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, genome, unit, args.cpu_sample_cells)
         sys.stdout.flush()

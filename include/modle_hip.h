@@ -158,6 +158,9 @@ void modle_hip_sort_barriers(uint64_t* bar_pos, uint8_t* bar_dir, double* bar_st
 /* Creates a simulation context on HIP device `device`.  Fails (returns NULL) when no gfx950
  * device is usable: there is no CPU fallback. */
 modle_hip_handle* modle_hip_create(const modle_hip_config* c, int device, char* err, size_t errlen);
+/* Frees the context.  With a launch still in flight it raises the abort word and waits for the kernel
+ * to drain for at most MODLE_HIP_DRAIN_TIMEOUT_S; a kernel that does not drain (a hung device) makes it
+ * return WITHOUT freeing anything -- every free would wait for that kernel -- so that the caller can exit. */
 void modle_hip_destroy(modle_hip_handle* h);
 
 /* Registers one genomic interval (reference: GenomicInterval, genome.hpp) with its extrusion
@@ -187,7 +190,7 @@ int modle_hip_submit_tasks(modle_hip_handle* h, int interval_id, const modle_hip
 int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen);
 /* Waits for the launch and collects per-task results (the counterpart of _ctx.shutdown(),
  * scheduler_simulate.cpp:162).  The wait is bounded: when the launch has been running for longer
- * than the handle's deadline (default 3600 s; environment variable MODLE_HIP_WAIT_TIMEOUT_S at
+ * than the handle's deadline (default: none; environment variable MODLE_HIP_WAIT_TIMEOUT_S at
  * modle_hip_create, or modle_hip_set_wait_timeout) the abort word of modle_hip_cancel is raised --
  * the waves read it every sixteenth epoch and inside every spin loop of the helper-wave protocol, so
  * a wave whose partner has stopped answering leaves too -- and the call returns
@@ -211,6 +214,10 @@ typedef struct modle_hip_launch_info {
   uint64_t tail_helpers;             /* 1: waves that find the queue empty help running cells */
 } modle_hip_launch_info;
 int modle_hip_last_launch_info(modle_hip_handle* h, modle_hip_launch_info* info);
+/* HIP_VERSION the library was compiled with and hipRuntimeGetVersion() of the runtime it is bound to in
+ * this process (a host process that also loads PyTorch-ROCm shares torch's bundled runtime with this
+ * library, INTEGRATION.md: the binding warns when the major versions differ).  No device is touched. */
+int modle_hip_runtime_versions(int* built_with, int* runtime);
 /* Asks a launch in flight to stop (the counterpart of the `_ctx` flag the reference polls once
  * per epoch, simulation.cpp:933; here every sixteenth epoch, the word being in host-mapped memory
  * so that it can be raised while the kernel holds every CU): every cell leaves at the top of one of its next epochs, cells that

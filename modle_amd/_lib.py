@@ -26,6 +26,7 @@ EXPORTS = [
     "modle_hip_cancel", "modle_hip_test_units", "modle_hip_interval_done",
     "modle_hip_enable_state_log", "modle_hip_get_state_log", "modle_hip_set_wait_timeout",
     "modle_hip_last_launch_info",
+    "modle_hip_runtime_versions",
 ]
 
 u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
@@ -66,6 +67,23 @@ def _share_the_hip_runtime_with_torch():
             pass  # (the system's runtime then serves this library alone)
 
 
+def _warn_on_runtime_mismatch(L):
+    """The library was built against the system's ROCm headers; when torch's bundled runtime serves it
+    (above), the two versions may differ.  Same major version: same code-object and ABI generation; a
+    different one is reported (MODLE_HIP_OWN_RUNTIME=1 keeps the system's runtime)."""
+    try:
+        built, rt = C.c_int(0), C.c_int(0)
+        L.modle_hip_runtime_versions.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        if L.modle_hip_runtime_versions(C.byref(built), C.byref(rt)) == 0 and \
+                rt.value // 10_000_000 != built.value // 10_000_000:
+            import warnings
+
+            warnings.warn(f"libmodle_hip.so was built with HIP {built.value} and runs on HIP runtime {rt.value}: "
+                          "set MODLE_HIP_OWN_RUNTIME=1 to use the system's runtime", RuntimeWarning)
+    except AttributeError:
+        pass
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -76,6 +94,7 @@ def lib():
             "g.build()'` (hipcc, gfx950). modle_amd has no CPU fallback.")
     _share_the_hip_runtime_with_torch()
     L = C.CDLL(SO_PATH)
+    _warn_on_runtime_mismatch(L)
     P = C.POINTER
     err = [C.c_char_p, C.c_size_t]
     L.modle_hip_config_default.argtypes = [P(Config)]

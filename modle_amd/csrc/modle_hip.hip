@@ -546,7 +546,7 @@ struct modle_hip_handle {
   float last_ms = 0.0f;
   // deadline of modle_hip_wait, counted from the launch (MODLE_HIP_WAIT_TIMEOUT_S /
   // modle_hip_set_wait_timeout), and how long an aborted launch gets to drain
-  double wait_timeout_s = 3600.0;
+  double wait_timeout_s = 0.0;  // 0: no deadline (the reference has none); bench.py and the tests set one
   double drain_timeout_s = 60.0;
   std::chrono::steady_clock::time_point launched_at;
   modle_hip_launch_info last_launch{};
@@ -614,7 +614,37 @@ modle_hip_handle* modle_hip_create(const modle_hip_config* c, int device, char* 
 void modle_hip_destroy(modle_hip_handle* h) {
   if (h == nullptr) return;
   (void)hipSetDevice(h->device);
-  if (h->in_flight) (void)hipStreamSynchronize(h->stream);
+  if (h->in_flight) {
+    // A launch is still in flight (the caller is going down on an error path, or the interpreter is
+    // shutting down): raise the abort word and give the kernel the drain time -- never an unbounded
+    // wait.  A kernel that does not drain is a hung device: everything the handle owns is LEAKED
+    // (freeing memory a running kernel uses waits for that kernel) and the caller gets its exit.
+    {
+      std::lock_guard<std::mutex> lock(h->abort_mu);
+      __atomic_store_n(h->h_abort, 1u, __ATOMIC_RELEASE);
+    }
+    const auto give_up = std::chrono::steady_clock::now() +
+                         std::chrono::duration_cast<std::chrono::steady_clock::duration>(
+                             std::chrono::duration<double>(h->drain_timeout_s));
+    bool drained = false;
+    for (;;) {
+      const hipError_t q = hipStreamQuery(h->stream);
+      if (q == hipSuccess) {
+        drained = true;
+        break;
+      }
+      if (q != hipErrorNotReady || std::chrono::steady_clock::now() > give_up) break;
+      std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    if (!drained) {
+      (void)hipGetLastError();
+      std::fprintf(stderr, "modle_hip_destroy: the launch in flight did not drain within %.0f s of the abort word; "
+                           "the handle's device memory is leaked (hung device: exit the process)\n",
+                   h->drain_timeout_s);
+      return;  // (no frees, no event destroys, no delete: each of them would wait for the kernel)
+    }
+    h->in_flight = false;
+  }
   if (h->ev_start != nullptr) (void)hipEventDestroy(h->ev_start);
   if (h->ev_stop != nullptr) (void)hipEventDestroy(h->ev_stop);
   if (h->h_abort != nullptr) (void)hipHostFree(h->h_abort);
@@ -1023,6 +1053,13 @@ int modle_hip_set_wait_timeout(modle_hip_handle* h, double seconds) {
   return MODLE_HIP_OK;
 }
 
+int modle_hip_runtime_versions(int* built_with, int* runtime) {
+  if (built_with == nullptr || runtime == nullptr) return MODLE_HIP_ERR_ARG;
+  *built_with = HIP_VERSION;
+  *runtime = 0;
+  return hipRuntimeGetVersion(runtime) == hipSuccess ? MODLE_HIP_OK : MODLE_HIP_ERR_DEVICE;
+}
+
 int modle_hip_last_launch_info(modle_hip_handle* h, modle_hip_launch_info* info) {
   if (h == nullptr || info == nullptr) return MODLE_HIP_ERR_ARG;
   *info = h->last_launch;
@@ -1043,8 +1080,9 @@ int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen) {
   bool timed_out = false;
   {
     using clock = std::chrono::steady_clock;
+    const bool has_deadline = h->wait_timeout_s > 0.0;
     const auto deadline = h->launched_at + std::chrono::duration_cast<clock::duration>(
-                                               std::chrono::duration<double>(h->wait_timeout_s));
+                                               std::chrono::duration<double>(has_deadline ? h->wait_timeout_s : 0.0));
     clock::time_point drain_deadline{};
     unsigned polls = 0;
     for (;;) {
@@ -1055,7 +1093,7 @@ int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen) {
         return MODLE_HIP_ERR_DEVICE;
       }
       const auto now = clock::now();
-      if (!timed_out && now > deadline) {
+      if (!timed_out && has_deadline && now > deadline) {
         std::lock_guard<std::mutex> lock(h->abort_mu);
         __atomic_store_n(h->h_abort, 1u, __ATOMIC_RELEASE);
         timed_out = true;
@@ -1120,11 +1158,13 @@ int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen) {
   }
 #endif
   int rc = MODLE_HIP_OK;
+  bool any_cancelled = false;
   for (size_t i = 0; i < res.size(); ++i) {
     const auto [iv, idx] = h->launch_map[i];
     static_assert(sizeof(CellResult) == sizeof(modle_hip_cell_result), "result layouts differ");
     std::memcpy(&h->intervals[static_cast<size_t>(iv)]->results[idx], &res[i], sizeof(CellResult));
     if (status[i] == ERR_CANCELLED) {
+      any_cancelled = true;
       if (rc == MODLE_HIP_OK) {
         set_err(err, errlen, "the launch was cancelled (modle_hip_cancel)");
         rc = MODLE_HIP_ERR_CANCELLED;
@@ -1136,7 +1176,9 @@ int modle_hip_wait(modle_hip_handle* h, char* err, size_t errlen) {
       rc = MODLE_HIP_ERR_STATE;
     }
   }
-  if (timed_out) {
+  // (a launch that finished on its own just as the deadline passed has no cancelled task: its outputs are
+  // complete and it is reported as what it is)
+  if (timed_out && any_cancelled) {
     set_err(err, errlen, "the launch exceeded the wait deadline of " + std::to_string(h->wait_timeout_s) +
                              " s (MODLE_HIP_WAIT_TIMEOUT_S / modle_hip_set_wait_timeout): it was aborted and has "
                              "drained; its outputs are incomplete");

@@ -1030,6 +1030,10 @@ MODLE_DEV_NOINLINE void resolve_listed_units(Cell& c, u32 n_listed) {
         if (hit) w_entry = e;  // later visits overwrite earlier ones
       }
     };
+#ifdef MODLE_EMU_TRACE_RANK  // (emulator only: which regime a test exercises)
+    if (lane == 0) fprintf(stderr, "lef_bar_trials: %s batch of %u units, %u trials%s\n", FWD ? "fwd" : "rev",
+                           umin(64u, n_listed - base), total, total > RNG_BLOCK ? " (resolved in rounds)" : "");
+#endif
     u32 w_entry = 0xFFFFFFFFu;
     if (total <= RNG_BLOCK) {
       if (total != 0) rng_ensure(c.g, total);

@@ -225,6 +225,9 @@ MODLE_DEV_NOINLINE void phase_extrude_and_release(Cell& c, bool burnin_completed
     wave::sync_lds();
     c.rel_valid = n_rel <= REL_CAP;
     c.n_rel = c.rel_valid ? n_rel : 0;
+#ifdef MODLE_EMU_TRACE_RANK  // (emulator only: which regime a test exercises)
+    if (lane == 0 && !c.rel_valid) fprintf(stderr, "release: %u LEFs released, the list holds %u: the next bind sweeps\n", n_rel, REL_CAP);
+#endif
     wave::sync_mem();
     return;
   }

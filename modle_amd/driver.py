@@ -201,3 +201,54 @@ def format_state_log(task, interval, n_barriers, records):
                    f"{interval['end']}\t{'True' if burnin else 'False'}\t{occ!r}\t{n}\t{int(rec[3])}\t"
                    f"{int(rec[4])}\t{int(rec[5])}\t{int(rec[6])}\t{int(rec[7])}\t{int(rec[8])}\t{avg!r}\n")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# what an N > 1 bench line says about itself (bench.py)
+# ---------------------------------------------------------------------------------------------
+def check_distinct_devices(devices, world):
+    """`devices`: one (hostname, device index or uuid) pair per rank, all-gathered.  An RCCL job of N ranks
+    on N GPUs has N distinct pairs; two ranks that ended up on one GPU (a launcher that did not set
+    LOCAL_RANK, a CUDA_VISIBLE_DEVICES mask) would still finish and report N x the cells."""
+    if len(devices) != world:
+        raise RuntimeError(f"{len(devices)} device records for {world} ranks")
+    if len(set(devices)) != world:
+        raise RuntimeError(f"ranks share a GPU: {devices}")
+    return True
+
+
+def scaling_report(world, scaling, total_cells, cells_per_gpu, reduce_ms, prediction=None):
+    """The keys an N > 1 line adds.  `prediction`: the parsed profiles/r04b/scale_prediction.json
+    (one-GPU rehearsal of the strong-scaling job: every rank's shard run one after the other), or None.
+    Strong scaling at the predicted job size: the predicted speed-up over N = 1 (with the reduce serial
+    behind the kernel); weak scaling: N minus the same serial reduce, i.e. what `value` should be a multiple of
+    the N = 1 value by.  Always labelled a prediction: the measured one is value(N) / value(1), which only the
+    driver, holding both lines, can compute."""
+    out = {"scaling": scaling, "total_cells": int(total_cells), "cells_per_gpu": int(cells_per_gpu),
+           "reduce_ms": reduce_ms,
+           "scaling_means": ("strong: total_cells fixed, each GPU simulates total_cells / N cells of every chromosome "
+                             "(north_star's '>= 6 x at 8 vs 1'; BASELINE configs[3] with --total-cells 16384)"
+                             if scaling == "strong" else
+                             "weak: cells_per_gpu fixed, the job grows with N; the reference splits a fixed number of "
+                             "target contacts over the cells, so a cell of the N-GPU job samples 1/N of the contacts "
+                             "(compare cell_epochs_per_s, not only value)")}
+    pred = None
+    if prediction is not None and world > 1:
+        w = prediction.get("worlds", {}).get(str(world))
+        if w is not None:
+            if scaling == "strong" and int(prediction.get("total_cells", -1)) == int(total_cells):
+                pred = {"predicted_speedup": w["predicted_speedup_with_serial_reduce"],
+                        "predicted_speedup_kernel_only": w["predicted_speedup_kernel_only"]}
+            elif scaling == "weak":
+                single = prediction.get("single", {})
+                k1 = single.get("kernel_ms") if isinstance(single, dict) else None
+                if k1:
+                    red = prediction.get("reduce_ms_at_one_xgmi_link", 0.0)
+                    # (weak scaling of independent cells: N x, less the serial reduce of one launch)
+                    pred = {"predicted_speedup": world * w["max_kernel_ms"] / (w["max_kernel_ms"] + red),
+                            "predicted_speedup_kernel_only": float(world)}
+            if pred is not None:
+                pred["prediction_source"] = ("profiles/r04b/scale_prediction.json (one-GPU rehearsal, "
+                                             "unmeasured on multi-GPU hardware)")
+    out["predicted"] = pred
+    return out

@@ -23,9 +23,9 @@ REGIMES = (["120000000", "1", "1", "20", "25000", "0", "0.002"],
 
 @pytest.fixture(scope="module")
 def builds():
-    """the three sanitizer builds, side by side (a minute each)"""
+    """the sanitizer builds, side by side (a minute each)"""
     procs = {t: subprocess.Popen(["make", "-C", EMU, t], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-             for t in ("msan_emu", "asan_emu", "tsan_emu")}
+             for t in ("msan_emu", "asan_emu", "tsan_emu", "tsan_emu_philox")}
     return {t: (p.communicate()[0], p.returncode) for t, p in procs.items()}
 
 
@@ -66,3 +66,51 @@ def test_no_lane_touches_what_another_wrote_without_a_collective(builds):
         run = subprocess.run([exe] + args, capture_output=True, text=True, timeout=1200, env=env)
         assert "ThreadSanitizer" not in run.stderr, run.stderr[:4000]
         assert run.returncode == 0 and "rc=0" in run.stdout, (run.stdout, run.stderr[:1000])
+
+
+# Round 5: the regimes the race detector had not seen.  The build prints which form of a
+# pass a cell takes (-DMODLE_EMU_TRACE_RANK); every regime must show its marker, or the test tests nothing.
+#   LEF-BAR detection with Bernoulli trials, batches resolved in rounds (a barrier every ~100 bp, blocking
+#     probabilities 0.7 / 0.4: tests/parity_cases.py "dense_barriers_trials")
+#   the one-sweep rank update with its keys in the generator's ring (1 023 keys; "rebinds_beyond_sort_buffer")
+#   more LEFs released than the LDS list holds: overflow of release_lefs, sweeping bind, general rank update
+#     ("mass_release")
+TSAN_REGIMES_R05 = (
+    (["600000", "1", "1", "64", "0", "1", "0.3", "0", "0", "spacing=100", "major=0.7", "minor=0.4"],
+     ("lef_bar_trials: rev", "lef_bar_trials: fwd", "(resolved in rounds)")),
+    (["120000000", "1", "1", "20", "25000", "1", "0.003"], ("key_cap 1023",)),
+    (["120000000", "1", "1", "20", "8000", "1", "0.0008"],
+     ("the next bind sweeps", "rank_update: general")),
+)
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="needs clang++ with ThreadSanitizer")
+def test_race_detector_on_trials_ring_borrow_and_mass_release(builds):
+    out, rc = builds["tsan_emu"]
+    if rc != 0 and "tsan" in out.lower():
+        pytest.skip("ThreadSanitizer runtime not available")
+    assert rc == 0, out[-2000:]
+    exe = os.path.join(EMU, "tsan_emu")
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0")
+    for args, markers in TSAN_REGIMES_R05:
+        run = subprocess.run([exe] + args, capture_output=True, text=True, timeout=1500, env=env)
+        assert "ThreadSanitizer" not in run.stderr, run.stderr[:4000]
+        assert run.returncode == 0 and "rc=0" in run.stdout, (run.stdout, run.stderr[-1000:])
+        for m in markers:
+            assert m in run.stderr, (args, m, run.stderr[-1500:])
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="needs clang++ with ThreadSanitizer")
+def test_race_detector_on_the_philox_policy(builds):
+    """the counter-based block generator (sim_rng.h, -DMODLE_RNG_PHILOX) through a burn-in and a cell with trials"""
+    out, rc = builds["tsan_emu_philox"]
+    if rc != 0 and "tsan" in out.lower():
+        pytest.skip("ThreadSanitizer runtime not available")
+    assert rc == 0, out[-2000:]
+    exe = os.path.join(EMU, "tsan_emu_philox")
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0")
+    for args in (["2000000", "1", "1", "0", "0", "0", "0.01", "0", "110"],
+                 ["30000000", "1", "1", "40", "0", "1", "0.002", "0.3"]):
+        run = subprocess.run([exe] + args, capture_output=True, text=True, timeout=1500, env=env)
+        assert "ThreadSanitizer" not in run.stderr, run.stderr[:4000]
+        assert run.returncode == 0 and "rc=0" in run.stdout, (run.stdout, run.stderr[-1000:])

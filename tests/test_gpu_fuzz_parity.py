@@ -53,3 +53,48 @@ def _compare(oracle, case, label):
         what = f"{label} (helper waves {mode}): {case['kw']}, size {case['size']}"
         assert_same_results(ores, gres, what)
         assert_same_outputs((oc, om, oo), (gc, gm, go if track else None), what)
+
+
+# --- seeds nobody has seen yet ---------------------------------------------------------
+# The seeds above are the committed regression set: every run of the suite repeats them.  These take up to 64
+# seeds per generator from the DATE of the run (MODLE_FUZZ_DATE=YYYYMMDD reproduces a day), so that the driver's
+# round-end run and every builder run in between cover set-ups no campaign has visited.  A generator's share of
+# the suite is bounded in time (the oracle runs on the host): it reports how many seeds it compared.
+FRESH_SEEDS_PER_GENERATOR = 64
+FRESH_BUDGET_S = 60.0
+
+
+def _date_base():
+    import datetime
+    import os
+
+    day = os.environ.get("MODLE_FUZZ_DATE") or datetime.date.today().strftime("%Y%m%d")
+    return int(day) * 1000
+
+
+@pytest.mark.parametrize("name", ["v1", "v2", "v3", "v4"])
+def test_gpu_matches_oracle_on_seeds_of_the_day(oracle, name):
+    import time
+
+    from modle_amd import api
+
+    gen = {"v1": random_case, "v2": random_case_v2, "v3": random_case_v3, "v4": random_case_v4}[name]
+    base = _date_base()
+    t0 = time.time()
+    done = skipped = 0
+    for i in range(FRESH_SEEDS_PER_GENERATOR):
+        if time.time() - t0 > FRESH_BUDGET_S:
+            break
+        seed = base + i
+        case = gen(seed)
+        cfg = case["cfg"]
+        # (keep the oracle's share short, like tools/fuzz_campaign.py: skip set-ups whose cells need many epochs)
+        per_epoch = max(1, api.compute_contacts_per_epoch(cfg, case["tasks"][0].num_lefs))
+        if cfg.target_contact_density >= 0 and case["tasks"][0].num_target_contacts / per_epoch > 3000:
+            skipped += 1
+            continue
+        _compare(oracle, case, f"{name} seed of the day {seed} (MODLE_FUZZ_DATE={base // 1000})")
+        done += 1
+    print(f"{name}: {done} fresh seeds from {base} compared in both launch modes, {skipped} skipped (long cells), "
+          f"{time.time() - t0:.0f} s")
+    assert done >= 8, f"only {done} fresh seeds fitted the time budget"

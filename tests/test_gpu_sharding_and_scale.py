@@ -258,6 +258,12 @@ def test_bench_runs_under_torch_distributed_run_with_one_rank(tmp_path):
     assert d["check"]["tasks"] == 24 * 16 and "side stream" in d["config"]["parallelism"]
     # the kernel time of every rank goes with the line (a real multi-GPU run shows its imbalance there)
     assert len(d["roofline"]["kernel_ms_per_rank"]) == 1 and d["roofline"]["kernel_ms_per_rank"][0] > 0
+    # ... and the line says what kind of job it was: scaling mode, cells, the time the side stream spent in the
+    # RCCL reduces, which GPU every rank ran on (distinct devices are asserted inside bench.py)
+    mg = d["multi_gpu"]
+    assert mg["scaling"] == "weak" and mg["total_cells"] == 16 and mg["cells_per_gpu"] == 16
+    assert mg["backend"] == "RCCL" and mg["reduce_ms"] > 0 and len(mg["reduce_ms_per_rank"]) == 1
+    assert len(mg["ranks"]) == 1 and mg["predicted"] is None  # (no prediction for one rank)
 
 
 def _bench(tmp_path, nproc, port, extra):
@@ -302,3 +308,9 @@ def test_bench_with_two_real_ranks_reduces_to_the_single_rank_matrices(tmp_path)
     assert round(two["tasks_per_s"] * two["ms_per_step"] / 1e3) == 24 * 24
     assert len(two["roofline"]["kernel_ms_per_rank"]) == 2 and all(x > 0 for x in two["roofline"]["kernel_ms_per_rank"])
     assert one["roofline"]["kernel_ms_per_rank"] is None
+    assert "multi_gpu" not in one
+    mg = two["multi_gpu"]
+    assert mg["scaling"] == "strong" and mg["total_cells"] == 24 and mg["cells_per_gpu"] == 12
+    assert mg["backend"].startswith("gloo") and len(mg["reduce_ms_per_rank"]) == 2 and mg["reduce_ms"] > 0
+    assert [r["device"] for r in mg["ranks"]] == [0, 0]  # (the rehearsal's ranks share this GPU: gloo only)
+    assert mg["predicted"] is None  # (the committed prediction is for 16 384 cells, not for this job)

@@ -105,3 +105,37 @@ def test_deadline_alone_aborts_a_long_launch_and_the_handle_survives(oracle):
                                                 stp_i, tasks, nthreads=4)
     assert np.array_equal(gc, oc) and gm == om and np.array_equal(go, oo)
     assert [(r.epochs, r.raws_consumed) for r in gres] == [(r.epochs, r.raws_consumed) for r in ores]
+
+
+def test_destroy_with_a_launch_in_flight_is_bounded(monkeypatch):
+    """modle_hip_destroy used to hipStreamSynchronize a launch that was still in flight: a caller going
+    down on an error path (or an interpreter shutting down with a Simulator alive) then waited for ever
+    behind a stuck kernel.  Now: abort word, bounded drain, and only then the frees."""
+    from modle_amd import api, driver, synthetic
+
+    genome = [synthetic.synthetic_chromosome("chrBig", 80_000_000, seed=5)]
+    cfg = api.make_config(num_cells=32768, seed=11)
+    entry = driver.plan_genome(cfg, genome)[0]
+    sim = api.Simulator(cfg, 0)
+    driver.enqueue_plan(sim, cfg, [dict(entry, tasks=api.slice_tasks(entry["tasks"], 0, 24000))])
+    sim.launch()  # seconds of kernel when left alone; never waited for
+    t0 = time.time()
+    sim.close()
+    closed = time.time() - t0
+    assert closed < 2.0, closed
+    # ... and with a helper that withholds its signal (the spin loops leave on the abort word)
+    monkeypatch.setenv("MODLE_HIP_TEST_FAULT", "stuck_helper")
+    monkeypatch.setenv("MODLE_HIP_PAIRED", "1")
+    case = build_case("chr20mb_barriers")
+    sim = api.Simulator(case["cfg"], 0)
+    ch = case["chrom"]
+    iid = sim.add_interval(ch["start"], ch["end"], ch["bar_pos"], ch["bar_dir"], case["stp_active"],
+                           case["stp_inactive"])
+    sim.submit(iid, api.slice_tasks(case["tasks"], 0, 12))
+    sim.launch()
+    time.sleep(0.5)
+    t0 = time.time()
+    sim.close()
+    closed_stuck = time.time() - t0
+    assert closed_stuck < 2.0, closed_stuck
+    print(f"destroy with a launch in flight: {closed:.3f} s (long launch), {closed_stuck:.3f} s (stuck helper)")

@@ -86,3 +86,56 @@ def test_two_rank_gloo_reduce_equals_single_rank(oracle, tmp_path):
         assert np.array_equal(np.load(tmp_path / f"c{k}.npy"), out[0])
         assert np.array_equal(np.load(tmp_path / f"o{k}.npy"), out[2])
         assert int(np.load(tmp_path / f"m{k}.npy")[0]) == out[1]
+
+
+def _devices_worker(rank, world, port, tmpdir, shared):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from modle_amd import driver
+
+    mine = ("host", 0 if shared else rank)
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    try:
+        driver.check_distinct_devices(everyone, world)
+        verdict = "distinct"
+    except RuntimeError as e:
+        verdict = "shared: " + str(e)
+    with open(os.path.join(tmpdir, f"devices_{rank}.txt"), "w") as f:
+        f.write(verdict)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_every_rank_reports_its_device_and_shared_gpus_are_refused(tmp_path, shared):
+    """What bench.py does right after init_process_group for N > 1: the ranks
+    all-gather (host, device) and every rank refuses a job in which two ranks sit on one GPU."""
+    port = 31500 + os.getpid() % 2000 + (1 if shared else 0)
+    mp.spawn(_devices_worker, args=(2, port, str(tmp_path), shared), nprocs=2, join=True)
+    for r in range(2):
+        verdict = (tmp_path / f"devices_{r}.txt").read_text()
+        assert verdict.startswith("shared") if shared else verdict == "distinct"
+
+
+def test_scaling_report_labels_the_job_and_quotes_the_prediction():
+    import json
+
+    from modle_amd import driver
+
+    with open(os.path.join(ROOT, "profiles", "r04b", "scale_prediction.json")) as f:
+        pred = json.load(f)
+    strong = driver.scaling_report(8, "strong", 16384, 2048, 11.5, pred)
+    assert strong["scaling"] == "strong" and strong["total_cells"] == 16384 and strong["cells_per_gpu"] == 2048
+    assert strong["reduce_ms"] == 11.5 and "strong" in strong["scaling_means"]
+    assert 7.5 < strong["predicted"]["predicted_speedup"] < strong["predicted"]["predicted_speedup_kernel_only"] < 8
+    assert "unmeasured" in strong["predicted"]["prediction_source"]
+    # another job size: no prediction is quoted for it
+    assert driver.scaling_report(8, "strong", 4096, 512, 1.0, pred)["predicted"] is None
+    weak = driver.scaling_report(4, "weak", 8192, 2048, 9.0, pred)
+    assert "weak" in weak["scaling_means"] and 3.9 < weak["predicted"]["predicted_speedup"] < 4.0
+    assert driver.scaling_report(1, "weak", 2048, 2048, None, pred)["predicted"] is None
+    with pytest.raises(RuntimeError):
+        driver.check_distinct_devices([("h", 0), ("h", 0)], 2)
+    assert driver.check_distinct_devices([("h", 0), ("h", 1)], 2)

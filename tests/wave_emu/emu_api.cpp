@@ -177,8 +177,21 @@ uint64_t tick() {
   }
   uint64_t changed = 0;  // a phase ends: 32-bit words that differ, in bytes
   for (size_t i = 0; i + 4 <= g_size; i += 4) changed += memcmp(g_base + i, g_snap.data() + i, 4) != 0 ? 4 : 0;
+  // ... and, in the high half of the reading, the aligned sectors of MODLE_EMU_WTRACE_SECTOR bytes that hold a
+  // changed byte (round 5: what leaves an L2 that cannot keep a line from one phase to the next is whole
+  // sectors, not the words that changed in them; profiles/r05*/write_accounting.txt)
+#ifndef MODLE_EMU_WTRACE_SECTOR
+#define MODLE_EMU_WTRACE_SECTOR 32
+#endif
+  uint64_t sectors = 0;
+  const size_t skew = reinterpret_cast<uintptr_t>(g_base) % MODLE_EMU_WTRACE_SECTOR;  // (sectors of the ADDRESS)
+  for (size_t i = 0; i < g_size;) {
+    const size_t end = std::min(g_size, i + (MODLE_EMU_WTRACE_SECTOR - (i + skew) % MODLE_EMU_WTRACE_SECTOR));
+    sectors += memcmp(g_base + i, g_snap.data() + i, end - i) != 0 ? 1 : 0;
+    i = end;
+  }
   g_state = 1;
-  return changed;
+  return changed | (sectors << 32);
 }
 }  // namespace emu_wtrace
 static uint64_t g_phase_bytes[16];

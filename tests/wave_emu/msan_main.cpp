@@ -2,6 +2,7 @@
 // runs whole cells so that any read of uninitialised registers / LDS / workspace is reported.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "modle_hip.h"
 
@@ -33,6 +34,16 @@ int main(int argc, char** argv) {
     cfg.soft_stall_lef_stability_multiplier = 2.0;
   }
   if (argc > 9 && atoi(argv[9]) > 0) cfg.max_burnin_epochs = static_cast<uint64_t>(atoi(argv[9]));
+  // named settings anywhere behind the positional ones: spacing=<bp> (a barrier every so many bp instead of
+  // one per 30-120 kb), major=<p> / minor=<p> (blocking probabilities: fractional ones make LEF-BAR detection
+  // draw Bernoulli trials), softstall=<x>
+  uint64_t spacing = 0;
+  for (int i = 1; i < argc; ++i) {
+    if (strncmp(argv[i], "spacing=", 8) == 0) spacing = strtoull(argv[i] + 8, nullptr, 10);
+    if (strncmp(argv[i], "major=", 6) == 0) cfg.lef_bar_major_collision_pblock = atof(argv[i] + 6);
+    if (strncmp(argv[i], "minor=", 6) == 0) cfg.lef_bar_minor_collision_pblock = atof(argv[i] + 6);
+    if (strncmp(argv[i], "softstall=", 10) == 0) cfg.soft_stall_lef_stability_multiplier = atof(argv[i] + 10);
+  }
   char err[256];
   if (modle_hip_config_transform(&cfg, err, sizeof(err)) < 0) return 2;
   std::vector<uint64_t> bp;
@@ -40,7 +51,9 @@ int main(int argc, char** argv) {
   std::vector<double> sa, si;
   if (with_barriers) {
     uint64_t x = 12345;
-    for (uint64_t pos = 20000; pos + 20000 < size; pos += 30000 + (x = x * 6364136223846793005ull + 1442695040888963407ull) % 90000) {
+    const uint64_t lo = spacing != 0 ? spacing / 2 + 1 : 30000, span = spacing != 0 ? spacing : 90000;
+    for (uint64_t pos = spacing != 0 ? spacing : 20000; pos + 20000 < size;
+         pos += lo + (x = x * 6364136223846793005ull + 1442695040888963407ull) % span) {
       bp.push_back(pos);
       bd.push_back(((x >> 40) & 1) ? MODLE_HIP_DIR_FWD : MODLE_HIP_DIR_REV);
       sa.push_back(modle_hip_stp_active_from_occupancy(cfg.barrier_not_occupied_stp, 0.6 + 0.3 * ((x >> 20) % 100) / 100.0));

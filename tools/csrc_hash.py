@@ -11,17 +11,17 @@ import hashlib
 import os
 import sys
 
-DEVICE_SOURCES = [
-    "modle_hip.hip", "sim_device.h", "sim_types.h", "sim_cell.h", "sim_rng.h", "sim_pair.h",
-    "sim_helper.h", "sim_bind_rank.h", "sim_moves.h", "sim_barriers.h", "sim_collisions.h",
-    "sim_release.h", "sim_contacts.h", "sim_burnin.h", "sim_epoch.h", "wave_hip.h", "modle_math.h",
-    "Makefile",
-]
+def device_sources(root):
+    """Every *.h / *.hpp / *.hip of modle_amd/csrc plus the Makefile, sorted by name: whatever is compiled into
+    the kernel or decides the workspace layout (a hand-kept list missed four of them in round 4)."""
+    d = os.path.join(root, "modle_amd", "csrc")
+    names = sorted(n for n in os.listdir(d) if n.endswith((".h", ".hpp", ".hip")) or n == "Makefile")
+    return names
 
 
 def csrc_sha256(root):
     h = hashlib.sha256()
-    for name in DEVICE_SOURCES:
+    for name in device_sources(root):
         with open(os.path.join(root, "modle_amd", "csrc", name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read() + b"\0")
     return h.hexdigest()

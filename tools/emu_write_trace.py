@@ -28,7 +28,10 @@ def main():
     from phase_backend import emu_lib
 
     names = sys.argv[1:] or ["chr20mb_barriers", "many_rebinds_per_epoch", "dense_stress_rebinds_and_displaced"]
-    lib = emu_lib("wtrace")
+    # MODLE_WTRACE_SECTOR=64: the build that counts dirty 64-byte sectors (default: 32-byte sectors)
+    variant = "wtrace64" if os.environ.get("MODLE_WTRACE_SECTOR", "32") == "64" else "wtrace"
+    sector = 64 if variant == "wtrace64" else 32
+    lib = emu_lib(variant)
     lib.emu_write_trace_read.argtypes = [C.POINTER(C.c_uint64 * 16), C.c_int]
     out = {}
     for name in names:
@@ -40,13 +43,20 @@ def main():
         _, _, _, res = emu_sim.simulate_interval(
             cfg, chrom["start"], chrom["end"], chrom["bar_pos"], chrom["bar_dir"], case["stp_active"],
             case["stp_inactive"], tasks, case["nrows"], case["ncols"],
-            track_occupancy=bool(cfg.track_1d_lef_position), variant="wtrace")
+            track_occupancy=bool(cfg.track_1d_lef_position), variant=variant)
         lib.emu_write_trace_read(C.byref(buf), 1)
         lef_epochs = int(res[0].sum_active_lefs)
-        row = {PHASES[i]: round(buf[i] / lef_epochs, 2) for i in range(15)}
-        row["all phases"] = round(sum(buf[i] for i in range(15)) / lef_epochs, 2)
+        # (low half of a reading: bytes changed; high half: dirty sectors -- tests/wave_emu/emu_api.cpp)
+        lo = [buf[i] & 0xFFFFFFFF for i in range(15)]
+        hi = [(buf[i] >> 32) * sector for i in range(15)]
+        row = {PHASES[i]: round(lo[i] / lef_epochs, 2) for i in range(15)}
+        row["all phases"] = round(sum(lo) / lef_epochs, 2)
+        srow = {PHASES[i]: round(hi[i] / lef_epochs, 2) for i in range(15)}
+        srow["all phases"] = round(sum(hi) / lef_epochs, 2)
         out[name] = {"lefs": int(tasks[0].num_lefs), "barriers": len(chrom["bar_pos"]), "epochs": int(res[0].epochs),
-                     "burnin_epochs": int(res[0].burnin_epochs), "bytes_changed_per_lef_epoch": row}
+                     "burnin_epochs": int(res[0].burnin_epochs), "lef_epochs": lef_epochs,
+                     "bytes_changed_per_lef_epoch": row,
+                     f"bytes_in_dirty_{sector}B_sectors_per_lef_epoch": srow}
     json.dump(out, sys.stdout, indent=1)
     print()
 
