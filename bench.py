@@ -44,6 +44,10 @@ def launch_mode(info):
     return "one wave per cell" + (", idle waves help in the tail of the launch" if info["tail_helpers"] else "")
 
 
+def size_class(info):
+    return "wide (32-bit LEF ids and moves)" if info.get("size_class") else "narrow (16-bit LEF ids and moves)"
+
+
 def measured_traffic(workload_key):
     """HBM bytes per launch of the simulation kernel, from the PMC passes committed under
     profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same workload,
@@ -450,6 +454,7 @@ def main():
     n_tasks = 0
     step_bytes = 0
     epochs = 0
+    lef_epochs = 0  # sum over cells and simulated epochs of the active LEFs
     longest = 0  # epochs of the longest cell: a launch with fewer tasks than wave slots lasts as long as it does
     for entry, iid in zip(plan, ids):
         if iid is None:
@@ -460,6 +465,7 @@ def main():
         step_bytes += driver.algorithmic_bytes(last, len(entry["interval"]["bar_pos"]),
                                                bool(cfg.track_1d_lef_position))
         epochs += sum(r.epochs for r in last)
+        lef_epochs += sum(r.sum_active_lefs for r in last)
         longest = max(longest, max((r.epochs for r in last), default=0))
         n_tasks += k
     import math
@@ -476,7 +482,11 @@ def main():
     missed_delta = [None if a is None else a - b for a, b in zip(missed_after, check["missed_before"])]
     msum = [None if x is None else int(x.item()) for x in check["matrix"]]
     osum = [None if x is None else int(x.item()) for x in check["occ"]]
-    verified = driver.verify_outputs(sim, cfg, plan, ids, msum, missed_delta, osum)
+    if os.environ.get("MODLE_BENCH_NO_VERIFY", "") not in ("", "0"):
+        # (measurement builds that leave the output increments out: profiles/r05*/write_accounting.txt)
+        verified = {"skipped": "MODLE_BENCH_NO_VERIFY"}
+    else:
+        verified = driver.verify_outputs(sim, cfg, plan, ids, msum, missed_delta, osum)
     if use_dist:
         import torch.distributed as dist
 
@@ -538,7 +548,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": args.scaling,
-            "checked": True,
+            "checked": "skipped" not in verified,
             "check": dict(verified, what="rank 0's shard of the last step: matrix + missed == contacts "
                                          "per interval, per-cell targets, occupancy parity, status 0"),
             "cell_epochs_per_s": job_epochs * args.steps / dt,
@@ -548,9 +558,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "cells_per_gpu": cells_per_gpu,
                        "total_cells": total_cells, "tasks_per_gpu": n_tasks,
-                       "cell_epochs_per_gpu_step": epochs,
+                       "cell_epochs_per_gpu_step": epochs, "lef_epochs_per_gpu_step": lef_epochs,
                        "longest_cell_epochs": longest, "mean_cell_epochs": epochs / max(n_tasks, 1), "seed": 0,
                        "waves_per_cell": launch_mode(sim.launch_info()),
+                       "size_class": size_class(sim.launch_info()),
                        "parallelism": f"cells sharded over {world} GPU(s); per-interval "
                                       + ("RCCL" if args.dist_backend == "nccl" else "gloo (host copies)")
                                       + " sum-reduce issued on a side stream as intervals complete"},

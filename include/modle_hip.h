@@ -212,8 +212,14 @@ typedef struct modle_hip_launch_info {
   uint64_t helper_waves;             /* per main wave: 1 in helper-wave mode, else 0 */
   uint64_t prng_producer_waves;      /* per main wave: 1 when a third wave produces the PRNG blocks */
   uint64_t tail_helpers;             /* 1: waves that find the queue empty help running cells */
+  uint64_t size_class;               /* 0: NARROW kernels (16-bit LEF ids and moves), 1: WIDE (modle_hip_size_class) */
 } modle_hip_launch_info;
 int modle_hip_last_launch_info(modle_hip_handle* h, modle_hip_launch_info* info);
+/* Size class of a launch whose largest cell has `max_lefs` LEFs: 0 = NARROW (the kernels keep LEF ids and
+ * moves as 16-bit values: fewer than 65 536 LEFs and extrusion speeds whose moves provably fit; every
+ * real chromosome at the reference's defaults), 1 = WIDE (32-bit).  modle_hip_launch picks it per launch;
+ * results do not depend on it.  The environment variable MODLE_HIP_SIZE_CLASS=wide forces WIDE. */
+int modle_hip_size_class(const modle_hip_config* c, uint64_t max_lefs);
 /* HIP_VERSION the library was compiled with and hipRuntimeGetVersion() of the runtime it is bound to in
  * this process (a host process that also loads PyTorch-ROCm shares torch's bundled runtime with this
  * library, INTEGRATION.md: the binding warns when the major versions differ).  No device is touched. */

@@ -26,7 +26,7 @@ EXPORTS = [
     "modle_hip_cancel", "modle_hip_test_units", "modle_hip_interval_done",
     "modle_hip_enable_state_log", "modle_hip_get_state_log", "modle_hip_set_wait_timeout",
     "modle_hip_last_launch_info",
-    "modle_hip_runtime_versions",
+    "modle_hip_runtime_versions", "modle_hip_size_class",
 ]
 
 u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")

@@ -14,10 +14,12 @@
 #include <type_traits>
 #include <vector>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
 #include "modle_hip.h"
+#include "launch_common.hpp"
 #include "host_prng.hpp"
 
 namespace {
@@ -327,6 +329,13 @@ int modle_hip_make_tasks(const modle_hip_config* c, const char* chrom_name, uint
     modle_host::xoshiro_jump(state);
   }
   return MODLE_HIP_OK;
+}
+
+int modle_hip_size_class(const modle_hip_config* c, uint64_t max_lefs) {
+  // (the rule: modle_host::size_class_required, launch_common.hpp)
+  if (c == nullptr) return 1;
+  if (const char* e = std::getenv("MODLE_HIP_SIZE_CLASS"); e != nullptr && e[0] == 'w') return 1;
+  return modle_host::size_class_required(*c, max_lefs);
 }
 
 void modle_hip_sort_barriers(uint64_t* bar_pos, uint8_t* bar_dir, double* bar_stp_active,

@@ -2,6 +2,7 @@
 // lane-emulator harness (tests/wave_emu): digests modle_hip_config into the device-side Params
 // and converts between the ABI's 64-bit arrays and the device's 32-bit fields.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -58,6 +59,22 @@ inline const char* check_limits(const modle_hip_config& c, uint64_t start, uint6
   if (c.burnin_target_epochs_for_lef_activation == 0 && !c.skip_burnin)
     return "burnin_target_epochs_for_lef_activation must be positive";
   return nullptr;
+}
+
+// Size class a set-up NEEDS (sim_types.h; modle_hip_size_class adds the environment's override).
+// NARROW (0): LEF ids and moves fit 16 bits.  Ids: fewer than 65 536 LEFs.  Moves: a draw is speed + std * z;
+// the move adjustment (reference: simulation.cpp:350-407) raises a move by at most one per link of a chain of
+// consecutive units, i.e. by less than the number of LEFs; clamping and the collision passes only shorten
+// moves.  z is bounded at 40 here -- the stream cannot produce it (the ziggurat's tail would need a uniform
+// below 2^-1000) -- and the kernel ends a cell with ERR_MOVE_RANGE should a move ever exceed the limit, instead
+// of truncating it.
+inline int size_class_required(const modle_hip_config& c, uint64_t max_lefs) {
+  if (max_lefs >= 65536) return 1;
+  const double speed = static_cast<double>(std::max(std::max(c.rev_extrusion_speed, c.fwd_extrusion_speed),
+                                                    std::max(c.rev_extrusion_speed_burnin, c.fwd_extrusion_speed_burnin)));
+  const double sd = std::max(std::fabs(c.rev_extrusion_speed_std), std::fabs(c.fwd_extrusion_speed_std));
+  const double bound = speed + 40.0 * sd + static_cast<double>(max_lefs) + 2.0;
+  return bound <= 65533.0 ? 0 : 1;  // (MOVE_LIMIT of the NARROW class)
 }
 
 inline uint32_t pos_to_dev(uint64_t v) {
@@ -117,9 +134,18 @@ inline modle_dev::Workspace carve_workspace(void* base, uint32_t max_lefs, uint3
   ws.hist = reinterpret_cast<double*>(p);
   p += w.f64_words * 8;
   uint32_t* q = reinterpret_cast<uint32_t*>(p);
-  uint32_t** slots[12] = {&ws.r_pos, &ws.r_id, &ws.r_move, &ws.r_coll, &ws.f_pos, &ws.f_id,
-                          &ws.f_move, &ws.f_coll, &ws.epoch, &ws.r_rank, &ws.f_rank, &ws.stall};
-  for (int k = 0; k < 12; ++k) *slots[k] = q + static_cast<size_t>(k) * Lp;
+  ws.r_pos = q + 0 * Lp;
+  ws.r_id = reinterpret_cast<modle_dev::lefid_t*>(q + 1 * Lp);
+  ws.r_move = reinterpret_cast<modle_dev::move_t*>(q + 2 * Lp);
+  ws.r_coll = q + 3 * Lp;
+  ws.f_pos = q + 4 * Lp;
+  ws.f_id = reinterpret_cast<modle_dev::lefid_t*>(q + 5 * Lp);
+  ws.f_move = reinterpret_cast<modle_dev::move_t*>(q + 6 * Lp);
+  ws.f_coll = q + 7 * Lp;
+  ws.epoch = q + 8 * Lp;
+  ws.r_rank = q + 9 * Lp;
+  ws.f_rank = q + 10 * Lp;
+  ws.stall = q + 11 * Lp;
   for (uint32_t k = 0; k < modle_dev::NUM_TMP; ++k) ws.tmp[k] = q + (12 + static_cast<size_t>(k)) * Lp;
   for (uint32_t d = 0; d < 2; ++d) ws.by_id_pos[d] = q + (12 + modle_dev::NUM_TMP + static_cast<size_t>(d)) * Lp;
   p += w.u32_words * 4;

@@ -1,4 +1,4 @@
-// modle_hip.hip -- gfx950 kernels and the device half of the C ABI (include/modle_hip.h).
+// modle_hip.hip -- host half of the C ABI (include/modle_hip.h); the gfx950 kernels are in sim_kernels.hip.
 //
 // One wavefront simulates one (interval, cell) task (reference seam:
 // Simulation::simulate_one_cell, src/libmodle/cpu/simulation.cpp:896-986, called from
@@ -31,419 +31,20 @@
 #include "modle_hip.h"
 #include "wave_hip.h"
 // clang-format off
-#include "sim_device.h"
+#include "sim_device.h"  // (constants and plain types of the device code; the kernels live in sim_kernels.hip)
 // clang-format on
+#include "sim_launch.h"
 #include "host_prng.hpp"
 #include "launch_common.hpp"
 #include "zig_tables.h"
 
 using namespace modle_dev;
 
+using namespace modle_launch;
+
 namespace {
 
-constexpr int kWavesPerBlock = MODLE_WAVES_PER_CU;
-constexpr int kThreadsPerBlock = kWavesPerBlock * 64;
-// Measurement build (round 5, profiles/r05a/lds_residency_ceiling.txt): MODLE_EXP_LDS_WS=<bytes> gives
-// MODLE_EXP_LDS_WAVES (1 or 2) waves of every workgroup -- waves 0 and MODLE_EXP_LDS_STRIDE (4: the same
-// SIMD, 1: two SIMDs) -- a slice of LDS that holds the unit arrays, the barrier states and the lists of
-// stalling barriers of their cell; with MODLE_EXP_LDS_WS_OFF the same waves keep them in device memory.
-#ifdef MODLE_EXP_LDS_WS
-#ifndef MODLE_EXP_LDS_WAVES
-#define MODLE_EXP_LDS_WAVES 2
-#endif
-#ifndef MODLE_EXP_LDS_STRIDE
-#define MODLE_EXP_LDS_STRIDE 4
-#endif
-constexpr int kLdsSlots = MODLE_EXP_LDS_WAVES;
-#else
-constexpr int kLdsSlots = kWavesPerBlock;
-#endif
-
-struct DeviceTables {
-  const u64* jump;   // JUMP_TABLE_WORDS
-  const f64* zig;    // norm_x[129] norm_y[129] exp_x[257] exp_y[257]
-};
-constexpr int kZigWords = 129 + 129 + 257 + 257;
-
-struct SimArgs {
-  Params params;
-  DeviceTables tables;
-  const Interval* intervals;
-  const Task* tasks;
-  CellResult* results;
-  u32* status;        // one word per task
-  u32* task_counter;
-  const u32* abort_flag;  // raised by modle_hip_cancel while the kernel runs
-  u32* interval_remaining;  // host-visible: tasks of every interval still to finish in this launch
-  u64* trace;  // diagnostic per-epoch trace of task 0 (MODLE_HIP_TRACE) or nullptr
-  u32 trace_cap;
-  u32 pad2_;
-  u64* phase_ticks;  // profiling build only
-  u64* state_log;    // MODLE_STATE_LOG build: n_tasks x state_log_cap records, or nullptr
-  u32 state_log_cap;
-  u32 pad3_;
-  char* workspace;
-  u64 workspace_stride;
-  u32 n_tasks;
-  u32 max_lefs;
-  u32 max_barriers;
-  u32 active_waves;  // waves of every workgroup that pull tasks (diagnostic: MODLE_HIP_ACTIVE_WAVES)
-  // helper-wave mode (sim_pair.h), chosen by the host for launches with at most half as many tasks
-  // as wave slots: waves 0 .. pair_mains-1 of a workgroup pull tasks, wave 7-m is the helper of
-  // main wave m (waves are dealt to the four SIMDs in turn: with one or two main waves per
-  // workgroup every wave of a pair has a SIMD of its own); 0 = off
-  u32 pair_mains;
-  // launches that fill the slots: a wave that finds the queue empty becomes the helper of a main
-  // wave of its workgroup that is still running (sim_pair.h: PAIR_STATE); 0 = off
-  u32 tail_helpers;
-  // tests only (MODLE_HIP_TEST_FAULT): a fault injected into the hand-over protocol (sim_helper.h)
-  u32 test_fault;
-};
-
-__device__ __forceinline__ Workspace device_carve(char* base, u32 max_lefs, u32 max_barriers, u32 hist_len,
-                                                  char* lds_base = nullptr) {
-  // mirrors modle_host::carve_workspace
-  const u64 Lp = (static_cast<u64>(max_lefs) + 63) & ~u64(63);
-  u64 pw = 1;
-  const u32 ml = max_lefs < 64 ? 64 : max_lefs;
-  while (pw < ml) pw <<= 1;
-  Workspace ws;
-  char* p = wave::as_global(base);
-  ws.sort_keys = reinterpret_cast<u64*>(p);
-  p += pw * 8;
-  ws.hist = reinterpret_cast<f64*>(p);
-  p += 2 * static_cast<u64>(hist_len) * 8;
-#if defined(MODLE_EXP_LDS_WS) && !defined(MODLE_EXP_LDS_WS_OFF)
-  // (the unit arrays, the barrier states and the lists of stalling barriers: in this wave's slice of LDS)
-  if (lds_base != nullptr) p = lds_base;
-#else
-  (void)lds_base;
-#endif
-  u32* q = reinterpret_cast<u32*>(p);
-  ws.r_pos = q + 0 * Lp;
-  ws.r_id = q + 1 * Lp;
-  ws.r_move = q + 2 * Lp;
-  ws.r_coll = q + 3 * Lp;
-  ws.f_pos = q + 4 * Lp;
-  ws.f_id = q + 5 * Lp;
-  ws.f_move = q + 6 * Lp;
-  ws.f_coll = q + 7 * Lp;
-  ws.epoch = q + 8 * Lp;
-  ws.r_rank = q + 9 * Lp;
-  ws.f_rank = q + 10 * Lp;
-  ws.stall = q + 11 * Lp;
-  for (u32 k = 0; k < NUM_TMP; ++k) ws.tmp[k] = q + (12 + static_cast<u64>(k)) * Lp;
-  for (u32 d = 0; d < 2; ++d) ws.by_id_pos[d] = q + (12 + NUM_TMP + static_cast<u64>(d)) * Lp;
-  p += static_cast<u64>(NUM_STATE_ARRAYS) * Lp * 4;
-  ws.bar_active = reinterpret_cast<u8*>(p);
-  const u64 Bp = (static_cast<u64>(max_barriers) + 63) & ~u64(63);
-  p += Bp;
-  u32* hq = reinterpret_cast<u32*>(p);
-  ws.hit_pos[0] = hq;
-  ws.hit_pos[1] = hq + Bp;
-  ws.hit_idx[0] = hq + 2 * Bp;
-  ws.hit_idx[1] = hq + 3 * Bp;
-  ws.capacity_lefs = max_lefs;
-  ws.capacity_barriers = max_barriers;
-  return ws;
-}
-
-struct BlockLds {
-  alignas(16) u64 jump[JUMP_TABLE_WORDS];  // rows are read 128 bits at a time
-  f64 zig[kZigWords];
-  u64 ring[kLdsSlots][RNG_RING];
-  u64 rng_state[kLdsSlots][4 * 64];
-  u64 rng_snap[kLdsSlots][8];
-  u64 sort_keys[kLdsSlots][SORT_LDS_CAP];
-  u32 stage[kLdsSlots][STAGE_CAP];
-  u32 pairbox[kLdsSlots][PAIR_WORDS];  // helper-wave mode: hand-over words of main wave w (sim_pair.h)
-#ifdef MODLE_EXP_LDS_WS
-  alignas(16) char ws[kLdsSlots][MODLE_EXP_LDS_WS];
-#endif
-};
-
-__device__ __forceinline__ WaveLds make_wave_lds(BlockLds& s, int wave_in_block) {
-  WaveLds l;
-  l.ring = s.ring[wave_in_block];
-  l.rng_state = s.rng_state[wave_in_block];
-  l.rng_snap = s.rng_snap[wave_in_block];
-  l.abort_flag = nullptr;
-  l.mbox = nullptr;
-  l.pair_dynamic = false;
-  l.jump_table = s.jump;
-  l.zig_norm_x = s.zig;
-  l.zig_norm_y = s.zig + 129;
-  l.zig_exp_x = s.zig + 258;
-  l.zig_exp_y = s.zig + 258 + 257;
-  l.sort_lds = s.sort_keys[wave_in_block];
-  l.stage = s.stage[wave_in_block];
-  l.phase_ticks = nullptr;
-  l.state_log = nullptr;
-  l.state_log_cap = 0;
-  l.trace = nullptr;
-  l.trace_cap = 0;
-  return l;
-}
-
-__device__ __forceinline__ void load_block_tables(BlockLds& s, const DeviceTables& t, int nthreads) {
-  // (hand-over words of the helper-wave mode -- the first lane-state words of a producer wave double
-  // as its own: sequence numbers start from zero on both sides, no main wave is running yet)
-  for (u32 i = threadIdx.x; i < static_cast<u32>(kLdsSlots) * PAIR_WORDS; i += nthreads) {
-    s.pairbox[i / PAIR_WORDS][i % PAIR_WORDS] = 0;
-    reinterpret_cast<u32*>(s.rng_state[i / PAIR_WORDS])[i % PAIR_WORDS] = 0;
-  }
-  const u64* jump = wave::as_global(t.jump);
-  const f64* zig = wave::as_global(t.zig);
-  for (u32 i = threadIdx.x; i < JUMP_TABLE_WORDS; i += nthreads) s.jump[i] = jump[i];
-  for (u32 i = threadIdx.x; i < static_cast<u32>(kZigWords); i += nthreads) s.zig[i] = zig[i];
-  __syncthreads();
-}
-
-// The task loop of a main wave.
-__device__ __forceinline__ void simulate_tasks(const SimArgs& a, const WaveLds& lds, u32 slot, int wave_in_block,
-                                               char* lds_ws = nullptr) {
-#ifdef MODLE_EXP_LDS_WS
-  const Workspace ws = device_carve(a.workspace + static_cast<u64>(slot) * a.workspace_stride,
-                                    a.max_lefs, a.max_barriers, a.params.hist_len, lds_ws);
-#else
-  const Workspace ws = device_carve(a.workspace + static_cast<u64>(slot) * a.workspace_stride,
-                                    a.max_lefs, a.max_barriers, a.params.hist_len);
-#endif
-  if (lds.pair_dynamic) pair_open(lds.mbox);  // this main wave is running: an idle wave may become its helper
-  u32 finished_interval = 0xFFFFFFFFu;  // interval of the task this wave has just completed
-#ifdef MODLE_PHASE_TIMERS
-  const u64 t_enter = wave::clock();
-#endif
-  for (;;) {
-    // Pop one task.  Only lane 0 touches the counter, so this block branches on the lane id; the
-    // wave barrier (a convergent operation the optimizer may not duplicate) and the laundered
-    // lane id keep jump threading from routing the other 63 lanes around the pop along a second
-    // back edge, which would split the wave for the convergent operations that follow.
-    wave::lockstep();
-    u32 leader = wave::lane();
-    asm volatile("" : "+v"(leader));
-    u32 t = 0;
-    if (leader == 0) {
-      // the previous task's outputs are complete (release fence at the end of the iteration):
-      // tell the host, which may start reducing that interval's matrix once the count is zero
-      if (finished_interval != 0xFFFFFFFFu)
-        __hip_atomic_fetch_sub(a.interval_remaining + finished_interval, 1u, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
-      t = atomicAdd(wave::as_global(a.task_counter), 1u);
-    }
-    finished_interval = 0xFFFFFFFFu;
-    t = wave::bcast(t, 0);  // scalar from here on: the queue loop is a scalar loop
-    if (t >= a.n_tasks) {  // every wave leaves once the queue is empty
-#ifdef MODLE_PHASE_TIMERS
-      if (a.phase_ticks != nullptr && wave::lane() == 0) {
-        // how long this wave had work for: sum, longest, shortest (the launch lasts as long as the longest)
-        const unsigned long long busy = wave::clock() - t_enter;
-        unsigned long long* const pt = reinterpret_cast<unsigned long long*>(wave::as_global(a.phase_ticks));
-        atomicAdd(pt + 16, busy);
-        atomicMax(pt + 17, busy);
-        atomicMin(pt + 18, busy);
-      }
-#endif
-      if (lds.mbox == nullptr) break;
-      if (!lds.pair_dynamic) {
-        pair_dismiss(lds.mbox);
-      } else {
-        pair_close(lds.mbox);  // no more hand-overs; a helper that had claimed this wave is dismissed
-      }
-      break;
-    }
-    if (wave::uniform(wave::load_system_u32(wave::as_global(a.abort_flag))) != 0) {
-      // cancelled: tasks that never started are reported as such (all lanes store the same word)
-      CellResult none;
-      __builtin_memset(&none, 0, sizeof(none));
-      wave::as_global(a.results)[t] = none;
-      wave::as_global(a.status)[t] = ERR_CANCELLED;
-      finished_interval = wave::as_global(a.tasks)[t].interval;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      continue;
-    }
-    const Task task = wave::as_global(a.tasks)[t];
-    CellResult res;
-    WaveLds lds_t = lds;
-    lds_t.phase_ticks = wave::as_global(a.phase_ticks);
-    lds_t.abort_flag = wave::as_global(a.abort_flag);
-    if (a.state_log != nullptr) {
-      lds_t.state_log = wave::as_global(a.state_log) + static_cast<u64>(t) * a.state_log_cap * STATE_LOG_WORDS;
-      lds_t.state_log_cap = a.state_log_cap;
-    }
-    if (t == 0 && a.trace != nullptr) {
-      lds_t.trace = a.trace;
-      lds_t.trace_cap = a.trace_cap;
-    }
-#ifdef MODLE_PHASE_TIMERS
-    const u64 t_task = wave::clock();
-#endif
-    const u32 st = simulate_cell(a.params, wave::as_global(a.intervals)[task.interval], task, ws, lds_t, res);
-#ifdef MODLE_PHASE_TIMERS
-    if (a.phase_ticks != nullptr) {  // (per task: start, end, wave slot -- MODLE_PROF_TASK_TIMES writes them out)
-      u64* const tt = wave::as_global(a.phase_ticks) + 20 + 3 * static_cast<u64>(t);
-      tt[0] = t_task;
-      tt[1] = wave::clock();
-      tt[2] = slot;
-    }
-#endif
-    // all lanes store the same words (no lane-dependent branch at the end of the loop body)
-    wave::as_global(a.results)[t] = res;
-    wave::as_global(a.status)[t] = st;
-    finished_interval = task.interval;
-    // contact increments (memory-side atomics) and the result words are performed before the
-    // completion count of the interval drops
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  }
-}
-
-__global__ __launch_bounds__(kThreadsPerBlock) void modle_simulate_cells(SimArgs a) {
-  __shared__ BlockLds s;
-  load_block_tables(s, a.tables, kThreadsPerBlock);
-  const int wave_in_block = wave::uniform(static_cast<int>(threadIdx.x / 64));
-  const u32 slot = blockIdx.x * kWavesPerBlock + wave_in_block;
-#ifdef MODLE_EXP_LDS_WS
-  // (measurement build: waves 0 and MODLE_EXP_LDS_STRIDE only, no helpers)
-  if (wave_in_block % MODLE_EXP_LDS_STRIDE != 0 || wave_in_block / MODLE_EXP_LDS_STRIDE >= kLdsSlots) return;
-  {
-    const int ls = wave_in_block / MODLE_EXP_LDS_STRIDE;
-    WaveLds lds = make_wave_lds(s, ls);
-    simulate_tasks(a, lds, slot, wave_in_block, s.ws[ls]);
-  }
-#else
-  WaveLds lds = make_wave_lds(s, wave_in_block);
-  // Roles (sim_pair.h).  Launches that leave wave slots empty (pair_mains != 0): fixed trios of
-  // main wave / helper / PRNG producer.  Launches that fill the slots: every wave is a main wave
-  // (one cell per wave) until the queue is empty, and then the helper of a main wave of its
-  // workgroup that is still running.
-#ifdef MODLE_NO_HELPERS  // (measurement: what the helper and producer loops cost the main path by being in the kernel)
-  const bool fixed = false, dynamic = false;
-#else
-  const bool fixed = a.pair_mains != 0;
-  const bool dynamic = !fixed && a.tail_helpers != 0;
-#endif
-  int serve_main = -1;  // >= 0: this wave is the helper of that main wave
-  u32* feed = nullptr;
-  if (fixed) {
-    // with one or two main waves per workgroup there are waves to spare: wave 2 + m produces the
-    // PRNG blocks for the helper of main wave m while that helper draws the moves (pair_feed)
-#ifndef MODLE_RNG_PHILOX
-    if (a.pair_mains <= 2 && wave_in_block >= 2 && wave_in_block < 4) {
-      const int m = wave_in_block - 2;
-      if (static_cast<u32>(m) >= a.pair_mains) return;
-      const WaveLds lm = make_wave_lds(s, m);
-      pair_feed(lm.ring, lm.jump_table, lm.rng_state, lm.rng_snap, reinterpret_cast<u32*>(s.rng_state[wave_in_block]),
-                wave::as_global(a.abort_flag));
-      return;
-    }
-#endif
-    const int main_wave = wave_in_block < kWavesPerBlock / 2 ? wave_in_block : kWavesPerBlock - 1 - wave_in_block;
-    if (static_cast<u32>(main_wave) >= a.pair_mains) return;
-#ifndef MODLE_RNG_PHILOX
-    if (a.pair_mains <= 2) feed = reinterpret_cast<u32*>(s.rng_state[2 + main_wave]);
-#endif
-    if (wave_in_block != main_wave) serve_main = main_wave;
-  }
-  if (serve_main < 0) {
-    if (static_cast<u32>(wave_in_block) >= a.active_waves) return;
-    if (fixed || dynamic) lds.mbox = s.pairbox[wave_in_block];
-    lds.pair_dynamic = dynamic;
-    simulate_tasks(a, lds, slot, wave_in_block);
-    if (!dynamic) return;
-  }
-  for (;;) {
-    u32* mbox = nullptr;
-    u32 seen = 0;  // (fixed roles: the request counter starts from zero)
-    if (dynamic) {
-      // the queue is empty: claim a main wave of this workgroup that is still running without a
-      // helper (sim_pair.h: pair_claim)
-      serve_main = pair_claim(&s.pairbox[0][0], kWavesPerBlock, wave_in_block, seen);
-      if (serve_main < 0) return;
-      mbox = s.pairbox[serve_main];
-    } else {
-      mbox = s.pairbox[serve_main];
-    }
-    {
-      // the helper: the main wave's generator, tables and workspace, its own staging and sort buffers
-      // (every other field of the context zero: no list, no filter, no error)
-      Cell c{};
-      c.p = &a.params;
-      c.lds = make_wave_lds(s, serve_main);
-      c.lds.stage = lds.stage;
-      c.lds.sort_lds = lds.sort_lds;
-      c.lds.abort_flag = wave::as_global(a.abort_flag);
-      c.ws = device_carve(a.workspace + static_cast<u64>(blockIdx.x * kWavesPerBlock + serve_main) * a.workspace_stride,
-                          a.max_lefs, a.max_barriers, a.params.hist_len);
-      c.g.ring = c.lds.ring;
-      c.g.jump = c.lds.jump_table;
-      c.g.state = c.lds.rng_state;
-      c.g.snap = c.lds.rng_snap;
-      pair_serve(c, wave::as_global(a.intervals), mbox, feed, seen, a.test_fault);
-    }
-    if (!dynamic) return;
-  }
-#endif
-}
-
-struct PhaseArgs {
-  Params params;
-  DeviceTables tables;
-  Interval interval;
-  char* workspace;
-  u32* image;  // TestImage: nine arrays of n words
-  u32 mask;
-  u32 n;
-  u64 prng[4];
-  u64* raws_out;
-  u32* status_out;
-  u32 max_barriers;
-};
-
-__global__ __launch_bounds__(64) void modle_test_phases(PhaseArgs a) {
-  __shared__ BlockLds s;
-  load_block_tables(s, a.tables, 64);
-  const WaveLds lds = make_wave_lds(s, 0);
-  const Workspace ws = device_carve(a.workspace, a.n, a.max_barriers, 4);
-  u64 raws = 0;
-  TestImage img;
-  img.rev_pos = a.image + 0 * a.n;
-  img.fwd_pos = a.image + 1 * a.n;
-  img.epoch = a.image + 2 * a.n;
-  img.rev_rank = a.image + 3 * a.n;
-  img.fwd_rank = a.image + 4 * a.n;
-  img.rev_moves = a.image + 5 * a.n;
-  img.fwd_moves = a.image + 6 * a.n;
-  img.rev_coll = a.image + 7 * a.n;
-  img.fwd_coll = a.image + 8 * a.n;
-  const u32 st = run_test_phases(a.params, a.interval, ws, lds, img, a.mask, a.n, a.prng, raws);
-  if (wave::lane() == 0) {
-    *a.raws_out = raws;
-    *a.status_out = st;
-  }
-}
-
-struct UnitArgs {
-  Params params;
-  DeviceTables tables;
-  Interval interval;
-  char* workspace;
-  const u64* in;
-  u64* out;
-  u32* status_out;
-  u32 what;
-  u32 n;
-};
-
-__global__ __launch_bounds__(64) void modle_test_units(UnitArgs a) {
-  __shared__ BlockLds s;
-  load_block_tables(s, a.tables, 64);
-  const WaveLds lds = make_wave_lds(s, 0);
-  const Workspace ws = device_carve(a.workspace, a.n, 0, 4);
-  const u32 st = run_test_units(a.params, a.interval, ws, lds, a.what, wave::as_global(a.in), a.n,
-                                wave::as_global(a.out));
-  if (wave::lane() == 0) *a.status_out = st;
-}
-
+// ---------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -1000,7 +601,8 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
     __atomic_store_n(h->h_abort, 0u, __ATOMIC_RELEASE);
     h->cancelled = false;
     const bool ev0 = hipEventRecord(h->ev_start, h->stream) == hipSuccess;
-    hipLaunchKernelGGL(modle_simulate_cells, dim3(grid), dim3(kThreadsPerBlock), 0, h->stream, a);
+    const bool wide = modle_hip_size_class(&h->cfg, max_lefs) != 0;
+    if (wide) simulate_wide(grid, h->stream, a); else simulate_narrow(grid, h->stream, a);
     HIP_TRY(hipGetLastError());
     // The kernel is enqueued: commit the bookkeeping NOW.  Nothing after this point may make the
     // call fail -- a caller that sees an error retries, and the same tasks would then be simulated
@@ -1026,6 +628,7 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
     h->last_launch.prng_producer_waves = (a.pair_mains != 0 && a.pair_mains <= 2) ? 1 : 0;
 #endif
     h->last_launch.tail_helpers = a.tail_helpers;
+    h->last_launch.size_class = wide ? 1 : 0;
     const bool ev1 = hipEventRecord(h->ev_stop, h->stream) == hipSuccess;
     h->timing_valid = ev0 && ev1;
     if (!h->timing_valid) (void)hipGetLastError();  // (clears the sticky error of the failed record)
@@ -1437,7 +1040,12 @@ int modle_hip_test_phases(modle_hip_handle* h, uint32_t phase_mask, uint64_t sta
   a.raws_out = h->d_phase_out.p;
   a.status_out = reinterpret_cast<u32*>(h->d_phase_out.p + 1);
   a.max_barriers = static_cast<u32>(n_barriers);
-  hipLaunchKernelGGL(modle_test_phases, dim3(1), dim3(64), 0, nullptr, a);
+  {
+    // the class the product would run this state in; WIDE also when a caller's move does not fit NARROW
+    bool wide = modle_hip_size_class(&h->cfg, n) != 0;
+    for (size_t i = 0; i < n; ++i) wide = wide || rev_moves[i] > 65533 || fwd_moves[i] > 65533;
+    if (wide) test_phases_wide(a); else test_phases_narrow(a);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   uint64_t out[2] = {0, 0};
@@ -1500,7 +1108,7 @@ int modle_hip_test_units(modle_hip_handle* h, uint32_t what, const uint64_t* in,
   a.status_out = d_status.p;
   a.what = what;
   a.n = static_cast<u32>(n);
-  hipLaunchKernelGGL(modle_test_units, dim3(1), dim3(64), 0, nullptr, a);
+  if (modle_hip_size_class(&h->cfg, n) != 0) test_units_wide(a); else test_units_narrow(a);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   u32 st = 0;

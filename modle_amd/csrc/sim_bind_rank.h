@@ -201,7 +201,7 @@ MODLE_DEV bool rank_pair_out_of_order(const Workspace& ws, const u32* where, u32
 // this hardware a wait for a load also waits for every store issued before it.
 template <bool FWD>
 MODLE_DEV bool rank_merge(const u64* keys, u32 n_new, u32 n_old, const u32* old_pos,
-                          const u32* old_id, const u32* new_id, u32* out_pos, u32* out_id,
+                          const lefid_t* old_id, const lefid_t* new_id, u32* out_pos, lefid_t* out_id,
                           u32* where_new, u32* cnt_lds) {
   const u32 lane = wave::lane();
   bool ties = false;
@@ -345,9 +345,9 @@ MODLE_DEV void rank_finish(Cell& c, bool ties, const u32* where, u32 t_lo, u32 t
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
   u32*& pos = FWD ? ws.f_pos : ws.r_pos;
-  u32*& ids = FWD ? ws.f_id : ws.r_id;
+  lefid_t*& ids = FWD ? ws.f_id : ws.r_id;
   u32* out_pos = ws.tmp[0];
-  u32* out_id = ws.tmp[1];
+  lefid_t* out_id = as_ids(ws.tmp[1]);
   u32* where_new = ws.tmp[7];
   const bool by_epoch_only = where == nullptr;
   if (ties) {
@@ -392,7 +392,7 @@ MODLE_DEV void rank_finish(Cell& c, bool ties, const u32* where, u32 t_lo, u32 t
   }
   // 5. the new arrays become current
   swap_ptr(pos, ws.tmp[0]);
-  swap_ptr(ids, ws.tmp[1]);
+  swap_with_scratch(ids, ws.tmp[1]);
   if (!by_epoch_only) {
     if (FWD) swap_ptr(ws.f_rank, ws.tmp[7]); else swap_ptr(ws.r_rank, ws.tmp[7]);
   }
@@ -421,8 +421,8 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
   const u32 n_listed = wave::uniform(c.n_keys);
   const u32 lane = wave::lane();
   const u32* pos = FWD ? ws.f_pos : ws.r_pos;
-  const u32* ids = FWD ? ws.f_id : ws.r_id;
-  const u32* marks = FWD ? ws.f_move : ws.r_move;
+  const lefid_t* ids = FWD ? ws.f_id : ws.r_id;
+  const move_t* marks = FWD ? ws.f_move : ws.r_move;
 #ifdef MODLE_SUBTIMER_RANK
   const u64 t_enter = wave::clock();
 #endif
@@ -462,7 +462,7 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
   const auto cnt_load = [&](u32 q, u64 key) -> u32 { return narrow ? static_cast<u32>(key) & 0xFFFFu : cnt32[q]; };
   const u64* src = reinterpret_cast<const u64*>(FWD ? ws.tmp[4] : ws.tmp[2]);
   u32* out_pos = ws.tmp[0];
-  u32* out_id = ws.tmp[1];
+  lefid_t* out_id = as_ids(ws.tmp[1]);
   const u32 nblk = (n + 255) / 256;
   wave::lockstep();
   for (u32 base = 0; base < n_listed; base += 64) {
@@ -672,7 +672,7 @@ MODLE_DEV_NOINLINE bool rank_update_listed(Cell& c) {
       // loads at the top of the loop becomes a wait for these stores as well)
       u32* const dump = reinterpret_cast<u32*>(ws.sort_keys) + lane;
       *(carried[j] ? &out_pos[slot[j]] : dump) = pp[j];
-      *(carried[j] ? &out_id[slot[j]] : dump) = oid[j];
+      *(carried[j] ? &out_id[slot[j]] : reinterpret_cast<lefid_t*>(dump)) = static_cast<lefid_t>(oid[j]);
     }
     if (wave::any(tie)) {
       ties = true;
@@ -741,12 +741,12 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
   ensure_inverse<FWD>(c);  // the previous ranks by LEF id are the last tie-break
   const u32 lane = wave::lane();
   const u32* pos = FWD ? ws.f_pos : ws.r_pos;
-  const u32* ids = FWD ? ws.f_id : ws.r_id;
-  const u32* marks = FWD ? ws.f_move : ws.r_move;
+  const lefid_t* ids = FWD ? ws.f_id : ws.r_id;
+  const move_t* marks = FWD ? ws.f_move : ws.r_move;
   u32* where = FWD ? ws.f_rank : ws.r_rank;  // previous ranks until the final scatter
   u32* old_pos = ws.tmp[2];
-  u32* old_id = ws.tmp[3];
-  u32* new_id = ws.tmp[4];
+  lefid_t* old_id = as_ids(ws.tmp[3]);
+  lefid_t* new_id = as_ids(ws.tmp[4]);
   u64* keys_lds = c.lds.sort_lds;
   u64* keys_glb = ws.sort_keys;
 
@@ -844,7 +844,7 @@ MODLE_DEV_NOINLINE void rank_update(Cell& c, bool all_new) {
   //    new inverse permutation.  Equal positions of bound units are the only thing this does not
   //    order completely (epoch rule); they are rare, so they are only flagged here.
   u32* out_pos = ws.tmp[0];
-  u32* out_id = ws.tmp[1];
+  lefid_t* out_id = as_ids(ws.tmp[1]);
   u32* where_new = ws.tmp[7];
   const bool ties = (n_new <= SORT_LDS_CAP)
                         ? rank_merge<FWD>(keys_lds, n_new, n_old, old_pos, old_id, new_id, out_pos,

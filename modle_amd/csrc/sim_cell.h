@@ -103,6 +103,10 @@ constexpr u32 RING_SPILL_AT = 64;
 constexpr u32 ERR_LIST_OVERFLOW = 1;
 constexpr u32 ERR_TRIAL_OVERFLOW = 2;
 constexpr u32 ERR_INTERNAL = 3;
+// NARROW class only: a move beyond MOVE_LIMIT (sim_types.h).  The host classes a launch NARROW only when the
+// parameters rule such a move out (modle_hip_size_class); this is the net under that proof.
+constexpr u32 ERR_MOVE_RANGE = 5;
+constexpr bool NARROW_MOVES = sizeof(move_t) < sizeof(u32);
 // (ERR_CANCELLED = 4, sim_rng.h: the host raised the abort word -- modle_hip_cancel, or the deadline
 // of modle_hip_wait)
 
@@ -127,6 +131,19 @@ MODLE_DEV void swap_ptr(T*& a, T*& b) {
   a = b;
   b = t;
 }
+
+// an id / move array changes places with a scratch array (a 32-bit slot either way: sim_types.h)
+template <class T>
+MODLE_DEV void swap_with_scratch(T*& a, u32*& scratch) {
+  T* t = a;
+  a = reinterpret_cast<T*>(scratch);
+  scratch = reinterpret_cast<u32*>(t);
+}
+// a scratch array seen as ids / moves
+MODLE_DEV lefid_t* as_ids(u32* scratch) { return reinterpret_cast<lefid_t*>(scratch); }
+MODLE_DEV const lefid_t* as_ids(const u32* scratch) { return reinterpret_cast<const lefid_t*>(scratch); }
+MODLE_DEV move_t* as_moves(u32* scratch) { return reinterpret_cast<move_t*>(scratch); }
+MODLE_DEV const move_t* as_moves(const u32* scratch) { return reinterpret_cast<const move_t*>(scratch); }
 
 // first barrier index whose position is >= key
 MODLE_DEV u32 bar_lower_bound(const Interval& iv, u64 key) {
@@ -156,7 +173,7 @@ MODLE_DEV_NOINLINE void ensure_inverse(Cell& c) {
   Workspace& ws = c.ws;
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
-  const u32* ids = FWD ? ws.f_id : ws.r_id;
+  const lefid_t* ids = FWD ? ws.f_id : ws.r_id;
   u32* rank = FWD ? ws.f_rank : ws.r_rank;
   const u32 nblk = (n + 255) / 256;
   for (u32 t = 0; t < nblk; ++t) {

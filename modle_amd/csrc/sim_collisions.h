@@ -261,7 +261,7 @@ MODLE_DEV_NOINLINE void detect_lef_bar_det(Cell& c, BoundaryCounts bc) {
   const u32 major_dir = FWD ? DIR_FWD : DIR_REV;
   const u32 lane = wave::lane();
   const u32* pos = FWD ? ws.f_pos : ws.r_pos;
-  const u32* moves = FWD ? ws.f_move : ws.r_move;
+  const move_t* moves = FWD ? ws.f_move : ws.r_move;
   u32* coll = FWD ? ws.f_coll : ws.r_coll;
   u32* barpos = stalling_barrier_positions<FWD>(ws);
   // positions of the compacted barriers and their indices (| HITBAR_HARD): at most BAR_FILL entries,
@@ -593,7 +593,7 @@ MODLE_DEV_NOINLINE u32 detect_lef_bar_sweep(Cell& c, BoundaryCounts bc) {
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
   const u32* pos = FWD ? ws.f_pos : ws.r_pos;
-  const u32* moves = FWD ? ws.f_move : ws.r_move;
+  const move_t* moves = FWD ? ws.f_move : ws.r_move;
   u32* coll = FWD ? ws.f_coll : ws.r_coll;
   u32* barpos = stalling_barrier_positions<FWD>(ws);
   // positions of the compacted barriers and their indices (| HITBAR_HARD): at most BAR_FILL entries,
@@ -1527,7 +1527,8 @@ struct SecondaryFilter {
     wave::U32x4 P, M, C, B;
   };
   const u32 *pos, *coll, *barpos;
-  u32 *moves, *q_k, *dump;
+  move_t *moves, *dump_m;
+  u32 *q_k, *dump;
   u32 n, lane, nblk, cap, n_cand, carry_pos, carry_coll;
   i32 f_first;
   bool correct_lef_bar, do_secondary, carry_pending;
@@ -1557,6 +1558,7 @@ struct SecondaryFilter {
     // wait for every store in flight)
     q_k = FWD ? ws.tmp[1] : ws.tmp[0];
     dump = reinterpret_cast<u32*>(ws.sort_keys) + 2 * lane + (FWD ? 1 : 0);
+    dump_m = reinterpret_cast<move_t*>(dump);
     cap = list_cap;
     correct_lef_bar = lef_bar;
     do_secondary = secondary;
@@ -1591,7 +1593,7 @@ struct SecondaryFilter {
         const u32 bp = g.B.v[q];
         M[j] = (FWD ? bp - P[j] : P[j] - bp) - 1;
       }
-      *((act[j] && M[j] != M0) ? &moves[k[j]] : dump) = M[j];
+      *((act[j] && M[j] != M0) ? &moves[k[j]] : dump_m) = static_cast<move_t>(M[j]);
     }
     // the blocker of a unit: the unit visited before it
     const u32 pP_in = wave::shfl_up1(P[3]), pC_in = wave::shfl_up1(C[3]);
@@ -1646,8 +1648,8 @@ MODLE_DEV_NOINLINE u32 secondary_resolve(Cell& c, u32 n_cand, u32* list, u32 lis
   const Params& p = *c.p;
   const u32 lane = wave::lane();
   const u32* pos = FWD ? ws.f_pos : ws.r_pos;
-  const u32* ids = FWD ? ws.f_id : ws.r_id;
-  u32* moves = FWD ? ws.f_move : ws.r_move;
+  const lefid_t* ids = FWD ? ws.f_id : ws.r_id;
+  move_t* moves = FWD ? ws.f_move : ws.r_move;
   u32* coll = FWD ? ws.f_coll : ws.r_coll;
   const u32* const q_k = FWD ? ws.tmp[1] : ws.tmp[0];
   // run_lef_lef_collision_trial (simulation_impl.hpp:93-96): no draw when the bypass probability

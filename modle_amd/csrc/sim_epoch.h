@@ -327,6 +327,10 @@ MODLE_DEV u32 simulate_cell(const Params& p, const Interval& iv, const Task& tas
       trace_stage(c, epoch, 2);
       PHASE(c, 7, barriers_next_state(c));
     }
+    if (NARROW_MOVES && c.error != 0) {  // (ERR_MOVE_RANGE: a move the NARROW class cannot hold)
+      status = c.error;
+      break;
+    }
     const bool coll_ok = phase_process_collisions(c);
     trace_stage(c, epoch, 3);
     if (!coll_ok) {

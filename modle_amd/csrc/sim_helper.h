@@ -61,7 +61,7 @@ MODLE_DEV void pair_serve(Cell& c, const Interval* intervals, u32* m, u32* feed,
       bc.n3 = wave::uniform(m[PAIR_BC + 1]);
       c.n_hit[1] = wave::uniform(m[PAIR_N_HIT + 1]);
       c.ws.f_pos = wave::as_global(reinterpret_cast<u32*>(pair_get_u64(m, PAIR_F_POS)));
-      c.ws.f_move = wave::as_global(reinterpret_cast<u32*>(pair_get_u64(m, PAIR_F_MOVE)));
+      c.ws.f_move = wave::as_global(reinterpret_cast<move_t*>(pair_get_u64(m, PAIR_F_MOVE)));
       detect_lef_bar<true>(c, bc);  // (ends with sync_mem)
       wave::lockstep();
       if (wave::lane() == 0) m[PAIR_ERR] = c.error;
@@ -73,7 +73,7 @@ MODLE_DEV void pair_serve(Cell& c, const Interval* intervals, u32* m, u32* feed,
       bc.n5 = wave::uniform(m[PAIR_BC]);
       bc.n3 = wave::uniform(m[PAIR_BC + 1]);
       c.ws.f_pos = wave::as_global(reinterpret_cast<u32*>(pair_get_u64(m, PAIR_F_POS)));
-      c.ws.f_move = wave::as_global(reinterpret_cast<u32*>(pair_get_u64(m, PAIR_F_MOVE)));
+      c.ws.f_move = wave::as_global(reinterpret_cast<move_t*>(pair_get_u64(m, PAIR_F_MOVE)));
       c.ws.tmp[1] = wave::as_global(reinterpret_cast<u32*>(pair_get_u64(m, PAIR_Q)));
       SecondaryFilter<true> ff;
       ff.init(c, bc, wave::uniform(m[PAIR_LIST_CAP]), true, true);
@@ -104,8 +104,8 @@ MODLE_DEV void pair_serve(Cell& c, const Interval* intervals, u32* m, u32* feed,
       c.g.feed_abort = abort_flag;
       c.g.feed_error = 0;
     }
-    generate_moves_by_id(c, burnin_completed ? p.rev_speed : p.rev_speed_burnin, p.rev_std, c.ws.tmp[8]);
-    generate_moves_by_id(c, burnin_completed ? p.fwd_speed : p.fwd_speed_burnin, p.fwd_std, c.ws.tmp[9]);
+    generate_moves_by_id(c, burnin_completed ? p.rev_speed : p.rev_speed_burnin, p.rev_std, as_moves(c.ws.tmp[8]));
+    generate_moves_by_id(c, burnin_completed ? p.fwd_speed : p.fwd_speed_burnin, p.fwd_std, as_moves(c.ws.tmp[9]));
     if (feed != nullptr) {
       // the producer stops (it may be a block ahead: the ring then ends where it says)
       wave::st_release_wg(&feed[FEED_STOP], fseq);

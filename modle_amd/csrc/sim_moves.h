@@ -99,11 +99,12 @@ MODLE_DEV_NOINLINE void generate_moves_dir(Cell& c, f64 speed, f64 std) {
   Workspace& ws = c.ws;
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
-  u32* moves = FWD ? ws.f_move : ws.r_move;
+  move_t* moves = FWD ? ws.f_move : ws.r_move;
   ensure_inverse<FWD>(c);
   const u32* rank = FWD ? ws.f_rank : ws.r_rank;
   if (std == 0.0) {
     const u32 move_int = static_cast<u32>(static_cast<u64>(wave::f_round(speed)));
+    if (NARROW_MOVES && move_int > MOVE_LIMIT) c.error = ERR_MOVE_RANGE;
     for (u32 base = 0; base < n; base += 64) {
       const u32 i = base + lane;
       if (i < n) moves[rank[i]] = ws.epoch[i] != UNBOUND ? move_int : 0;
@@ -148,6 +149,7 @@ MODLE_DEV_NOINLINE void generate_moves_dir(Cell& c, f64 speed, f64 std) {
     u32 mv = 0;
     if (bnd) mv = q_move[(head + static_cast<u32>(wave::popc64(bm & lanemask_lt(lane)))) % MOVQ_CAP];
     head += need;
+    if (NARROW_MOVES && wave::any(mv > MOVE_LIMIT)) c.error = ERR_MOVE_RANGE;
     if (act) moves[slot] = mv;
     }
   }
@@ -168,12 +170,13 @@ MODLE_DEV_NOINLINE void generate_moves_dir(Cell& c, f64 speed, f64 std) {
 // box against the scattering form: 23 % fewer bytes written to the fabric and a kernel 0.7 %
 // faster -- the adjustment pass itself takes twice as long (dependent gathers), every other pass
 // gains from the lighter write traffic.
-MODLE_DEV_NOINLINE void generate_moves_by_id(Cell& c, f64 speed_in, f64 std_in, u32* mv_by_id) {
+MODLE_DEV_NOINLINE void generate_moves_by_id(Cell& c, f64 speed_in, f64 std_in, move_t* mv_by_id) {
   const f64 speed = wave::own_regs(speed_in), std = wave::own_regs(std_in);
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
   if (std == 0.0) {
     const u32 move_int = static_cast<u32>(static_cast<u64>(wave::f_round(speed)));
+    if (NARROW_MOVES && move_int > MOVE_LIMIT) c.error = ERR_MOVE_RANGE;
     for (u32 base = 0; base < n; base += 64) {
       const u32 i = base + lane;
       if (i < n) mv_by_id[i] = move_int;
@@ -183,12 +186,16 @@ MODLE_DEV_NOINLINE void generate_moves_by_id(Cell& c, f64 speed_in, f64 std_in, 
   const u32* q_move = c.lds.stage;
   const u32* q_end = c.lds.stage + MOVQ_CAP;
   u32 head = 0, tail = 0;  // entries consumed / produced
+  u32 widest = 0;          // largest move this lane has stored
   for (u32 base = 0; base < n; base += 64) {
     const u32 need = umin(64u, n - base);
     while (tail - head < need) tail = draw_moves_step(c, speed, std, tail);
-    if (lane < need) mv_by_id[base + lane] = q_move[(head + lane) % MOVQ_CAP];
+    const u32 mv = lane < need ? q_move[(head + lane) % MOVQ_CAP] : 0u;
+    if (lane < need) mv_by_id[base + lane] = mv;
+    widest = umax(widest, mv);
     head += need;
   }
+  if (NARROW_MOVES && wave::any(widest > MOVE_LIMIT)) c.error = ERR_MOVE_RANGE;
   if (head != 0) {
     // hand back what the last step evaluated beyond the draw of the last LEF
     const u32 end_low = wave::uniform(q_end[(head - 1) % MOVQ_CAP]);
@@ -219,8 +226,10 @@ struct AdjustSweepX4 {
   struct Blk {
     wave::U32x4 P, M;
   };
-  const u32 *pos, *uid, *mv_in, *mv_by_id;
-  u32* mv_out;
+  const u32* pos;
+  const lefid_t* uid;
+  const move_t *mv_in, *mv_by_id;
+  move_t* mv_out;
   u32 n, lane, start, last, nblk;
   bool by_id, do_adjust, do_clamp;
   i32 carry_d;
@@ -248,7 +257,7 @@ struct AdjustSweepX4 {
       cur.M = wave::ld4(mv_in, in ? w : 0u);
     }
   }
-  MODLE_DEV_MEMBER void init(Cell& c, bool adjust, bool clamp, const u32* by_id_moves, u32* out) {
+  MODLE_DEV_MEMBER void init(Cell& c, bool adjust, bool clamp, const move_t* by_id_moves, move_t* out) {
     Workspace& ws = c.ws;
     n = wave::uniform(c.n_active);
     lane = wave::lane();
@@ -357,10 +366,11 @@ struct AdjustSweepX4 {
 };
 
 template <bool FWD>
-MODLE_DEV_NOINLINE i64 adjust_moves_x4(Cell& c, bool do_adjust, bool do_clamp, const u32* mv_by_id) {
+MODLE_DEV_NOINLINE i64 adjust_moves_x4(Cell& c, bool do_adjust, bool do_clamp, const move_t* mv_by_id) {
   AdjustSweepX4<FWD> sw;
-  sw.init(c, do_adjust, do_clamp, mv_by_id, c.ws.tmp[0]);
+  sw.init(c, do_adjust, do_clamp, mv_by_id, as_moves(c.ws.tmp[0]));
   for (u32 t = 0; t < sw.nblk; ++t) sw.step(t);
+  if (NARROW_MOVES && wave::any(sw.lane_max > MOVE_LIMIT)) c.error = ERR_MOVE_RANGE;
   return sw.viol_rank;
 }
 
@@ -369,7 +379,7 @@ MODLE_DEV_NOINLINE i64 adjust_moves_x4(Cell& c, bool do_adjust, bool do_clamp, c
 // `out_slot` / `swept`: the scratch array the sweep writes (ws.tmp[out_slot]) and, when the sweep
 // has been done already (adjust_moves_both_x4), the rank its replay starts from
 MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp,
-                                         const u32* mv_by_id = nullptr, u32 out_slot = 0,
+                                         const move_t* mv_by_id = nullptr, u32 out_slot = 0,
                                          const i64* swept = nullptr) {
   Workspace& ws = c.ws;
   const u32 n = wave::uniform(c.n_active);
@@ -377,8 +387,8 @@ MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp,
   const u64 start = c.iv->start;
   // landing positions minus ranks fit 32 bits on every real chromosome: scans at half the cost
   const bool narrow = wave::uniform(c.iv->end) < 0x7F000000u;
-  const u32* mv_in = ws.r_move;
-  u32* mv_out = ws.tmp[out_slot];
+  const move_t* mv_in = ws.r_move;
+  move_t* mv_out = as_moves(ws.tmp[out_slot]);
   const u32 nbatch = (n + 63) / 64;
   const bool by_id = mv_by_id != nullptr;
   i64 carry_d = 0;
@@ -451,7 +461,9 @@ MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp,
     u32 Mnew = M;
     if (okself) Mnew = P - static_cast<u32>(val + static_cast<i64>(k));
     const bool cross = okself && static_cast<u64>(P) <= start + Mnew;
-    if (act) wave::st_stream(&mv_out[k], (bnd && do_clamp) ? umin(Mnew, P - static_cast<u32>(start)) : Mnew);
+    const u32 Mst = (bnd && do_clamp) ? umin(Mnew, P - static_cast<u32>(start)) : Mnew;
+    if (act) wave::st_stream(&mv_out[k], Mst);
+    if (NARROW_MOVES && wave::any(act && Mst > MOVE_LIMIT)) c.error = ERR_MOVE_RANGE;
     const bool cross_next_in = wave::shfl_up1(cross);
     const bool cross_next = lane > 0 ? cross_next_in : carry_cross;
     const u64 vm = wave::ballot(link && cross_next);
@@ -484,25 +496,27 @@ MODLE_DEV_NOINLINE void adjust_moves_rev(Cell& c, bool do_adjust, bool do_clamp,
       }
       M2u = M1;
       first = false;
-      mv_out[i - 1] = (P1 != UNBOUND && do_clamp) ? umin(M1, static_cast<u32>(P1 - start)) : M1;
+      const u32 Mst = (P1 != UNBOUND && do_clamp) ? umin(M1, static_cast<u32>(P1 - start)) : M1;
+      mv_out[i - 1] = Mst;
+      if (NARROW_MOVES && Mst > MOVE_LIMIT) c.error = ERR_MOVE_RANGE;
     }
     wave::sync_mem();
   }
-  swap_ptr(ws.r_move, ws.tmp[out_slot]);
+  swap_with_scratch(ws.r_move, ws.tmp[out_slot]);
 }
 
 // `out_slot` / `swept`: the scratch array the sweep writes (ws.tmp[out_slot]) and, when the sweep
 // has been done already (adjust_moves_both_x4), the rank its replay starts from
 MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp,
-                                         const u32* mv_by_id = nullptr, u32 out_slot = 0,
+                                         const move_t* mv_by_id = nullptr, u32 out_slot = 0,
                                          const i64* swept = nullptr) {
   Workspace& ws = c.ws;
   const u32 n = wave::uniform(c.n_active);
   const u32 lane = wave::lane();
   const u64 last = static_cast<u64>(c.iv->end) - 1;
   const bool narrow = wave::uniform(c.iv->end) < 0x7F000000u;  // see adjust_moves_rev
-  const u32* mv_in = ws.f_move;
-  u32* mv_out = ws.tmp[out_slot];
+  const move_t* mv_in = ws.f_move;
+  move_t* mv_out = as_moves(ws.tmp[out_slot]);
   const u32 nbatch = (n + 63) / 64;
   const bool by_id = mv_by_id != nullptr;
   i64 carry_d = 0;
@@ -570,7 +584,9 @@ MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp,
     u32 Mnew = M;
     if (okself) Mnew = static_cast<u32>(val + static_cast<i64>(k) - static_cast<i64>(P));
     const bool cross = okself && static_cast<u64>(P) + Mnew > last;
-    if (act) wave::st_stream(&mv_out[k], (bnd && do_clamp) ? umin(Mnew, static_cast<u32>(last - P)) : Mnew);
+    const u32 Mst = (bnd && do_clamp) ? umin(Mnew, static_cast<u32>(last - P)) : Mnew;
+    if (act) wave::st_stream(&mv_out[k], Mst);
+    if (NARROW_MOVES && wave::any(act && Mst > MOVE_LIMIT)) c.error = ERR_MOVE_RANGE;
     const bool cross_prev_in = wave::shfl_up1(cross);
     const bool cross_prev = lane > 0 ? cross_prev_in : carry_cross;
     const u64 vm = wave::ballot(link && cross_prev);
@@ -601,27 +617,30 @@ MODLE_DEV_NOINLINE void adjust_moves_fwd(Cell& c, bool do_adjust, bool do_clamp,
       }
       M1u = M2;
       first = false;
-      mv_out[i] = (P2 != UNBOUND && do_clamp) ? umin(M2, static_cast<u32>(last - P2)) : M2;
+      const u32 Mst = (P2 != UNBOUND && do_clamp) ? umin(M2, static_cast<u32>(last - P2)) : M2;
+      mv_out[i] = Mst;
+      if (NARROW_MOVES && Mst > MOVE_LIMIT) c.error = ERR_MOVE_RANGE;
     }
     wave::sync_mem();
   }
-  swap_ptr(ws.f_move, ws.tmp[out_slot]);
+  swap_with_scratch(ws.f_move, ws.tmp[out_slot]);
 }
 
 // Both sweeps in one loop: they are independent of each other (rev walks the blocks downwards, fwd
 // upwards), so every iteration carries two dependency chains instead of one.
-MODLE_DEV_NOINLINE void adjust_moves_both_x4(Cell& c, const u32* mv_rev, const u32* mv_fwd, i64& viol_rev,
+MODLE_DEV_NOINLINE void adjust_moves_both_x4(Cell& c, const move_t* mv_rev, const move_t* mv_fwd, i64& viol_rev,
                                              i64& viol_fwd) {
   AdjustSweepX4<false> r;
   AdjustSweepX4<true> f;
-  r.init(c, true, true, mv_rev, c.ws.tmp[0]);
-  f.init(c, true, true, mv_fwd, c.ws.tmp[1]);
+  r.init(c, true, true, mv_rev, as_moves(c.ws.tmp[0]));
+  f.init(c, true, true, mv_fwd, as_moves(c.ws.tmp[1]));
   for (u32 t = 0; t < r.nblk; ++t) {
     r.step(t);
     f.step(t);
   }
   viol_rev = r.viol_rank;
   viol_fwd = f.viol_rank;
+  if (NARROW_MOVES && wave::any(r.lane_max > MOVE_LIMIT || f.lane_max > MOVE_LIMIT)) c.error = ERR_MOVE_RANGE;
   // the largest fwd move of the epoch bounds what a fwd unit can contribute to a primary collision
   // (detect_primary's filter pass); unknown when the sequential replay is going to change moves
   c.max_fwd_move = viol_fwd < 0 ? wave::bcast(wave_prefix_max_u32(f.lane_max), 63) : 0xFFFFFFFFu;
@@ -630,8 +649,8 @@ MODLE_DEV_NOINLINE void adjust_moves_both_x4(Cell& c, const u32* mv_rev, const u
 // `all_bound`: every active LEF is bound (the epoch loop's invariant at this point)
 // the move adjustment on the id-ordered moves of ws.tmp[8] (rev) / ws.tmp[9] (fwd)
 MODLE_DEV void phase_adjust_moves_by_id(Cell& c) {
-  u32* mv_rev = c.ws.tmp[8];
-  u32* mv_fwd = c.ws.tmp[9];
+  move_t* mv_rev = as_moves(c.ws.tmp[8]);
+  move_t* mv_fwd = as_moves(c.ws.tmp[9]);
   if (wave::uniform(c.iv->end) < 0x7F000000u) {  // (the 32-bit scans apply: see adjust_moves_rev)
     PHASE(c, 6, i64 vr; i64 vf; adjust_moves_both_x4(c, mv_rev, mv_fwd, vr, vf);
           wave::sync_mem();
@@ -653,8 +672,8 @@ MODLE_DEV void phase_generate_moves(Cell& c, bool burnin_completed, bool all_bou
   }
   // id-ordered moves: two scratch arrays of their own (the helper wave of sim_pair.h fills them
   // while the rank updates use the others)
-  u32* mv_rev = c.ws.tmp[8];
-  u32* mv_fwd = c.ws.tmp[9];
+  move_t* mv_rev = as_moves(c.ws.tmp[8]);
+  move_t* mv_fwd = as_moves(c.ws.tmp[9]);
   PHASE(c, 5, generate_moves_by_id(c, burnin_completed ? p.rev_speed : p.rev_speed_burnin, p.rev_std, mv_rev);
         generate_moves_by_id(c, burnin_completed ? p.fwd_speed : p.fwd_speed_burnin, p.fwd_std, mv_fwd);
         wave::sync_mem());

@@ -115,6 +115,29 @@ struct CellResult {
   u64 sum_active_lefs, sampling_events, sim_epochs;
 };
 
+// Size classes (round 5: fewer bytes per unit and sweep).  The kernels exist twice.  NARROW, the class of every
+// real chromosome: a launch whose largest cell has fewer than 65 536 LEFs and whose moves provably stay below
+// MOVE_LIMIT (modle_hip_size_class, host_logic.cpp) keeps LEF ids and moves as 16-bit values -- the four
+// rank-ordered id / move arrays and the id-ordered moves of an epoch, a third of what the sweeps of an epoch
+// read and write.  WIDE (-DMODLE_WIDE): 32-bit ids and moves, for everything else.  The class is a property of
+// the launch, chosen on the host; results do not depend on it (tests run both).
+#ifdef MODLE_WIDE
+using lefid_t = u32;
+using move_t = u32;
+#else
+using lefid_t = u16;
+using move_t = u16;
+#endif
+// marker left in r_move / f_move by bind: "this unit was (re)bound this epoch"
+constexpr u32 NEW_MARK = static_cast<move_t>(~0u);
+// ... and by the extrusion sweep: "this unit ended up below a unit of lower rank" (moves are
+// bounded by the interval's length -- WIDE -- or by the class's bound -- NARROW --, below both marks)
+constexpr u32 DISP_MARK = NEW_MARK - 1;
+// largest move a unit can hold: a draw or an adjustment beyond it ends the cell with ERR_MOVE_RANGE (the host
+// picks the WIDE class whenever the parameters allow such a move: it cannot happen in a launch it has classed
+// NARROW short of a 40-sigma draw)
+constexpr u32 MOVE_LIMIT = DISP_MARK - 1;
+
 // Per-wave state in device memory (sized for the largest task of the launch).
 //
 // Extrusion units are stored in RANK ORDER (5'->3'), rev and fwd units separately, so that the
@@ -124,8 +147,10 @@ struct CellResult {
 // permutations r_rank / f_rank connecting the views.
 constexpr u32 NUM_TMP = 10;
 struct Workspace {
-  u32 *r_pos, *r_id, *r_move, *r_coll;  // rev units, by rev rank
-  u32 *f_pos, *f_id, *f_move, *f_coll;  // fwd units, by fwd rank
+  u32 *r_pos, *r_coll;  // rev units, by rev rank
+  u32 *f_pos, *f_coll;  // fwd units, by fwd rank
+  lefid_t *r_id, *f_id;     // LEF id of the unit at a rank
+  move_t *r_move, *f_move;  // move of the unit at a rank (or NEW_MARK / DISP_MARK)
   u32 *epoch, *r_rank, *f_rank, *stall; // by LEF id
   u32* tmp[NUM_TMP];                    // L words each
   // rev / fwd position of every LEF in LEF-id order, as of the last evaluation of the burn-in
@@ -141,11 +166,8 @@ struct Workspace {
   u32 capacity_lefs, capacity_barriers;
 };
 constexpr u32 NUM_STATE_ARRAYS = 12 + NUM_TMP + 2;
-// marker left in r_move / f_move by bind: "this unit was (re)bound this epoch"
-constexpr u32 NEW_MARK = 0xFFFFFFFFu;
-// ... and by the extrusion sweep: "this unit ended up below a unit of lower rank" (moves are
-// bounded by the interval's length, far below both marks)
-constexpr u32 DISP_MARK = 0xFFFFFFFEu;
+// (every array keeps a slot of capacity_lefs 32-bit words in both classes: a scratch array serves as positions
+// in one pass and as ids or moves in the next; the NARROW class simply touches half of such a slot)
 
 // LDS-resident (or host-emulated) per-wave context.
 struct WaveLds {

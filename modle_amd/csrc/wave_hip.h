@@ -208,20 +208,20 @@ MODLE_DEV uint64_t clock() { return wall_clock64(); }
 #ifdef MODLE_NT
 template <class T>
 MODLE_DEV T ld_stream(const T* p) { return __builtin_nontemporal_load(p); }
-template <class T>
-MODLE_DEV void st_stream(T* p, T v) { __builtin_nontemporal_store(v, p); }
+template <class T, class V>
+MODLE_DEV void st_stream(T* p, V v) { __builtin_nontemporal_store(static_cast<T>(v), p); }
 #elif defined(MODLE_L1_BYPASS)
 // experiment: the loads of the sweeps go to L2 directly (agent scope: the vector L1 does not look
 // them up, hence cannot stall on a line that is still on its way)
 template <class T>
 MODLE_DEV T ld_stream(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <class T>
-MODLE_DEV void st_stream(T* p, T v) { *p = v; }
+template <class T, class V>
+MODLE_DEV void st_stream(T* p, V v) { *p = static_cast<T>(v); }
 #else
 template <class T>
 MODLE_DEV T ld_stream(const T* p) { return *p; }
-template <class T>
-MODLE_DEV void st_stream(T* p, T v) { *p = v; }
+template <class T, class V>
+MODLE_DEV void st_stream(T* p, V v) { *p = static_cast<T>(v); }
 #endif
 // a value that is the same in every lane by construction, where the compiler cannot see it: keeps
 // it in scalar registers and branches on it scalar (no exchange in the emulator)
@@ -255,6 +255,19 @@ struct alignas(16) U32x4 {
 };
 MODLE_DEV U32x4 ld4(const uint32_t* p, uint32_t k) { return *reinterpret_cast<const U32x4*>(at(p, k)); }
 MODLE_DEV void st4(uint32_t* p, uint32_t k, const U32x4& x) { *reinterpret_cast<U32x4*>(at(p, k)) = x; }
+// the same on arrays of 16-bit values (NARROW class: LEF ids, moves): four consecutive elements as one 64-bit
+// access (p + k 8-byte aligned), widened to / narrowed from 32 bits in registers
+MODLE_DEV U32x4 ld4(const uint16_t* p, uint32_t k) {
+  const U32x2 x = *reinterpret_cast<const U32x2*>(at(p, k));
+  return U32x4{{x.v[0] & 0xFFFFu, x.v[0] >> 16, x.v[1] & 0xFFFFu, x.v[1] >> 16}};
+}
+MODLE_DEV void st4(uint16_t* p, uint32_t k, const U32x4& x) {
+  *reinterpret_cast<U32x2*>(at(p, k)) = U32x2{{x.v[0] | (x.v[1] << 16), x.v[2] | (x.v[3] << 16)}};
+}
+MODLE_DEV U32x2 ld2(const uint16_t* p, uint32_t k) {
+  const uint32_t x = *reinterpret_cast<const uint32_t*>(at(p, k));
+  return U32x2{{x & 0xFFFFu, x >> 16}};
+}
 // Four zeros made on the spot.  A literal {0, 0, 0, 0} is loop-invariant: the optimizer builds it once at
 // the top of the kernel, holds four registers for it through every phase and, when registers run
 // short, SPILLS it -- a 16-byte scratch reload in front of every store of zeros inside the sweeps
@@ -267,17 +280,18 @@ MODLE_DEV U32x4 zero4() {
 // The two halves of ld_sel for loads that are requested one group ahead of their use: LdRaw at
 // the request (no select, hence no wait, behind the load), LdMask where the values are consumed.
 // A loader written as `r.x = op(p, k, ok, dflt, r.x)` serves both.
+// (R: the type of the register the value lands in -- 32 bits also where the array holds 16-bit elements)
 struct LdRaw {
-  template <class T, class D>
-  MODLE_DEV T operator()(const T* p, uint32_t k, bool ok, D dflt, T) const {
+  template <class T, class D, class R>
+  MODLE_DEV R operator()(const T* p, uint32_t k, bool ok, D dflt, R) const {
     (void)dflt;
-    return ld_stream(at(p, ok ? k : 0u));
+    return static_cast<R>(ld_stream(at(p, ok ? k : 0u)));
   }
 };
 struct LdMask {
-  template <class T, class D>
-  MODLE_DEV T operator()(const T*, uint32_t, bool ok, D dflt, T cur) const {
-    return ok ? cur : static_cast<T>(dflt);
+  template <class T, class D, class R>
+  MODLE_DEV R operator()(const T*, uint32_t, bool ok, D dflt, R cur) const {
+    return ok ? cur : static_cast<R>(dflt);
   }
 };
 template <class T, class D>

@@ -104,4 +104,5 @@ class LaunchInfo(C.Structure):
         ("helper_waves", C.c_uint64),
         ("prng_producer_waves", C.c_uint64),
         ("tail_helpers", C.c_uint64),
+        ("size_class", C.c_uint64),
     ]

@@ -15,6 +15,11 @@ u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
 
 def simulate_interval(cfg, start, end, bar_pos, bar_dir, stp_active, stp_inactive, tasks, nrows,
                       ncols, track_occupancy=True, variant=None):
+    from phase_backend import emu_size_class
+
+    # the size class the product would run these cells in (NARROW builds refuse WIDE set-ups)
+    if variant in (None, "philox") and emu_size_class(cfg, max(int(t.num_lefs) for t in tasks)) != 0:
+        variant = "wide" if variant is None else "philox_wide"
     L = emu_lib(variant)
     L.emu_simulate_interval.argtypes = [C.POINTER(Config), C.c_uint64, C.c_uint64, u64p, u8p,
                                         f64p, f64p, C.c_size_t, C.POINTER(Task), C.c_size_t,

@@ -139,8 +139,30 @@ def emu_lib(variant=None):
     return _emu
 
 
+def emu_size_class(cfg, max_lefs, moves=()):
+    """0 = NARROW, 1 = WIDE: the size class the product runs a set-up in (modle_hip_size_class; the emulator's
+    build of host_logic.cpp answers), WIDE also when a caller-supplied move does not fit 16 bits"""
+    L = emu_lib()
+    L.modle_hip_size_class.argtypes = [C.POINTER(Config), C.c_uint64]
+    wide = L.modle_hip_size_class(C.byref(cfg), int(max_lefs)) != 0
+    for m in moves:
+        wide = wide or (len(m) != 0 and int(np.max(m)) > 65533)
+    return 1 if wide else 0
+
+
+def _declare_phases(L):
+    L.emu_test_phases.argtypes = ([C.POINTER(Config), C.c_uint32, C.c_uint64, C.c_uint64,
+                                   C.c_size_t] + [u64p] * 9 +
+                                  [C.c_size_t, u64p, u8p, u8p, C.POINTER(C.c_uint64),
+                                   C.POINTER(C.c_uint64)])
+    L.emu_test_phases.restype = C.c_int
+    return L
+
+
 def emu_phases(cfg, mask, st, state, skip):
     L = emu_lib()
+    if emu_size_class(cfg, st.n, (st.rev_moves, st.fwd_moves)) != 0:
+        L = _declare_phases(emu_lib("wide"))
     prng = (C.c_uint64 * 4)(*_advance(state, skip))
     consumed = C.c_uint64(0)
     rc = L.emu_test_phases(C.byref(cfg), mask, st.start, st.end, st.n, st.rev_pos, st.fwd_pos,

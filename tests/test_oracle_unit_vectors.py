@@ -14,18 +14,26 @@ IDS = [v["name"] for _, v in VECTORS]
 
 def _emu_backend(oracle):
     from modle_amd.params import Config
-    from phase_backend import emu_lib, emu_phases
+    from phase_backend import emu_lib, emu_phases, emu_size_class
 
-    L = emu_lib()
     u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
-    L.emu_test_units.argtypes = [C.POINTER(Config), C.c_uint32, u64p, C.c_size_t, C.c_uint64,
-                                 C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), u64p]
-    L.emu_test_units.restype = C.c_int
+    libs = {}
+
+    def lib(variant):
+        if variant not in libs:
+            L = emu_lib(variant)
+            L.emu_test_units.argtypes = [C.POINTER(Config), C.c_uint32, u64p, C.c_size_t, C.c_uint64,
+                                         C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), u64p]
+            L.emu_test_units.restype = C.c_int
+            libs[variant] = L
+        return libs[variant]
 
     def units(cfg, what, pairs, nrows, ncols, contacts, missed):
         pairs = np.ascontiguousarray(pairs, dtype=np.uint64).reshape(-1)
         out = np.zeros(len(pairs), dtype=np.uint64)
         m = C.c_uint64(missed)
+        # (65 536 elements or more: the WIDE size class, like the product's modle_hip_test_units)
+        L = lib("wide" if emu_size_class(cfg, len(pairs) // 2) != 0 else None)
         rc = L.emu_test_units(C.byref(cfg), what, pairs, len(pairs) // 2, nrows, ncols,
                               contacts.ctypes.data if contacts is not None else None, C.byref(m), out)
         assert rc == 0

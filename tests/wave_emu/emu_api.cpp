@@ -238,6 +238,12 @@ int emu_simulate_interval(const modle_hip_config* cfg, uint64_t start, uint64_t 
     fprintf(stderr, "emu_simulate_interval: %s\n", msg);
     return MODLE_HIP_ERR_ARG;
   }
+#ifndef MODLE_WIDE
+  if (modle_host::size_class_required(*cfg, max_lefs) != 0) {  // (tests/emu_sim.py loads libmodle_emu_wide.so for these)
+    fprintf(stderr, "emu_simulate_interval: this set-up is of the WIDE size class, the build is NARROW\n");
+    return MODLE_HIP_ERR_ARG;
+  }
+#endif
   const Params p = modle_host::make_params(*cfg);
   IntervalImage img(start, end, bar_pos, bar_dir, bar_stp_active, bar_stp_inactive, n_barriers,
                     contacts, nrows, ncols, occupancy);
@@ -299,6 +305,16 @@ int emu_test_phases(const modle_hip_config* cfg, uint32_t phase_mask, uint64_t s
                     uint64_t* fwd_moves, uint64_t* rev_coll, uint64_t* fwd_coll,
                     size_t n_barriers, const uint64_t* bar_pos, const uint8_t* bar_dir,
                     const uint8_t* bar_active, uint64_t prng[4], uint64_t* raws_consumed) {
+  #ifndef MODLE_WIDE
+  {
+    bool wide = modle_host::size_class_required(*cfg, n) != 0;
+    for (size_t i = 0; i < n; ++i) wide = wide || rev_moves[i] > 65533 || fwd_moves[i] > 65533;
+    if (wide) {  // (tests/phase_backend.py loads libmodle_emu_wide.so for these)
+      fprintf(stderr, "emu_test_phases: this state is of the WIDE size class, the build is NARROW\n");
+      return MODLE_HIP_ERR_ARG;
+    }
+  }
+#endif
   const Params p = modle_host::make_params(*cfg);
   IntervalImage img_iv(start, end, bar_pos, bar_dir, nullptr, nullptr, n_barriers, nullptr, 1, 1,
                        nullptr);
@@ -342,6 +358,12 @@ static void unit_body(void* arg) {
 int emu_test_units(const modle_hip_config* cfg, uint32_t what, const uint64_t* in, size_t n,
                    uint64_t nrows, uint64_t ncols, uint32_t* contacts, uint64_t* missed_updates,
                    uint64_t* out) {
+#ifndef MODLE_WIDE
+  if (modle_host::size_class_required(*cfg, n) != 0) {  // (the tests load libmodle_emu_wide.so for these)
+    fprintf(stderr, "emu_test_units: %zu elements are of the WIDE size class, the build is NARROW\n", n);
+    return MODLE_HIP_ERR_ARG;
+  }
+#endif
   const Params p = modle_host::make_params(*cfg);
   uint32_t dummy = 0;
   IntervalImage img(0, 0xFFFFFFF0ull, nullptr, nullptr, nullptr, nullptr, 0,

@@ -252,8 +252,8 @@ MODLE_DEV F64x2 lds_ld2_f64(const double* p) { return F64x2{{p[0], p[1]}}; }
 
 template <class T>
 MODLE_DEV T ld_stream(const T* p) { return *p; }
-template <class T>
-MODLE_DEV void st_stream(T* p, T v) { *p = v; }
+template <class T, class V>
+MODLE_DEV void st_stream(T* p, V v) { *p = static_cast<T>(v); }
 template <class T>
 MODLE_DEV T known_uniform(T v) { return v; }
 // four consecutive words as one 128-bit access: p + k must be 16-byte aligned (k a multiple of 4
@@ -295,6 +295,21 @@ MODLE_DEV U32x4 ld4(const uint32_t* p, uint32_t k) {
   for (int q = 0; q < 4; ++q) x.v[q] = p[k + q];
   return x;
 }
+MODLE_DEV U32x4 ld4(const uint16_t* p, uint32_t k) {
+  MODLE_EMU_DUMMY_LOAD(k);
+  U32x4 x;
+  for (int q = 0; q < 4; ++q) x.v[q] = p[k + q];
+  return x;
+}
+MODLE_DEV void st4(uint16_t* p, uint32_t k, const U32x4& x) {
+  for (int q = 0; q < 4; ++q) p[k + q] = static_cast<uint16_t>(x.v[q]);
+}
+MODLE_DEV U32x2 ld2(const uint16_t* p, uint32_t k) {
+  U32x2 x;
+  x.v[0] = p[k];
+  x.v[1] = p[k + 1];
+  return x;
+}
 MODLE_DEV U32x4 zero4() { return U32x4{{0, 0, 0, 0}}; }
 MODLE_DEV void st4(uint32_t* p, uint32_t k, const U32x4& x) {
   for (int q = 0; q < 4; ++q) p[k + q] = x.v[q];
@@ -303,17 +318,17 @@ MODLE_DEV void st4(uint32_t* p, uint32_t k, const U32x4& x) {
 // the request (no select, hence no wait, behind the load), LdMask where the values are consumed.
 // A loader written as `r.x = op(p, k, ok, dflt, r.x)` serves both.
 struct LdRaw {
-  template <class T, class D>
-  T operator()(const T* p, uint32_t k, bool ok, D dflt, T) const {
+  template <class T, class D, class R>
+  R operator()(const T* p, uint32_t k, bool ok, D dflt, R) const {
     (void)dflt;
     MODLE_EMU_DUMMY_LOAD(k);
-    return ok ? p[k] : static_cast<T>(dflt);
+    return ok ? static_cast<R>(p[k]) : static_cast<R>(dflt);
   }
 };
 struct LdMask {
-  template <class T, class D>
-  T operator()(const T*, uint32_t, bool ok, D dflt, T cur) const {
-    return ok ? cur : static_cast<T>(dflt);
+  template <class T, class D, class R>
+  R operator()(const T*, uint32_t, bool ok, D dflt, R cur) const {
+    return ok ? cur : static_cast<R>(dflt);
   }
 };
 template <class T, class D>
