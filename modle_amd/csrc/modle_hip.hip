@@ -450,7 +450,11 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
   }
   // one workgroup per CU even when there are fewer tasks than waves: the waves that win a task
   // are then spread over all CUs instead of being packed 8 to a CU
-  const int grid = std::max(1, static_cast<int>(std::min<size_t>(h->num_cus, sorted.size())));
+  int grid = std::max(1, static_cast<int>(std::min<size_t>(h->num_cus, sorted.size())));
+  if (const char* g = std::getenv("MODLE_HIP_GRID"); g != nullptr && std::atoi(g) >= 1) {
+    // diagnostic: fewer workgroups than CUs (what do the waves of a CU share, what do the CUs share?)
+    grid = std::min(grid, std::atoi(g));
+  }
   const auto layout = modle_host::workspace_layout(max_lefs, max_barriers, h->params.hist_len);
   const size_t n_slots = static_cast<size_t>(grid) * kWavesPerBlock;
 #if defined(MODLE_EXP_LDS_WS) && !defined(MODLE_EXP_LDS_WS_OFF)
