@@ -568,7 +568,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved is not None else None,
                          "traffic": traffic_bytes, "traffic_source": traffic_source,
-                         "kernel": "modle_simulate_cells",
+                         "kernel": "modle_simulate_cells_wide" if sim.launch_info().get("size_class")
+                                   else "modle_simulate_cells_narrow",
                          "kernel_ms": avg_kernel_s * 1e3 if avg_kernel_s else None,
                          "kernel_ms_per_rank": kernel_ms_per_rank,
                          "algorithmic_bytes_per_launch": step_bytes},
