@@ -76,7 +76,7 @@ def test_no_lane_touches_what_another_wrote_without_a_collective(builds):
 #   more LEFs released than the LDS list holds: overflow of release_lefs, sweeping bind, general rank update
 #     ("mass_release")
 TSAN_REGIMES_R05 = (
-    (["600000", "1", "1", "64", "0", "1", "0.3", "0", "0", "spacing=100", "major=0.7", "minor=0.4"],
+    (["600000", "1", "1", "64", "0", "1", "0.1", "0", "0", "spacing=100", "major=0.7", "minor=0.4"],
      ("lef_bar_trials: rev", "lef_bar_trials: fwd", "(resolved in rounds)")),
     (["120000000", "1", "1", "20", "25000", "1", "0.003"], ("key_cap 1023",)),
     (["120000000", "1", "1", "20", "8000", "1", "0.0008"],
@@ -109,7 +109,7 @@ def test_race_detector_on_the_philox_policy(builds):
     assert rc == 0, out[-2000:]
     exe = os.path.join(EMU, "tsan_emu_philox")
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0")
-    for args in (["2000000", "1", "1", "0", "0", "0", "0.01", "0", "110"],
+    for args in (["2000000", "1", "1", "0", "0", "0", "0.01", "0", "60"],
                  ["30000000", "1", "1", "40", "0", "1", "0.002", "0.3"]):
         run = subprocess.run([exe] + args, capture_output=True, text=True, timeout=1500, env=env)
         assert "ThreadSanitizer" not in run.stderr, run.stderr[:4000]
