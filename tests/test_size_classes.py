@@ -65,6 +65,46 @@ def test_emulated_cells_are_identical_in_both_classes(oracle, monkeypatch, name)
         assert_same_outputs(ref[:3], got[:3], f"{name}, emulator, class {forced or 'as classed'}")
 
 
+def test_a_move_the_narrow_class_cannot_hold_ends_the_cell_with_an_error(monkeypatch):
+    """The host never classes such a launch NARROW; should the rule ever be wrong, the kernel must say so
+    (ERR_MOVE_RANGE -> MODLE_HIP_ERR_STATE) instead of truncating a move.  The NARROW emulator build is made
+    to run a configuration whose moves are 70 kb per epoch."""
+    import ctypes as C
+
+    from modle_amd import api, synthetic
+    from modle_amd.params import CellResult, Config, Task
+    from phase_backend import emu_lib
+
+    cfg = api.make_config(num_cells=4, rev_extrusion_speed=70000, fwd_extrusion_speed=70000,
+                          rev_extrusion_speed_set=1, fwd_extrusion_speed_set=1, max_burnin_epochs=50)
+    ch = synthetic.synthetic_chromosome("chrFast", 6_000_000, seed=3)
+    stp_a, stp_i = api.barrier_stps(cfg, ch["bar_occupancy"])
+    tasks = api.slice_tasks(api.make_tasks(cfg, ch["name"], ch["size"], 0, ch["size"]), 0, 1)
+    nrows, ncols = api.matrix_shape(cfg, ch["size"])
+    L = emu_lib()  # the NARROW build
+    u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+    u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+    f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+    u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+    L.emu_simulate_interval.argtypes = [C.POINTER(Config), C.c_uint64, C.c_uint64, u64p, u8p, f64p, f64p, C.c_size_t,
+                                        C.POINTER(Task), C.c_size_t, u32p, C.c_uint64, C.c_uint64,
+                                        C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(CellResult)]
+    L.emu_simulate_interval.restype = C.c_int
+    contacts = np.zeros(nrows * ncols + 1, dtype=np.uint32)
+    missed = C.c_uint64(0)
+    res = (CellResult * 1)()
+
+    def run():
+        return L.emu_simulate_interval(C.byref(cfg), 0, ch["size"], np.ascontiguousarray(ch["bar_pos"], dtype=np.uint64),
+                                       np.ascontiguousarray(ch["bar_dir"], dtype=np.uint8),
+                                       np.ascontiguousarray(stp_a), np.ascontiguousarray(stp_i), len(ch["bar_pos"]),
+                                       tasks, 1, contacts, nrows, ncols, C.byref(missed), None, res)
+
+    assert run() == api.ERR_ARG  # refused: the set-up is of the WIDE class
+    monkeypatch.setenv("MODLE_EMU_FORCE_NARROW", "1")
+    assert run() == api.ERR_STATE  # run all the same: the first move beyond the limit ends the cell
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["chr20mb_barriers", "dense_barriers_trials", "many_rebinds_per_epoch"])
 def test_gpu_cells_are_identical_in_both_classes(oracle, monkeypatch, name):

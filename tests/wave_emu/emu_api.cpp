@@ -239,7 +239,9 @@ int emu_simulate_interval(const modle_hip_config* cfg, uint64_t start, uint64_t 
     return MODLE_HIP_ERR_ARG;
   }
 #ifndef MODLE_WIDE
-  if (modle_host::size_class_required(*cfg, max_lefs) != 0) {  // (tests/emu_sim.py loads libmodle_emu_wide.so for these)
+  // (MODLE_EMU_FORCE_NARROW=1: tests/test_size_classes.py runs a set-up the rule classes WIDE through the NARROW
+  // code on purpose, to see the net under the rule -- ERR_MOVE_RANGE -- catch it)
+  if (modle_host::size_class_required(*cfg, max_lefs) != 0 && getenv("MODLE_EMU_FORCE_NARROW") == nullptr) {  // (tests/emu_sim.py loads libmodle_emu_wide.so for these)
     fprintf(stderr, "emu_simulate_interval: this set-up is of the WIDE size class, the build is NARROW\n");
     return MODLE_HIP_ERR_ARG;
   }
