@@ -562,14 +562,16 @@ def main():
                        "longest_cell_epochs": longest, "mean_cell_epochs": epochs / max(n_tasks, 1), "seed": 0,
                        "waves_per_cell": launch_mode(sim.launch_info()),
                        "size_class": size_class(sim.launch_info()),
+                       "waves_per_workgroup": sim.launch_info().get("waves_per_workgroup"),
                        "parallelism": f"cells sharded over {world} GPU(s); per-interval "
                                       + ("RCCL" if args.dist_backend == "nccl" else "gloo (host copies)")
                                       + " sum-reduce issued on a side stream as intervals complete"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved is not None else None,
                          "traffic": traffic_bytes, "traffic_source": traffic_source,
-                         "kernel": "modle_simulate_cells_wide" if sim.launch_info().get("size_class")
-                                   else "modle_simulate_cells_narrow",
+                         "kernel": ("modle_simulate_cells_wide" if sim.launch_info().get("size_class")
+                                    else "modle_simulate_cells_narrow")
+                                   + ("12" if sim.launch_info().get("waves_per_workgroup") == 12 else ""),
                          "kernel_ms": avg_kernel_s * 1e3 if avg_kernel_s else None,
                          "kernel_ms_per_rank": kernel_ms_per_rank,
                          "algorithmic_bytes_per_launch": step_bytes},

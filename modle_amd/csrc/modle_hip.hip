@@ -107,7 +107,8 @@ struct modle_hip_handle {
   int device = 0;
   int num_cus = 0;
   std::vector<std::unique_ptr<IntervalRec>> intervals;
-  DevBuf<u64> d_jump;
+  DevBuf<u64> d_jump;    // T^512 (8-wave kernels: blocks of 512 outputs)
+  DevBuf<u64> d_jump12;  // T^256 (12-wave kernels: blocks of 256 outputs)
   DevBuf<f64> d_zig;
   DevBuf<Interval> d_intervals;
   DevBuf<Task> d_tasks;
@@ -193,13 +194,17 @@ modle_hip_handle* modle_hip_create(const modle_hip_config* c, int device, char* 
     h->wait_timeout_s = std::atof(e);
   if (const char* e = std::getenv("MODLE_HIP_DRAIN_TIMEOUT_S"); e != nullptr && std::atof(e) > 0.0)
     h->drain_timeout_s = std::atof(e);
-  const std::vector<uint64_t> jump = modle_host::build_jump_table(RNG_BLOCK);
+  static_assert(RNG_BLOCK == 512, "the host half is compiled with the 8-wave geometry");
+  const std::vector<uint64_t> jump = modle_host::build_jump_table(512);
+  const std::vector<uint64_t> jump12 = modle_host::build_jump_table(256);
   std::vector<f64> zig;
   zig.insert(zig.end(), ZIG_NORM_X, ZIG_NORM_X + 129);
   zig.insert(zig.end(), ZIG_NORM_Y, ZIG_NORM_Y + 129);
   zig.insert(zig.end(), ZIG_EXP_X, ZIG_EXP_X + 257);
   zig.insert(zig.end(), ZIG_EXP_Y, ZIG_EXP_Y + 257);
-  if (h->d_jump.ensure(jump.size()) != hipSuccess || h->d_zig.ensure(zig.size()) != hipSuccess ||
+  if (h->d_jump.ensure(jump.size()) != hipSuccess || h->d_jump12.ensure(jump12.size()) != hipSuccess ||
+      hipMemcpy(h->d_jump12.p, jump12.data(), jump12.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+      h->d_zig.ensure(zig.size()) != hipSuccess ||
       h->d_counter.ensure(1) != hipSuccess || h->d_phase_out.ensure(2) != hipSuccess ||
       hipHostMalloc(reinterpret_cast<void**>(&h->h_abort), 64, hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_abort), h->h_abort, 0) != hipSuccess ||
@@ -456,7 +461,26 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
     grid = std::min(grid, std::atoi(g));
   }
   const auto layout = modle_host::workspace_layout(max_lefs, max_barriers, h->params.hist_len);
-  const size_t n_slots = static_cast<size_t>(grid) * kWavesPerBlock;
+  // Waves per workgroup (round 5): 12 -- three per SIMD, 168 VGPRs, 256-output PRNG blocks, 256-key LDS buffers -- is
+  // worth 1.2 % on a launch that fills the slots and whose epochs re-insert few units (the default parameters: 70 - 134
+  // per epoch on chr1); a launch whose epochs re-insert more than the small buffers hold (BASELINE configs[4]: 600 - 800)
+  // loses 17 % with them, and the fixed roles of a launch that leaves slots empty are laid out for 8.  Expected
+  // re-insertions per epoch and direction ~ LEFs x release probability.  MODLE_HIP_WAVES=8 / 12 forces it.
+  int waves = 8;
+  {
+    const bool paired_launch = sorted.size() <= static_cast<size_t>(grid) * 4;
+    const double p_rel = std::max(h->params.p_release, h->params.p_release_burnin);
+    if (!paired_launch && sorted.size() >= static_cast<size_t>(grid) * 12 && static_cast<double>(max_lefs) * p_rel < 170.0)
+      waves = 12;
+    if (const char* e = std::getenv("MODLE_HIP_WAVES"); e != nullptr && (std::atoi(e) == 8 || std::atoi(e) == 12))
+      waves = std::atoi(e);
+    // (helper-wave mode asked for by name -- tests, A/B runs -- means the kernels that have it)
+    if (const char* pm = std::getenv("MODLE_HIP_PAIRED"); pm != nullptr && pm[0] != '\0' && pm[0] != '0') waves = 8;
+#if defined(MODLE_EXP_LDS_WS) || defined(MODLE_STAGE_TRACE) || (MODLE_WAVES_PER_CU != 8)
+    waves = 8;  // (measurement / diagnostic builds)
+#endif
+  }
+  const size_t n_slots = static_cast<size_t>(grid) * static_cast<size_t>(waves);
 #if defined(MODLE_EXP_LDS_WS) && !defined(MODLE_EXP_LDS_WS_OFF)
   if (layout.u32_words * 4 + layout.u8_bytes + layout.hit_words * 4 > static_cast<size_t>(MODLE_EXP_LDS_WS)) {
     set_err(err, errlen, "measurement build: the cell's state does not fit the LDS slice (" +
@@ -507,7 +531,7 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
   a.params.exp_flags = std::getenv("MODLE_HIP_EXP") != nullptr ? static_cast<u32>(std::atoi(std::getenv("MODLE_HIP_EXP"))) : 0u;
   a.params.exp_pad_ = 0;
 #endif
-  a.tables.jump = h->d_jump.p;
+  a.tables.jump = waves == 12 ? h->d_jump12.p : h->d_jump.p;
   a.tables.zig = h->d_zig.p;
   a.intervals = h->d_intervals.p;
   a.tasks = h->d_tasks.p;
@@ -573,13 +597,13 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
   // MODLE_HIP_PAIRED=0 / 1 turns it off / on whatever the number of tasks (tests, A/B runs)
   a.pair_mains = 0;
   {
-    constexpr size_t kMaxMains = kWavesPerBlock / 2;
-    bool paired = sorted.size() <= static_cast<size_t>(grid) * kMaxMains;
+    constexpr size_t kMaxMains = 4;  // (of the 8 waves of the kernels that know fixed roles)
+    bool paired = waves == 8 && sorted.size() <= static_cast<size_t>(grid) * kMaxMains;
     if (const char* pm = std::getenv("MODLE_HIP_PAIRED"); pm != nullptr && pm[0] != '\0') paired = pm[0] != '0';
 #ifdef MODLE_STAGE_TRACE
     paired = false;  // (the stage trace records the generator position between the phases)
 #endif
-    if (paired)
+    if (paired && waves == 8)
       a.pair_mains = static_cast<u32>(std::min(kMaxMains, (sorted.size() + static_cast<size_t>(grid) - 1) / grid));
   }
   a.tail_helpers = a.pair_mains == 0 ? 1u : 0u;
@@ -590,11 +614,11 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
   a.test_fault = 0;
   if (const char* tf = std::getenv("MODLE_HIP_TEST_FAULT"); tf != nullptr && std::strcmp(tf, "stuck_helper") == 0)
     a.test_fault = TEST_FAULT_STUCK_HELPER;  // (tests/test_gpu_wait_deadline.py)
-  a.active_waves = kWavesPerBlock;
+  a.active_waves = static_cast<u32>(waves);
   if (const char* aw = std::getenv("MODLE_HIP_ACTIVE_WAVES"); aw != nullptr) {
     // diagnostic: how the kernel time scales with the waves in flight per CU
     const int v = std::atoi(aw);
-    if (v >= 1 && v <= kWavesPerBlock) a.active_waves = static_cast<u32>(v);
+    if (v >= 1 && v <= waves) a.active_waves = static_cast<u32>(v);
   }
   {
     // The abort word is cleared, the kernel enqueued and the launch marked as in flight under the
@@ -606,7 +630,11 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
     h->cancelled = false;
     const bool ev0 = hipEventRecord(h->ev_start, h->stream) == hipSuccess;
     const bool wide = modle_hip_size_class(&h->cfg, max_lefs) != 0;
-    if (wide) simulate_wide(grid, h->stream, a); else simulate_narrow(grid, h->stream, a);
+    if (waves == 12) {
+      if (wide) simulate_wide12(grid, h->stream, a); else simulate_narrow12(grid, h->stream, a);
+    } else {
+      if (wide) simulate_wide(grid, h->stream, a); else simulate_narrow(grid, h->stream, a);
+    }
     HIP_TRY(hipGetLastError());
     // The kernel is enqueued: commit the bookkeeping NOW.  Nothing after this point may make the
     // call fail -- a caller that sees an error retries, and the same tasks would then be simulated
@@ -623,7 +651,7 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
     h->last_launch.n_tasks = sorted.size();
     h->last_launch.num_cus = static_cast<uint64_t>(h->num_cus);
     h->last_launch.workgroups = static_cast<uint64_t>(grid);
-    h->last_launch.waves_per_workgroup = kWavesPerBlock;
+    h->last_launch.waves_per_workgroup = static_cast<uint64_t>(waves);
     h->last_launch.main_waves_per_workgroup = a.pair_mains != 0 ? a.pair_mains : a.active_waves;
     h->last_launch.helper_waves = a.pair_mains != 0 ? 1 : 0;
 #ifdef MODLE_RNG_PHILOX

@@ -23,10 +23,20 @@
 using namespace modle_dev;
 using namespace modle_launch;
 
+#if MODLE_WAVES_PER_CU == 8
 #ifdef MODLE_WIDE
 #define MODLE_CLS(x) x##_wide
 #else
 #define MODLE_CLS(x) x##_narrow
+#endif
+#elif MODLE_WAVES_PER_CU == 12
+#ifdef MODLE_WIDE
+#define MODLE_CLS(x) x##_wide12
+#else
+#define MODLE_CLS(x) x##_narrow12
+#endif
+#else
+#error "sim_kernels.hip is built for 8 or 12 waves per workgroup"
 #endif
 
 namespace {
@@ -316,6 +326,7 @@ __global__ __launch_bounds__(kThreadsPerBlock) void MODLE_CLS(modle_simulate_cel
 #endif
 }
 
+#if MODLE_WAVES_PER_CU == 8  // (the phase / unit hooks: one build per size class is enough)
 __global__ __launch_bounds__(64) void MODLE_CLS(modle_test_phases)(PhaseArgs a) {
   __shared__ BlockLds s;
   load_block_tables(s, a.tables, 64);
@@ -349,16 +360,20 @@ __global__ __launch_bounds__(64) void MODLE_CLS(modle_test_units)(UnitArgs a) {
   if (wave::lane() == 0) *a.status_out = st;
 }
 
+#endif
+
 }  // namespace
 
 namespace modle_launch {
 void MODLE_CLS(simulate)(int grid, hipStream_t stream, const SimArgs& a) {
   hipLaunchKernelGGL(MODLE_CLS(modle_simulate_cells), dim3(grid), dim3(kThreadsPerBlock), 0, stream, a);
 }
+#if MODLE_WAVES_PER_CU == 8
 void MODLE_CLS(test_phases)(const PhaseArgs& a) {
   hipLaunchKernelGGL(MODLE_CLS(modle_test_phases), dim3(1), dim3(64), 0, nullptr, a);
 }
 void MODLE_CLS(test_units)(const UnitArgs& a) {
   hipLaunchKernelGGL(MODLE_CLS(modle_test_units), dim3(1), dim3(64), 0, nullptr, a);
 }
+#endif
 }  // namespace modle_launch

@@ -95,13 +95,17 @@ struct UnitArgs {
   u32 n;
 };
 
-// one set per size class (sim_kernels.hip)
-#define MODLE_DECLARE_LAUNCHERS(cls)                                              \
-  void simulate_##cls(int grid, hipStream_t stream, const SimArgs& a);           \
-  void test_phases_##cls(const PhaseArgs& a);                                    \
-  void test_units_##cls(const UnitArgs& a);
-MODLE_DECLARE_LAUNCHERS(narrow)
-MODLE_DECLARE_LAUNCHERS(wide)
-#undef MODLE_DECLARE_LAUNCHERS
+// One set per build of sim_kernels.hip: size class (narrow / wide) x waves per workgroup (8: 256 VGPRs, 512-output
+// PRNG blocks, 512-key LDS buffers; 12: 168 VGPRs, 256-output blocks, 256-key buffers -- round 5: three waves per
+// SIMD are worth 1.2 % on launches whose epochs re-insert few units; modle_hip.hip picks per launch).  The
+// phase / unit test kernels exist in the 8-wave builds only.
+void simulate_narrow(int grid, hipStream_t stream, const SimArgs& a);
+void simulate_wide(int grid, hipStream_t stream, const SimArgs& a);
+void simulate_narrow12(int grid, hipStream_t stream, const SimArgs& a);
+void simulate_wide12(int grid, hipStream_t stream, const SimArgs& a);
+void test_phases_narrow(const PhaseArgs& a);
+void test_phases_wide(const PhaseArgs& a);
+void test_units_narrow(const UnitArgs& a);
+void test_units_wide(const UnitArgs& a);
 
 }  // namespace modle_launch

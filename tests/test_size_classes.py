@@ -131,6 +131,58 @@ def test_gpu_cells_are_identical_in_both_classes(oracle, monkeypatch, name):
         assert_same_outputs(ref[:3], (gc, gm, go if track else None), f"{name}, class {expect}")
 
 
+@pytest.mark.parametrize("name", ["chr20mb_barriers", "many_rebinds_per_epoch", "rebinds_beyond_sort_buffer"])
+def test_emulated_cells_with_the_geometry_of_the_12_wave_kernels(oracle, name):
+    """The kernels exist for 8 and for 12 waves per workgroup (sim_launch.h; the host picks per launch); the
+    12-wave builds halve the PRNG blocks and the LDS key buffers.  The same device code with that geometry on
+    the lane emulator -- one of the cases re-inserts more units per epoch than the small buffers hold -- against
+    the oracle."""
+    import emu_sim
+    from modle_amd import api
+
+    case = build_case(name)
+    cfg, ch = case["cfg"], case["chrom"]
+    tasks = api.slice_tasks(case["tasks"], 0, 1)
+    track = bool(cfg.track_1d_lef_position)
+    ref = oracle.simulate_interval(cfg, ch["start"], ch["end"], ch["bar_pos"], ch["bar_dir"], case["stp_active"],
+                                   case["stp_inactive"], tasks, nthreads=2, track_occupancy=track)
+    got = emu_sim.simulate_interval(cfg, ch["start"], ch["end"], ch["bar_pos"], ch["bar_dir"], case["stp_active"],
+                                    case["stp_inactive"], tasks, case["nrows"], case["ncols"], track_occupancy=track,
+                                    variant="w12")
+    assert_same_results(ref[3], got[3], f"{name}, emulator, 12-wave geometry")
+    assert_same_outputs(ref[:3], got[:3], f"{name}, emulator, 12-wave geometry")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("waves", ["8", "12"])
+@pytest.mark.parametrize("klass", [None, "wide"])
+def test_gpu_all_four_kernels_agree_with_the_oracle(oracle, monkeypatch, waves, klass):
+    """narrow / wide x 8 / 12 waves per workgroup, forced by name, on a launch that fills no slot and on one
+    that leaves tail helpers work to do"""
+    from modle_amd import api
+
+    monkeypatch.setenv("MODLE_HIP_WAVES", waves)
+    if klass:
+        monkeypatch.setenv("MODLE_HIP_SIZE_CLASS", klass)
+    for name, n_cells in (("chr20mb_barriers", 40), ("many_rebinds_per_epoch", 4), ("dense_barriers_trials", 8)):
+        case = build_case(name)
+        cfg, ch = case["cfg"], case["chrom"]
+        tasks = api.slice_tasks(case["tasks"], 0, min(n_cells, len(case["tasks"])))
+        track = bool(cfg.track_1d_lef_position)
+        ref = oracle.simulate_interval(cfg, ch["start"], ch["end"], ch["bar_pos"], ch["bar_dir"], case["stp_active"],
+                                       case["stp_inactive"], tasks, nthreads=8, track_occupancy=track)
+        sim = api.Simulator(cfg, 0)
+        try:
+            gc, gm, go, gres = sim.simulate_interval(ch["start"], ch["end"], ch["bar_pos"], ch["bar_dir"],
+                                                     case["stp_active"], case["stp_inactive"], tasks)
+            info = sim.launch_info()
+        finally:
+            sim.close()
+        assert info["waves_per_workgroup"] == int(waves) and info["size_class"] == (1 if klass else 0), info
+        assert_same_results(ref[3], gres, f"{name}, {waves} waves, class {klass}")
+        assert_same_outputs(ref[:3], (gc, gm, go if track else None), f"{name}, {waves} waves, class {klass}")
+
+
 @pytest.mark.gpu
 def test_gpu_a_fast_extrusion_speed_is_classed_wide_by_itself(oracle, monkeypatch):
     """moves of 70 kb per epoch do not fit 16 bits: the library runs the 32-bit kernels without being told"""
