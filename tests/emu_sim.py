@@ -17,6 +17,10 @@ def simulate_interval(cfg, start, end, bar_pos, bar_dir, stp_active, stp_inactiv
                       ncols, track_occupancy=True, variant=None):
     from phase_backend import emu_size_class
 
+    # MODLE_EMU_VARIANT=w12: campaigns on the geometry of the 12-wave kernels (tools/emu_fuzz_campaign.py)
+    if variant is None and os.environ.get("MODLE_EMU_VARIANT"):
+        variant = os.environ["MODLE_EMU_VARIANT"]
+
     # the size class the product would run these cells in (NARROW builds refuse WIDE set-ups)
     if variant in (None, "philox") and emu_size_class(cfg, max(int(t.num_lefs) for t in tasks)) != 0:
         variant = "wide" if variant is None else "philox_wide"
