@@ -54,3 +54,20 @@ def test_launch_mode_words_follow_the_library_record():
         "main wave + helper + PRNG producer")
     assert bench.launch_mode(dict(helper_waves=1, prng_producer_waves=0, tail_helpers=0)).startswith(
         "main wave + helper (")
+
+
+def test_size_class_words_follow_the_library_record():
+    assert bench.size_class({"size_class": 0}).startswith("narrow (16-bit")
+    assert bench.size_class({"size_class": 1}).startswith("wide (32-bit")
+    assert bench.size_class({}).startswith("narrow")  # (a library older than the field)
+
+
+def test_the_committed_traffic_figure_is_of_the_committed_kernel():
+    """profiles/traffic.json carries the hash of the device sources it was measured on: a change to any file
+    of modle_amd/csrc after the last profile round makes `roofline.traffic` null -- say so here, in the CPU
+    suite, not only on the GPU box."""
+    with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+        table = json.load(f)
+    for key, entry in table.items():
+        assert entry["csrc_sha256"] == csrc_sha256(ROOT), \
+            f"{key}: measured on other device sources -- re-run tools/profile_round.sh + tools/assemble_profile.py"
