@@ -186,7 +186,10 @@ int modle_hip_submit_tasks(modle_hip_handle* h, int interval_id, const modle_hip
  * results do not depend on the mode; the environment variable MODLE_HIP_PAIRED=0 / 1, read at every
  * launch, forces it off / on (tests, A/B measurements).  In a launch that fills the slots, a wave
  * that finds the task queue empty helps a cell of its workgroup that is still running
- * (MODLE_HIP_TAIL_HELPERS=0 turns that off). */
+ * (MODLE_HIP_TAIL_HELPERS=0 turns that off).  Since round 5 the library holds the kernels for 8 and for 12 waves per
+ * workgroup and for 16-bit and 32-bit LEF ids and moves (modle_hip_size_class): a launch that fills the GPU and whose
+ * epochs re-insert few units runs the 12-wave ones; MODLE_HIP_WAVES=8 / 12 and MODLE_HIP_SIZE_CLASS=wide force the
+ * choice (A/B measurements, tests); modle_hip_last_launch_info says what ran.  None of it shows in the results. */
 int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen);
 /* Waits for the launch and collects per-task results (the counterpart of _ctx.shutdown(),
  * scheduler_simulate.cpp:162).  The wait is bounded: when the launch has been running for longer
