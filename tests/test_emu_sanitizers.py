@@ -25,7 +25,7 @@ REGIMES = (["120000000", "1", "1", "20", "25000", "0", "0.002"],
 def builds():
     """the sanitizer builds, side by side (a minute each)"""
     procs = {t: subprocess.Popen(["make", "-C", EMU, t], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-             for t in ("msan_emu", "asan_emu", "tsan_emu", "tsan_emu_philox")}
+             for t in ("msan_emu", "asan_emu", "tsan_emu", "tsan_emu_philox", "tsan_emu_w12")}
     return {t: (p.communicate()[0], p.returncode) for t, p in procs.items()}
 
 
@@ -114,3 +114,22 @@ def test_race_detector_on_the_philox_policy(builds):
         run = subprocess.run([exe] + args, capture_output=True, text=True, timeout=1500, env=env)
         assert "ThreadSanitizer" not in run.stderr, run.stderr[:4000]
         assert run.returncode == 0 and "rc=0" in run.stdout, (run.stdout, run.stderr[-1000:])
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="needs clang++ with ThreadSanitizer")
+def test_race_detector_on_the_geometry_of_the_12_wave_kernels(builds):
+    """round 5: the kernels for 12 waves per workgroup halve the PRNG blocks and the LDS key buffers
+    (-DMODLE_WAVES_PER_CU=12): a rank update that borrows the (smaller) ring for 511 keys, and a burn-in on the
+    256-key sort buffer"""
+    out, rc = builds["tsan_emu_w12"]
+    if rc != 0 and "tsan" in out.lower():
+        pytest.skip("ThreadSanitizer runtime not available")
+    assert rc == 0, out[-2000:]
+    exe = os.path.join(EMU, "tsan_emu_w12")
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0")
+    for args, marker in ((["60000000", "1", "1", "20", "25000", "1", "0.004"], "key_cap 511"),
+                         (["2000000", "1", "1", "0", "0", "0", "0.01", "0", "60"], "key_cap 255")):
+        run = subprocess.run([exe] + args, capture_output=True, text=True, timeout=1500, env=env)
+        assert "ThreadSanitizer" not in run.stderr, run.stderr[:4000]
+        assert run.returncode == 0 and "rc=0" in run.stdout, (run.stdout, run.stderr[-1000:])
+        assert marker in run.stderr, (args, marker, run.stderr[-1500:])
