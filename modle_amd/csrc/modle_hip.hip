@@ -107,8 +107,7 @@ struct modle_hip_handle {
   int device = 0;
   int num_cus = 0;
   std::vector<std::unique_ptr<IntervalRec>> intervals;
-  DevBuf<u64> d_jump;    // T^512 (8-wave kernels: blocks of 512 outputs)
-  DevBuf<u64> d_jump12;  // T^256 (12-wave kernels: blocks of 256 outputs)
+  DevBuf<u64> d_jump;  // T^512 (8-wave kernels: blocks of 512 outputs; 12-wave kernels: pairs of blocks of 256)
   DevBuf<f64> d_zig;
   DevBuf<Interval> d_intervals;
   DevBuf<Task> d_tasks;
@@ -195,15 +194,15 @@ modle_hip_handle* modle_hip_create(const modle_hip_config* c, int device, char* 
   if (const char* e = std::getenv("MODLE_HIP_DRAIN_TIMEOUT_S"); e != nullptr && std::atof(e) > 0.0)
     h->drain_timeout_s = std::atof(e);
   static_assert(RNG_BLOCK == 512, "the host half is compiled with the 8-wave geometry");
+  // (one table for every kernel: the 8-wave kernels hop block by block, 512 outputs; the 12-wave kernels
+  // hop once per pair of their blocks of 256: sim_types.h RNG_HOP)
   const std::vector<uint64_t> jump = modle_host::build_jump_table(512);
-  const std::vector<uint64_t> jump12 = modle_host::build_jump_table(256);
   std::vector<f64> zig;
   zig.insert(zig.end(), ZIG_NORM_X, ZIG_NORM_X + 129);
   zig.insert(zig.end(), ZIG_NORM_Y, ZIG_NORM_Y + 129);
   zig.insert(zig.end(), ZIG_EXP_X, ZIG_EXP_X + 257);
   zig.insert(zig.end(), ZIG_EXP_Y, ZIG_EXP_Y + 257);
-  if (h->d_jump.ensure(jump.size()) != hipSuccess || h->d_jump12.ensure(jump12.size()) != hipSuccess ||
-      hipMemcpy(h->d_jump12.p, jump12.data(), jump12.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+  if (h->d_jump.ensure(jump.size()) != hipSuccess ||
       h->d_zig.ensure(zig.size()) != hipSuccess ||
       h->d_counter.ensure(1) != hipSuccess || h->d_phase_out.ensure(2) != hipSuccess ||
       hipHostMalloc(reinterpret_cast<void**>(&h->h_abort), 64, hipHostMallocMapped) != hipSuccess ||
@@ -531,7 +530,7 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
   a.params.exp_flags = std::getenv("MODLE_HIP_EXP") != nullptr ? static_cast<u32>(std::atoi(std::getenv("MODLE_HIP_EXP"))) : 0u;
   a.params.exp_pad_ = 0;
 #endif
-  a.tables.jump = waves == 12 ? h->d_jump12.p : h->d_jump.p;
+  a.tables.jump = h->d_jump.p;
   a.tables.zig = h->d_zig.p;
   a.intervals = h->d_intervals.p;
   a.tasks = h->d_tasks.p;

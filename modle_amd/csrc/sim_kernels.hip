@@ -93,7 +93,7 @@ struct BlockLds {
   alignas(16) u64 jump[JUMP_TABLE_WORDS];  // rows are read 128 bits at a time
   f64 zig[kZigWords];
   u64 ring[kLdsSlots][RNG_RING];
-  u64 rng_state[kLdsSlots][4 * 64];
+  u64 rng_state[kLdsSlots][RNG_STATE_WORDS];
   u64 rng_snap[kLdsSlots][8];
   u64 sort_keys[kLdsSlots][SORT_LDS_CAP];
   u32 stage[kLdsSlots][STAGE_CAP];

@@ -13,8 +13,8 @@
 //     (layout in sim_types.h / sim_device.h); 32-bit fields throughout.
 //   * The cell's single xoshiro256++ stream is produced in blocks of RNG_BLOCK raw outputs by
 //     all 64 lanes (lane l owns RNG_CHUNK consecutive outputs of every block and hops to its
-//     chunk of the next block with a GF(2) jump table) and consumed strictly in the reference's
-//     order; draws whose raw-output count is data dependent are resolved with a
+//     chunk of the next block with a GF(2) jump table; the 12-wave kernels hop once per pair of
+//     blocks: rng_gen_block_call) and consumed strictly in the reference's order; draws whose raw-output count is data dependent are resolved with a
 //     speculate / verify / restart scheme so the stream position of every draw is exact.
 #pragma once
 #include "sim_types.h"
@@ -184,41 +184,23 @@ MODLE_DEV u64 xo_next(u64& s0, u64& s1, u64& s2, u64& s3) {
   return result;
 }
 
+#ifdef MODLE_RNG_PHILOX
+constexpr u32 RNG_SWZ = RNG_CHUNK;  // (counter based: every lane fills its chunk of every block)
+#else
+constexpr u32 RNG_SWZ = RNG_RUN;
+#endif
 MODLE_DEV u32 ring_index(u64 p) {
   const u32 off = static_cast<u32>(p) & (RNG_BLOCK - 1);
   const u32 blk = (static_cast<u32>(p) / RNG_BLOCK) & 1u;
-  // chunk-local XOR swizzle: lanes writing element t of their chunks hit distinct LDS banks
-  return blk * RNG_BLOCK + (off ^ ((off / RNG_CHUNK) & (RNG_CHUNK - 1)));
+  // run-local XOR swizzle: lanes writing element t of their runs hit distinct LDS banks
+  return blk * RNG_BLOCK + (off ^ ((off / RNG_SWZ) & (RNG_SWZ - 1)));
 }
 
-// Produces one block of the stream: every lane emits its RNG_CHUNK outputs into the ring half
-// `ring_base` and hops to its chunk of the next block (state <- T^RNG_BLOCK * state through the
-// nibble table).  A real call: it is reached from every phase that draws, and its registers
-// stay out of the callers' allocation.
-MODLE_DEV_CALL void rng_gen_block_call(MODLE_LDS u64* ring, const MODLE_LDS u64* jump,
-                                       MODLE_LDS u64* state, MODLE_LDS u64* snap, u32 ring_base) {
-  const u32 lane = wave::lane();
-  u64 a0 = state[0 * 64 + lane], a1 = state[1 * 64 + lane], a2 = state[2 * 64 + lane],
-      a3 = state[3 * 64 + lane];
-  const u64 w[4] = {a0, a1, a2, a3};
-  if (lane == 0) {
-    // lane 0 sits at the first output of the block: the engine state a sequential generator
-    // would have there (rng_final_state recovers the state at any position inside the ring)
-    MODLE_LDS u64* sn = snap + 4 * (ring_base / RNG_BLOCK);
-    sn[0] = a0;
-    sn[1] = a1;
-    sn[2] = a2;
-    sn[3] = a3;
-  }
-  const u32 base = ring_base + RNG_CHUNK * lane;
-#pragma unroll
-  for (u32 t = 0; t < RNG_CHUNK; ++t) {
-    ring[base + (t ^ (lane & (RNG_CHUNK - 1)))] = xo_next(a0, a1, a2, a3);
-  }
-  // T^RNG_BLOCK * state: XOR of one table row (4 words) per state nibble.  Rows are fetched in
-  // groups of four (all loads of a group in flight, then folded; left alone the compiler waits
-  // for every LDS load before issuing the next one), each row as two 128-bit reads, and folded
-  // on 32-bit halves with three-input XORs.
+// T^RNG_HOP * state: XOR of one table row (4 words) per state nibble.  Rows are fetched in groups
+// of four (all loads of a group in flight, then folded; left alone the compiler waits for every LDS
+// load before issuing the next one), each row as two 128-bit reads, and folded on 32-bit halves with
+// three-input XORs.
+MODLE_DEV void rng_hop(const MODLE_LDS u64* jump, const u64 w[4], u64 j[4]) {
   u32 acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   constexpr int GROUP = 4;
 #pragma unroll
@@ -241,12 +223,84 @@ MODLE_DEV_CALL void rng_gen_block_call(MODLE_LDS u64* ring, const MODLE_LDS u64*
     }
     wave::sched_fence();
   }
-  const u64 j0 = (static_cast<u64>(acc[1]) << 32) | acc[0], j1 = (static_cast<u64>(acc[3]) << 32) | acc[2],
-            j2 = (static_cast<u64>(acc[5]) << 32) | acc[4], j3 = (static_cast<u64>(acc[7]) << 32) | acc[6];
-  state[0 * 64 + lane] = j0;
-  state[1 * 64 + lane] = j1;
-  state[2 * 64 + lane] = j2;
-  state[3 * 64 + lane] = j3;
+  j[0] = (static_cast<u64>(acc[1]) << 32) | acc[0];
+  j[1] = (static_cast<u64>(acc[3]) << 32) | acc[2];
+  j[2] = (static_cast<u64>(acc[5]) << 32) | acc[4];
+  j[3] = (static_cast<u64>(acc[7]) << 32) | acc[6];
+}
+
+// Produces one block of the stream into the ring half `ring_base`.  A real call: it is reached from
+// every phase that draws, and its registers stay out of the callers' allocation.
+//   RNG_SPLIT == 1 (8-wave kernels): every lane emits its RNG_CHUNK outputs and hops to its chunk
+//     of the next block (state <- T^RNG_BLOCK * state through the nibble table).
+//   RNG_SPLIT == 2 (12-wave kernels): blocks come in pairs (ring half 0, then ring half 1; the
+//     callers alternate, starting with half 0).  Half 0: lanes 0-31 emit their runs of RNG_RUN
+//     outputs, and EVERY lane hops from the start of its run by T^RNG_HOP -- lanes 0-31 keep the
+//     result as their state, lanes 32-63 park it (they have not emitted yet).  Half 1: lanes 32-63
+//     emit their runs and take the parked states.  One hop per 512 outputs instead of two.
+MODLE_DEV_CALL void rng_gen_block_call(MODLE_LDS u64* ring, const MODLE_LDS u64* jump,
+                                       MODLE_LDS u64* state, MODLE_LDS u64* snap, u32 ring_base) {
+  const u32 lane = wave::lane();
+  u64 a0 = state[0 * 64 + lane], a1 = state[1 * 64 + lane], a2 = state[2 * 64 + lane],
+      a3 = state[3 * 64 + lane];
+  const u64 w[4] = {a0, a1, a2, a3};
+  if constexpr (RNG_SPLIT == 2) {
+    const bool second = wave::uniform(ring_base) != 0;
+    MODLE_LDS u64* park = state + 4 * 64;
+    if (lane == (second ? 32u : 0u)) {
+      // this lane sits at the first output of the block: the engine state a sequential generator
+      // would have there (rng_final_state recovers the state at any position inside the ring)
+      MODLE_LDS u64* sn = snap + (second ? 4 : 0);
+      sn[0] = a0;
+      sn[1] = a1;
+      sn[2] = a2;
+      sn[3] = a3;
+    }
+    if ((lane >= 32) == second) {
+      const u32 base = ring_base + RNG_RUN * (lane & 31u);
+#pragma unroll
+      for (u32 t = 0; t < RNG_RUN; ++t) {
+        ring[base + (t ^ (lane & (RNG_RUN - 1)))] = xo_next(a0, a1, a2, a3);
+      }
+    }
+    if (second) {
+      if (lane >= 32) {
+#pragma unroll
+        for (u32 k = 0; k < 4; ++k) state[k * 64 + lane] = park[k * 32 + (lane - 32)];
+      }
+      return;
+    }
+    u64 j[4];
+    rng_hop(jump, w, j);
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) {
+      if (lane < 32) {
+        state[k * 64 + lane] = j[k];
+      } else {
+        park[k * 32 + (lane - 32)] = j[k];
+      }
+    }
+    return;
+  }
+  if (lane == 0) {
+    // lane 0 sits at the first output of the block
+    MODLE_LDS u64* sn = snap + 4 * (ring_base / RNG_BLOCK);
+    sn[0] = a0;
+    sn[1] = a1;
+    sn[2] = a2;
+    sn[3] = a3;
+  }
+  const u32 base = ring_base + RNG_CHUNK * lane;
+#pragma unroll
+  for (u32 t = 0; t < RNG_CHUNK; ++t) {
+    ring[base + (t ^ (lane & (RNG_CHUNK - 1)))] = xo_next(a0, a1, a2, a3);
+  }
+  u64 j[4];
+  rng_hop(jump, w, j);
+  state[0 * 64 + lane] = j[0];
+  state[1 * 64 + lane] = j[1];
+  state[2 * 64 + lane] = j[2];
+  state[3 * 64 + lane] = j[3];
 }
 
 // Philox4x32-10 (the round function of the PHILOX generator policy below; compiled into every
@@ -310,9 +364,9 @@ MODLE_DEV void rng_gen_block(Rng& g) {
 MODLE_DEV void rng_init(Rng& g, const u64 state[4]) {
   const u32 lane = wave::lane();
   u64 s0 = state[0], s1 = state[1], s2 = state[2], s3 = state[3];
-  // lane l starts RNG_CHUNK * l outputs into the stream
-  for (u32 k = 0; k < RNG_CHUNK * 63; ++k) {
-    if (k < RNG_CHUNK * lane) (void)xo_next(s0, s1, s2, s3);
+  // lane l starts at its run (RNG_SPLIT == 1: chunk) of the first block (pair of blocks)
+  for (u32 k = 0; k < RNG_RUN * 63; ++k) {
+    if (k < RNG_RUN * lane) (void)xo_next(s0, s1, s2, s3);
   }
   wave::lockstep();
   g.state[0 * 64 + lane] = s0;
@@ -400,11 +454,12 @@ MODLE_DEV void rng_final_state(const Rng& g, u64 out[4]) {
   const u64 q = g.pos / RNG_BLOCK;
   u64 s0, s1, s2, s3;
   if (q * RNG_BLOCK == g.gen_end) {
-    // next block: lane 0's chunk starts there
-    s0 = wave::uniform(g.state[0 * 64]);
-    s1 = wave::uniform(g.state[1 * 64]);
-    s2 = wave::uniform(g.state[2 * 64]);
-    s3 = wave::uniform(g.state[3 * 64]);
+    // next block: lane 0's chunk starts there (the second block of a pair: lane 32's run)
+    const u32 first = (RNG_SPLIT == 2 && (q & 1u) != 0) ? 32u : 0u;
+    s0 = wave::uniform(g.state[0 * 64 + first]);
+    s1 = wave::uniform(g.state[1 * 64 + first]);
+    s2 = wave::uniform(g.state[2 * 64 + first]);
+    s3 = wave::uniform(g.state[3 * 64 + first]);
   } else {
     const u32 b = static_cast<u32>(q & 1u);
     s0 = wave::uniform(g.snap[4 * b + 0]);

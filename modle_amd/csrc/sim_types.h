@@ -47,6 +47,15 @@ constexpr u32 CS_LOOP = 4u;
 constexpr u32 RNG_CHUNK = MODLE_WAVES_PER_CU > 8 ? 4 : 8;
 constexpr u32 RNG_BLOCK = 64 * RNG_CHUNK;      // raws per block
 constexpr u32 RNG_RING = 2 * RNG_BLOCK;        // raws held in LDS per wave
+// The hop to the next block costs twice what a block of 256 outputs costs to emit, so the 12-wave
+// kernels (whose ring holds two blocks of 256) hop once per TWO blocks: a lane owns a run of
+// RNG_RUN = 8 consecutive outputs of a super-block of 512, lanes 0-31 emit theirs into the first
+// block of the pair (and every lane hops, by T^512), lanes 32-63 theirs into the second, their
+// hopped states parked in the meantime (32 x 4 words behind the lane states).
+constexpr u32 RNG_SPLIT = MODLE_WAVES_PER_CU > 8 ? 2 : 1;  // blocks per hop
+constexpr u32 RNG_RUN = RNG_CHUNK * RNG_SPLIT;             // consecutive outputs a lane owns
+constexpr u32 RNG_HOP = RNG_BLOCK * RNG_SPLIT;             // the jump table is T^RNG_HOP
+constexpr u32 RNG_STATE_WORDS = 4 * 64 + (RNG_SPLIT == 2 ? 4 * 32 : 0);
 constexpr u32 JUMP_TABLE_WORDS = 64 * 16 * 4;  // u64 words (32 KiB)
 
 // Parameters of the path, digested once on the host from modle_hip_config.
@@ -172,8 +181,8 @@ constexpr u32 NUM_STATE_ARRAYS = 12 + NUM_TMP + 2;
 // LDS-resident (or host-emulated) per-wave context.
 struct WaveLds {
   u64* ring;              // RNG_RING raws
-  u64* rng_state;         // xoshiro256++ state of every lane: 4 x 64 words (word-major)
-  const u64* jump_table;  // T^RNG_BLOCK nibble table
+  u64* rng_state;         // xoshiro256++ state of every lane: 4 x 64 words (word-major) [+ 4 x 32 parked: RNG_SPLIT]
+  const u64* jump_table;  // T^RNG_HOP nibble table
   const f64* zig_norm_x;  // 129
   const f64* zig_norm_y;  // 129
   const f64* zig_exp_x;   // 257

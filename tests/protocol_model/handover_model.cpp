@@ -164,7 +164,7 @@ std::atomic<bool> g_failed{false};
 // everything one main wave owns on the device: its LDS (ring, lane states, snapshots, staging) and
 // its slice of the workspace
 struct WaveMemory {
-  std::vector<u64> ring = std::vector<u64>(RNG_RING, 0), state = std::vector<u64>(4 * 64, 0), snap = std::vector<u64>(8, 0);
+  std::vector<u64> ring = std::vector<u64>(RNG_RING, 0), state = std::vector<u64>(RNG_STATE_WORDS, 0), snap = std::vector<u64>(8, 0);
   std::vector<u64> sort = std::vector<u64>(SORT_LDS_CAP, 0);
   std::vector<u32> stage = std::vector<u32>(STAGE_CAP, 0);
   std::vector<u32> arr[24];
@@ -522,7 +522,7 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "usage: %s fixed|dynamic|stuck [rounds]\n", argv[0]);
     return 2;
   }
-  g_jump = modle_host::build_jump_table(RNG_BLOCK);
+  g_jump = modle_host::build_jump_table(RNG_HOP);
   const std::string mode = argv[1];
   if (mode == "fixed") return mode_fixed(0);
   if (mode == "stuck") return mode_fixed(TEST_FAULT_STUCK_HELPER);

@@ -59,9 +59,9 @@ struct LdsImage {
   }
   LdsImage()
       : ring(RNG_RING),
-        rng_state(4 * 64),
+        rng_state(RNG_STATE_WORDS),
         rng_snap(8),
-        jump(modle_host::build_jump_table(RNG_BLOCK)),
+        jump(modle_host::build_jump_table(RNG_HOP)),
         sort_lds(SORT_LDS_CAP),
         stage(STAGE_CAP) {
     // on the device these scratch regions start with whatever the previous kernel left there
