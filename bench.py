@@ -44,6 +44,16 @@ def launch_mode(info):
     return "one wave per cell" + (", idle waves help in the tail of the launch" if info["tail_helpers"] else "")
 
 
+def workspace_placement(info):
+    """what the library's placement search did when it allocated the per-wave workspace (include/modle_hip.h:
+    modle_hip_launch_info; once per handle, outside the timed region unless --warmup 0)"""
+    tries = info.get("workspace_tries", 0)
+    if not tries:
+        return "first allocation (no search)"
+    return {"candidates_probed": tries, "probe_ms_kept": info.get("workspace_probe_us", 0) / 1e3,
+            "probe_ms_slowest": info.get("workspace_probe_worst_us", 0) / 1e3}
+
+
 def size_class(info):
     return "wide (32-bit LEF ids and moves)" if info.get("size_class") else "narrow (16-bit LEF ids and moves)"
 
@@ -563,6 +573,7 @@ def main():
                        "waves_per_cell": launch_mode(sim.launch_info()),
                        "size_class": size_class(sim.launch_info()),
                        "waves_per_workgroup": sim.launch_info().get("waves_per_workgroup"),
+                       "workspace_placement": workspace_placement(sim.launch_info()),
                        "parallelism": f"cells sharded over {world} GPU(s); per-interval "
                                       + ("RCCL" if args.dist_backend == "nccl" else "gloo (host copies)")
                                       + " sum-reduce issued on a side stream as intervals complete"},

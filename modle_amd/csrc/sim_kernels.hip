@@ -364,6 +364,42 @@ __global__ __launch_bounds__(64) void MODLE_CLS(modle_test_units)(UnitArgs a) {
 
 }  // namespace
 
+#if MODLE_WAVES_PER_CU == 8 && !defined(MODLE_WIDE)
+namespace {
+// The memory side of a launch without its arithmetic: every wave streams `reps` times through the first `hot` bytes of
+// `n_arrays` arrays of its own workspace slot (128-bit loads, a store to every fourth array).  The host times it on a
+// freshly allocated workspace to learn which of the placements the driver handed out (modle_hip.hip: place_workspace).
+__global__ __launch_bounds__(768) void modle_probe_workspace(char* base, size_t slot_stride, u32 waves_per_block, size_t array_stride,
+                                                             u32 n_arrays, u32 hot, u32 reps) {
+  const u32 wave_in_block = threadIdx.x / 64, lane = threadIdx.x % 64;
+  if (wave_in_block >= waves_per_block) return;
+  char* slot = base + (static_cast<size_t>(blockIdx.x) * waves_per_block + wave_in_block) * slot_stride;
+  u32 acc = 0;
+  for (u32 r = 0; r < reps; ++r) {
+    for (u32 k = 0; k < n_arrays; ++k) {
+      uint4* arr = reinterpret_cast<uint4*>(slot + k * array_stride);
+      for (u32 off = lane; off < hot / 16; off += 64) {
+        uint4 v = arr[off];
+        acc += v.x ^ v.y ^ v.z ^ v.w;
+        if ((k & 3u) == (r & 3u)) {
+          v.x += 1;
+          arr[off] = v;
+        }
+      }
+    }
+  }
+  if (acc == 0x12345678u) *reinterpret_cast<u32*>(slot) = acc;  // (keeps the loads; the workspace holds nothing yet)
+}
+}  // namespace
+namespace modle_launch {
+void probe_workspace(char* base, size_t slot_stride, u32 n_blocks, u32 waves_per_block, size_t array_stride, u32 n_arrays, u32 hot,
+                     u32 reps, hipStream_t stream) {
+  hipLaunchKernelGGL(modle_probe_workspace, dim3(n_blocks), dim3(64 * waves_per_block), 0, stream, base, slot_stride,
+                     waves_per_block, array_stride, n_arrays, hot, reps);
+}
+}  // namespace modle_launch
+#endif
+
 namespace modle_launch {
 void MODLE_CLS(simulate)(int grid, hipStream_t stream, const SimArgs& a) {
   hipLaunchKernelGGL(MODLE_CLS(modle_simulate_cells), dim3(grid), dim3(kThreadsPerBlock), 0, stream, a);

@@ -107,5 +107,8 @@ void test_phases_narrow(const PhaseArgs& a);
 void test_phases_wide(const PhaseArgs& a);
 void test_units_narrow(const UnitArgs& a);
 void test_units_wide(const UnitArgs& a);
+// (sim_kernels.hip, NARROW 8-wave build: the streaming probe behind modle_hip.hip's place_workspace)
+void probe_workspace(char* base, size_t slot_stride, u32 n_blocks, u32 waves_per_block, size_t array_stride, u32 n_arrays, u32 hot,
+                     u32 reps, hipStream_t stream);
 
 }  // namespace modle_launch

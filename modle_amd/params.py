@@ -105,4 +105,7 @@ class LaunchInfo(C.Structure):
         ("prng_producer_waves", C.c_uint64),
         ("tail_helpers", C.c_uint64),
         ("size_class", C.c_uint64),
+        ("workspace_tries", C.c_uint64),
+        ("workspace_probe_us", C.c_uint64),
+        ("workspace_probe_worst_us", C.c_uint64),
     ]
