@@ -590,7 +590,7 @@ def main():
         if use_dist:
             prediction = None
             try:
-                with open(os.path.join(ROOT, "profiles", "r05zz", "scale_prediction.json")) as f:
+                with open(os.path.join(ROOT, "profiles", "r05zs", "scale_prediction.json")) as f:
                     prediction = json.load(f)
             except (OSError, ValueError):
                 pass

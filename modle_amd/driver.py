@@ -218,7 +218,7 @@ def check_distinct_devices(devices, world):
 
 
 def scaling_report(world, scaling, total_cells, cells_per_gpu, reduce_ms, prediction=None):
-    """The keys an N > 1 line adds.  `prediction`: the parsed profiles/r05zz/scale_prediction.json
+    """The keys an N > 1 line adds.  `prediction`: the parsed profiles/r05zs/scale_prediction.json
     (one-GPU rehearsal of the strong-scaling job: every rank's shard run one after the other), or None.
     Strong scaling at the predicted job size: the predicted speed-up over N = 1 (with the reduce serial
     behind the kernel); weak scaling: N minus the same serial reduce, i.e. what `value` should be a multiple of
@@ -248,7 +248,7 @@ def scaling_report(world, scaling, total_cells, cells_per_gpu, reduce_ms, predic
                     pred = {"predicted_speedup": world * w["max_kernel_ms"] / (w["max_kernel_ms"] + red),
                             "predicted_speedup_kernel_only": float(world)}
             if pred is not None:
-                pred["prediction_source"] = ("profiles/r05zz/scale_prediction.json (one-GPU rehearsal, "
+                pred["prediction_source"] = ("profiles/r05zs/scale_prediction.json (one-GPU rehearsal, "
                                              "unmeasured on multi-GPU hardware)")
     out["predicted"] = pred
     return out

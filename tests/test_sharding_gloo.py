@@ -124,7 +124,7 @@ def test_scaling_report_labels_the_job_and_quotes_the_prediction():
 
     from modle_amd import driver
 
-    with open(os.path.join(ROOT, "profiles", "r05zz", "scale_prediction.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r05zs", "scale_prediction.json")) as f:
         pred = json.load(f)
     strong = driver.scaling_report(8, "strong", 16384, 2048, 11.5, pred)
     assert strong["scaling"] == "strong" and strong["total_cells"] == 16384 and strong["cells_per_gpu"] == 2048
