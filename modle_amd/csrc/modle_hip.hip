@@ -579,6 +579,11 @@ int modle_hip_launch(modle_hip_handle* h, void* stream, char* err, size_t errlen
   }
 #endif
   HIP_TRY(place_workspace(h, layout.total_bytes, grid, waves));
+  if (const char* e = std::getenv("MODLE_HIP_POISON_WORKSPACE"); e != nullptr && e[0] != '\0' && e[0] != '0') {
+    // tests: a cell must not depend on what its workspace slot held before (fresh device memory is usually zero, the
+    // placement probe and earlier cells leave anything): every byte 0xA5 before the launch
+    HIP_TRY(hipMemsetAsync(h->d_workspace.p, 0xA5, layout.total_bytes * n_slots, h->stream));
+  }
   if (h->remaining_cap < ivs.size()) {
     if (h->h_remaining != nullptr) (void)hipHostFree(h->h_remaining);
     h->h_remaining = nullptr;

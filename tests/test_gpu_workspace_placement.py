@@ -51,3 +51,31 @@ def test_gpu_the_search_runs_once_per_workspace_and_changes_no_result(oracle, mo
         assert_same_outputs(ref[:3], (gc, gm, go if track else None), "without the placement search")
     finally:
         sim.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["chr20mb_barriers", "dense_barriers_trials", "many_rebinds_per_epoch"])
+def test_gpu_cells_do_not_depend_on_what_the_workspace_held(oracle, monkeypatch, name):
+    """Fresh device memory is usually zero, the placement probe writes into the candidates it times, earlier
+    cells leave their state behind: MODLE_HIP_POISON_WORKSPACE=1 sets every byte of the workspace to 0xA5 before
+    the launch, in both launch modes and with 8 and 12 waves per workgroup; results against the oracle."""
+    from modle_amd import api
+
+    case = build_case(name)
+    cfg, ch = case["cfg"], case["chrom"]
+    track = bool(cfg.track_1d_lef_position)
+    monkeypatch.setenv("MODLE_HIP_POISON_WORKSPACE", "1")
+    for n_cells, waves in ((6, "8"), (40, "8"), (40, "12")):
+        tasks = api.slice_tasks(case["tasks"], 0, min(n_cells, len(case["tasks"])))
+        ref = oracle.simulate_interval(cfg, ch["start"], ch["end"], ch["bar_pos"], ch["bar_dir"], case["stp_active"],
+                                       case["stp_inactive"], tasks, nthreads=8, track_occupancy=track)
+        monkeypatch.setenv("MODLE_HIP_WAVES", waves)
+        sim = api.Simulator(cfg, 0)
+        try:
+            gc, gm, go, gres = sim.simulate_interval(ch["start"], ch["end"], ch["bar_pos"], ch["bar_dir"],
+                                                     case["stp_active"], case["stp_inactive"], tasks)
+        finally:
+            sim.close()
+        what = f"{name}, {len(tasks)} cells, {waves} waves, poisoned workspace"
+        assert_same_results(ref[3], gres, what)
+        assert_same_outputs(ref[:3], (gc, gm, go if track else None), what)
