@@ -218,7 +218,7 @@ typedef struct modle_hip_launch_info {
   uint64_t size_class;               /* 0: NARROW kernels (16-bit LEF ids and moves), 1: WIDE (modle_hip_size_class) */
   /* Placement of the per-wave workspace (a launch runs up to 6 % faster or slower depending on which physical pages
    * the driver handed out for it; when the workspace is allocated the library probes up to MODLE_HIP_WORKSPACE_TRIES
-   * (default 8; 1 = no search) candidate allocations with a streaming kernel and keeps the fastest: DESIGN.md): */
+   * (default 24; 1 = no search) candidate allocations with a streaming kernel and keeps the fastest: DESIGN.md): */
   uint64_t workspace_tries;          /* candidates probed when the current workspace was allocated (0: no probe ran) */
   uint64_t workspace_probe_us;       /* the probe's duration on the candidate that was kept, microseconds ... */
   uint64_t workspace_probe_worst_us; /* ... and on the slowest candidate */

@@ -391,8 +391,10 @@ int modle_hip_submit_tasks(modle_hip_handle* h, int interval_id, const modle_hip
 // 0.605 / 0.66 / 0.69 ms on the three of them and told which speed the next launch would run at in 100 % of the
 // cases measured.  So a workspace that has to be allocated is allocated up to `tries` times, each candidate behind a
 // small hole of another size, probed (three repetitions, the fastest counts), and the best one is kept; the search
-// ends early once both a fast and a slow placement have been seen (10 % apart).  One-time cost per handle and
-// workspace size: tens of milliseconds.  MODLE_HIP_WORKSPACE_TRIES=1 switches the search off.
+// ends early once both a fast and a slow placement have been seen (10 % apart).  A draw costs 2.3 ms and is fast one
+// time in three on some boxes and one time in six on others (profiles/r05zr/ws_search_strategies_last_run.txt: holding
+// the losers or other hole sizes change nothing), hence 24: at most 55 ms, once per handle and workspace size.
+// MODLE_HIP_WORKSPACE_TRIES=1 switches the search off.
 static hipError_t place_workspace(modle_hip_handle* h, size_t slot_stride, int grid, int waves) {
   const size_t bytes = slot_stride * static_cast<size_t>(grid) * static_cast<size_t>(waves);
   if (bytes <= h->d_workspace.n) return hipSuccess;  // (large enough, and chosen when it was allocated)
@@ -401,7 +403,7 @@ static hipError_t place_workspace(modle_hip_handle* h, size_t slot_stride, int g
   h->ws_probe_ms = h->ws_probe_worst_ms = 0.0f;
   hipError_t e = h->d_workspace.ensure(bytes);
   if (e != hipSuccess) return e;
-  int tries = 8;
+  int tries = 24;
   if (const char* t = std::getenv("MODLE_HIP_WORKSPACE_TRIES"); t != nullptr && std::atoi(t) >= 1) tries = std::min(std::atoi(t), 64);
   if (tries <= 1) return hipSuccess;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -444,7 +446,7 @@ static hipError_t place_workspace(modle_hip_handle* h, size_t slot_stride, int g
       best = ms;
       h->d_workspace.swap(cand);
     }
-    if (best <= 0.9f * worst) break;
+    if (best <= 0.895f * worst) break;
   }
   h->ws_probe_ms = best < 1e29f ? best : 0.0f;
   h->ws_probe_worst_ms = worst < 1e29f ? worst : 0.0f;
