@@ -2,7 +2,7 @@
 # Fresh processes of the product with and without the workspace placement search (modle_hip.hip: place_workspace).
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05search; mkdir -p $O; cd $R
 for i in 1 2 3 4 5 6 7 8 9 10; do
-  t=8; [ $((i % 3)) = 0 ] && t=1
+  t=24; [ $((i % 3)) = 0 ] && t=1
   MODLE_HIP_WORKSPACE_TRIES=$t timeout -k 10 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} > $O/p$i.json 2> $O/p$i.err
   python3 -c "
 import json
