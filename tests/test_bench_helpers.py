@@ -62,6 +62,30 @@ def test_size_class_words_follow_the_library_record():
     assert bench.size_class({}).startswith("narrow")  # (a library older than the field)
 
 
+def test_workspace_placement_words_follow_the_library_record():
+    """`config.workspace_placement` of the bench line: what `modle_hip_launch_info` says the placement search saw
+    (include/modle_hip.h), microseconds turned into ms; a library record without a search reads as such"""
+    assert bench.workspace_placement({"workspace_tries": 0}) == "first allocation (no search)"
+    assert bench.workspace_placement({}) == "first allocation (no search)"
+    got = bench.workspace_placement({"workspace_tries": 12, "workspace_probe_us": 604, "workspace_probe_worst_us": 699})
+    assert got == {"candidates_probed": 12, "probe_ms_kept": 0.604, "probe_ms_slowest": 0.699}
+
+
+def test_the_launch_info_record_mirrors_the_header():
+    """the ctypes mirror of `modle_hip_launch_info` has the header's fields in the header's order"""
+    import os
+    import re
+
+    from modle_amd.params import LaunchInfo
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "include", "modle_hip.h")) as f:
+        text = f.read()
+    body = text[text.index("typedef struct modle_hip_launch_info {"):text.index("} modle_hip_launch_info;")]
+    fields = re.findall(r"^\s*uint64_t\s+(\w+);", body, flags=re.M)
+    assert fields == [name for name, _ in LaunchInfo._fields_]
+
+
 def test_the_committed_traffic_figure_is_of_the_committed_kernel():
     """profiles/traffic.json carries the hash of the device sources it was measured on: a change to any file
     of modle_amd/csrc after the last profile round makes `roofline.traffic` null -- say so here, in the CPU
