@@ -580,6 +580,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS if achieved is not None else None,
                          "traffic": traffic_bytes, "traffic_source": traffic_source,
+                         # (what the committed counters say this kernel really moves per second of THIS run's launches:
+                         # the launch is limited by that rate -- 5.7 TB/s is what its 3 072 waves reach when they only
+                         # stream through their slots, profiles/r05zs/probe_counters.txt -- while `frac` prices the
+                         # algorithmic bytes)
+                         "traffic_GBps": (traffic_bytes / avg_kernel_s / 1e9
+                                          if traffic_bytes is not None and avg_kernel_s else None),
                          "kernel": ("modle_simulate_cells_wide" if sim.launch_info().get("size_class")
                                     else "modle_simulate_cells_narrow")
                                    + ("12" if sim.launch_info().get("waves_per_workgroup") == 12 else ""),
